@@ -1,0 +1,171 @@
+/* lvbgpu.h - C ABI of the MI355X-native Fitch parsimony scoring path for LVB.
+ *
+ * This is the drop-in boundary for ONE path of phylolvb/lvb: tree evaluation (getplen) and the
+ * packed state-set data it drives.  The search host (SA schedule, NNI/SPR/TBR proposals,
+ * treestack) stays on the CPU and calls through this header; everything behind it is
+ * hand-written HIP for gfx950 (lvb_amd/csrc/).  No CPU fallback exists: every entry point that
+ * needs the device returns LVBGPU_E_NODEVICE / LVBGPU_E_HIP when it is missing.
+ *
+ * Reference interfaces replaced (file:line under the reference's src/):
+ *   LVB.h:187  long getplen(Dataptr, TREESTACK_TREE_NODES*, Parameters, long root, long*, long*, int*)
+ *              -> lvbgpu_getplen_compat()            (strict, stateless, B = 1)
+ *              -> lvbgpu_set_tree()/lvbgpu_score_batch()/lvbgpu_commit()  (resident, batched)
+ *   LVB.h:188-189 alloc_memory_to_getplen / free_memory_to_getplen -> nothing to allocate; the
+ *              C++ adapter (lvb_amd/csrc/getplen_adapter.cpp) keeps them for link compatibility
+ *   LVB.h:235  DNAToBinary(Dataptr, Lvb_bit_length**)  -> lvbgpu_encode_text()/lvbgpu_create_from_text()
+ *   LVB.h:228  words_per_row(long)                     -> lvbgpu_words_per_row()
+ *   LVB.h:222  ss_init(Dataptr, tree, enc_mat)         -> lvbgpu_create() (leaf rows become resident)
+ *   TreeOperations.c:88-103 make_dirty_below + the "sitestate[0]==0 means dirty" convention
+ *              -> candidates are *edits* (node, new left, new right); the library derives the
+ *                 dirty set (edited nodes + their ancestors below the root) itself
+ *
+ * Data conventions (identical to the reference):
+ *   - n taxa, nodes 0..n-1 are leaves (leaf i = taxon i), n..2n-4 internal; every index is in
+ *     the tree; the tree is rooted at a leaf `root` whose record holds the two top children.
+ *   - a state-set row is nwords uint64 words, 16 sites per word, nibble k of word j = site
+ *     16j+k, bit0=A bit1=C bit2=G bit3=T (LVB.h:73-76); positions >= m hold 0xF.
+ *   - children of a leaf other than the root are LVBGPU_UNSET (-1).
+ *
+ * Error convention: every function returns LVBGPU_OK (0) or a negative code and never exits;
+ * the reference's "FATAL ERROR ... exit(1)" convention (Error.c:49-67) is reproduced only by
+ * the C++ adapter that carries the reference's own getplen signature.
+ *
+ * Threading: a context is bound to one device and owns one HIP stream; it is not thread-safe
+ * (the reference's callers are single-threaded and non-reentrant).
+ */
+#ifndef LVBGPU_H
+#define LVBGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVBGPU_UNSET (-1)
+
+enum lvbgpu_status
+{
+    LVBGPU_OK = 0,
+    LVBGPU_E_ARG = -1,       /* bad argument (null pointer, size out of range) */
+    LVBGPU_E_NODEVICE = -2,  /* no usable HIP device / HIP runtime not functional */
+    LVBGPU_E_HIP = -3,       /* a HIP call failed; see lvbgpu_last_error() */
+    LVBGPU_E_NOMEM = -4,     /* host or device allocation failed */
+    LVBGPU_E_STATE = -5,     /* call order violated (e.g. score before set_tree) */
+    LVBGPU_E_TOPOLOGY = -6,  /* arrays/edits do not describe a binary tree rooted at a leaf */
+    LVBGPU_E_SYMBOL = -7,    /* alignment text holds a symbol DNAToBinary rejects */
+    LVBGPU_E_ZEROLEN = -8,   /* computed length <= 0 (the reference asserts > 0, TreeEvaluation.c:267) */
+    LVBGPU_E_COMM = -9       /* RCCL communicator failure */
+};
+
+typedef struct lvbgpu_ctx lvbgpu_ctx;
+typedef struct lvbgpu_batch lvbgpu_batch;
+
+/* One child-pair rewrite relative to the resident current tree: node `node` gets children
+ * (left, right).  An NNI is 2 edits, an SPR 3, a TBR 3 + the re-rooted path inside the moved
+ * subtree, a re-root the path between old and new root (the old root leaf gets (-1,-1)). */
+typedef struct
+{
+    int32_t node;
+    int32_t left;
+    int32_t right;
+} lvbgpu_edit;
+
+/* what one batch costs (for the roofline line): all counts are per launch of the batch */
+typedef struct
+{
+    int64_t candidates;   /* B */
+    int64_t combines;     /* sum over candidates of (D + 2) word-combines per word */
+    int64_t rows_read;    /* sum over candidates of (D + 3) clean rows read */
+    int64_t dirty_nodes;  /* sum over candidates of D */
+    int64_t max_stack;    /* deepest operand stack any candidate needs */
+    int64_t algorithmic_bytes; /* rows_read * nwords * 8 */
+} lvbgpu_batch_stats;
+
+/* ---- library / device --------------------------------------------------------------- */
+const char *lvbgpu_strerror(int status);
+const char *lvbgpu_last_error(const lvbgpu_ctx *ctx); /* text of the last failing HIP/RCCL call */
+int lvbgpu_device_count(void);                        /* >= 0, or a negative status */
+int lvbgpu_abi_version(void);
+
+/* ---- encoding (DataOperations.c:164-249, 446-467) ------------------------------------ */
+long lvbgpu_words_per_row(long m);
+/* text rows (upper-case, m chars each) -> packed rows on the device, copied to out[n][nwords].
+ * Returns LVBGPU_E_SYMBOL for a character the reference would crash() on (235-241). */
+int lvbgpu_encode_text(int device, long n, long m, const char *const *rows, uint64_t *out);
+
+/* ---- context: alignment resident in HBM ---------------------------------------------- */
+/* leaf_matrix: host pointer, n rows of nwords words, row i at leaf_matrix + i*row_stride_words */
+int lvbgpu_create(lvbgpu_ctx **out, int device, long n, long nwords, const uint64_t *leaf_matrix,
+                  long row_stride_words);
+int lvbgpu_create_from_text(lvbgpu_ctx **out, int device, long n, long m, const char *const *rows);
+void lvbgpu_destroy(lvbgpu_ctx *ctx);
+long lvbgpu_n(const lvbgpu_ctx *ctx);
+long lvbgpu_nwords(const lvbgpu_ctx *ctx);
+
+/* ---- resident current tree ------------------------------------------------------------ */
+/* Full evaluation (every internal node recomputed: getplen's all-dirty case after ss_init /
+ * lvb_reroot, TreeEvaluation.c:204-264) of the tree given by child arrays of 2n-3 entries;
+ * node sets and per-node `changes` become resident.  *length_out = tree length. */
+int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32_t *right, int32_t root,
+                    int64_t *length_out);
+int lvbgpu_current_length(lvbgpu_ctx *ctx, int64_t *length_out);
+int lvbgpu_get_topology(lvbgpu_ctx *ctx, int32_t *parent, int32_t *left, int32_t *right, int32_t *root);
+int lvbgpu_get_changes(lvbgpu_ctx *ctx, int64_t *changes /* [2n-3]; leaves hold 0 */);
+int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out /* [nwords] */);
+
+/* ---- batched incremental scoring -------------------------------------------------------
+ * Candidate b is the current tree with edits[edit_offsets[b] .. edit_offsets[b+1]) applied and
+ * rooted at roots[b] (roots == NULL or roots[b] < 0: same root).  Length semantics are
+ * getplen's incremental case: only dirty nodes are recomputed, clean nodes contribute their
+ * cached `changes` (TreeEvaluation.c:191-202); nothing resident is modified.            */
+int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets,
+                       const lvbgpu_edit *edits, const int32_t *roots, int64_t *lengths_out);
+
+/* the same in three steps, so a batch can stay resident and be re-launched (benchmarks) or be
+ * overlapped with host work: build (host: dirty sets + postorder programs; H2D), launch
+ * (asynchronous on the context's stream), lengths (synchronise + D2H). */
+int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets,
+                       const lvbgpu_edit *edits, const int32_t *roots, lvbgpu_batch **out);
+int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *batch);
+int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *batch, int64_t *lengths_out);
+int lvbgpu_batch_get_stats(const lvbgpu_batch *batch, lvbgpu_batch_stats *out);
+void lvbgpu_batch_free(lvbgpu_batch *batch);
+
+/* B whole topologies scored from the leaf rows alone (every internal node recomputed, nothing
+ * resident read or written): left/right are [B][2n-3]. */
+int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *left, const int32_t *right,
+                            const int32_t *roots, int64_t *lengths_out);
+
+/* Accept a candidate (SwapTrees after getplen, Solve.c:323/370): apply the edits to the
+ * resident tree, recompute its dirty nodes' sets and per-node changes in place. */
+int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit *edits, int32_t root,
+                  int64_t *length_out);
+
+/* ---- strict compatibility: the reference's own tree block ------------------------------
+ * `tree` is the reference's BranchArray: 2n-3 records of 40 bytes {long parent,left,right,
+ * changes; uint64_t *sitestate} (LVB.h:121-128).  Dirty == sitestate[0]==0.  Recomputes the
+ * dirty nodes on the device and writes their sets and `changes` back into the host block, so
+ * the caller's next treecopy/getplen sees exactly what the reference would have left there.
+ * Stateless with respect to the resident tree (operand rows are uploaded per call). */
+int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree, long root, int64_t *length_out);
+
+/* ---- timing on the context's stream (HIP events) -------------------------------------- */
+int lvbgpu_timer_start(lvbgpu_ctx *ctx);
+int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms); /* synchronises */
+int lvbgpu_synchronize(lvbgpu_ctx *ctx);
+void *lvbgpu_stream(lvbgpu_ctx *ctx); /* hipStream_t, for interop */
+
+/* ---- multi-GPU: best length over independent restarts (one context per process/GPU) ----
+ * id is an opaque 128-byte RCCL unique id created on rank 0 and distributed by the launcher. */
+int lvbgpu_comm_unique_id(void *id128);
+int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const void *id128);
+int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value /* in: local best, out: global best */,
+                         int32_t *argmin_rank /* may be NULL */);
+int lvbgpu_comm_destroy(lvbgpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVBGPU_H */

@@ -1,0 +1,328 @@
+"""Python face of the C ABI in include/lvbgpu.h (ctypes; no torch types cross the boundary).
+
+Mirrors the reference's call surface for the path: ``FitchContext.getplen(...)`` family instead of
+``getplen(Dataptr, TREESTACK_TREE_NODES*, ...)`` (reference LVB.h:187).  Everything here calls
+into lvb_amd/liblvbgpu.so; if that library (or a HIP device) is missing the call raises
+``LvbGpuError`` - there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "liblvbgpu.so"
+
+UNSET = -1
+
+
+class LvbGpuError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"lvbgpu error {status}: {message}")
+        self.status = status
+
+
+class Edit(C.Structure):
+    _fields_ = [("node", C.c_int32), ("left", C.c_int32), ("right", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("candidates", C.c_int64), ("combines", C.c_int64), ("rows_read", C.c_int64),
+                ("dirty_nodes", C.c_int64), ("max_stack", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+
+
+EDIT_DTYPE = np.dtype([("node", np.int32), ("left", np.int32), ("right", np.int32)])
+
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+# every symbol include/lvbgpu.h declares: (restype, argtypes)
+SIGNATURES = {
+    "lvbgpu_strerror": (C.c_char_p, [C.c_int]),
+    "lvbgpu_last_error": (C.c_char_p, [C.c_void_p]),
+    "lvbgpu_device_count": (C.c_int, []),
+    "lvbgpu_abi_version": (C.c_int, []),
+    "lvbgpu_words_per_row": (C.c_long, [C.c_long]),
+    "lvbgpu_encode_text": (C.c_int, [C.c_int, C.c_long, C.c_long, C.POINTER(C.c_char_p), _u64p]),
+    "lvbgpu_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_long, _u64p, C.c_long]),
+    "lvbgpu_create_from_text": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_long, C.c_long, C.POINTER(C.c_char_p)]),
+    "lvbgpu_destroy": (None, [C.c_void_p]),
+    "lvbgpu_n": (C.c_long, [C.c_void_p]),
+    "lvbgpu_nwords": (C.c_long, [C.c_void_p]),
+    "lvbgpu_set_tree": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int32, C.POINTER(C.c_int64)]),
+    "lvbgpu_current_length": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "lvbgpu_get_topology": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, C.POINTER(C.c_int32)]),
+    "lvbgpu_get_changes": (C.c_int, [C.c_void_p, _i64p]),
+    "lvbgpu_get_sets": (C.c_int, [C.c_void_p, C.c_int32, _u64p]),
+    "lvbgpu_score_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_void_p, C.c_void_p, _i64p]),
+    "lvbgpu_batch_build": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "lvbgpu_batch_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lvbgpu_batch_lengths": (C.c_int, [C.c_void_p, C.c_void_p, _i64p]),
+    "lvbgpu_batch_get_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
+    "lvbgpu_batch_free": (None, [C.c_void_p]),
+    "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
+    "lvbgpu_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "lvbgpu_getplen_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_int64)]),
+    "lvbgpu_timer_start": (C.c_int, [C.c_void_p]),
+    "lvbgpu_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "lvbgpu_synchronize": (C.c_int, [C.c_void_p]),
+    "lvbgpu_stream": (C.c_void_p, [C.c_void_p]),
+    "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "lvbgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lvbgpu_allreduce_min": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "lvbgpu_comm_destroy": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load liblvbgpu.so or raise: the HIP library is the product, nothing stands in for it."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise LvbGpuError(-2, f"{LIB_PATH} is not built (run `python -m lvb_amd.build`); "
+                              "lvb_amd has no CPU fallback")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    lib = load_library()
+    c = lib.lvbgpu_device_count()
+    if c < 0:
+        raise LvbGpuError(c, (lib.lvbgpu_last_error(None) or b"").decode())
+    return c
+
+
+def words_per_row(m: int) -> int:
+    return int(load_library().lvbgpu_words_per_row(m))
+
+
+def _edits_array(edits) -> np.ndarray:
+    arr = np.ascontiguousarray(edits)
+    if arr.dtype != EDIT_DTYPE:
+        arr = np.ascontiguousarray(np.asarray(edits, dtype=np.int32).reshape(-1, 3)).view(EDIT_DTYPE).reshape(-1)
+    return arr
+
+
+def encode_text(rows: list[bytes], device: int = 0) -> np.ndarray:
+    """DNAToBinary on the device (reference DataOperations.c:164-249)."""
+    lib = load_library()
+    n, m = len(rows), len(rows[0])
+    out = np.zeros((n, lib.lvbgpu_words_per_row(m)), dtype=np.uint64)
+    arr = (C.c_char_p * n)(*rows)
+    rc = lib.lvbgpu_encode_text(device, n, m, arr, out)
+    if rc != 0:
+        raise LvbGpuError(rc, (lib.lvbgpu_last_error(None) or b"").decode())
+    return out
+
+
+class Batch:
+    """A resident batch of candidate programs (lvbgpu_batch)."""
+
+    def __init__(self, ctx: "FitchContext", handle: C.c_void_p, B: int):
+        self.ctx, self.h, self.B = ctx, handle, B
+
+    def launch(self) -> None:
+        self.ctx._chk(self.ctx.lib.lvbgpu_batch_launch(self.ctx.h, self.h))
+
+    def lengths(self) -> np.ndarray:
+        out = np.zeros(self.B, dtype=np.int64)
+        self.ctx._chk(self.ctx.lib.lvbgpu_batch_lengths(self.ctx.h, self.h, out))
+        return out
+
+    def stats(self) -> dict:
+        st = BatchStats()
+        self.ctx._chk(self.ctx.lib.lvbgpu_batch_get_stats(self.h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in BatchStats._fields_}
+
+    def free(self) -> None:
+        if self.h:
+            self.ctx.lib.lvbgpu_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FitchContext:
+    """One alignment resident on one MI355X, plus (optionally) a resident current tree."""
+
+    def __init__(self, leaf_matrix: np.ndarray | None = None, *, text_rows: list[bytes] | None = None,
+                 device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if leaf_matrix is not None:
+            m = np.ascontiguousarray(leaf_matrix, dtype=np.uint64)
+            n, nwords = m.shape
+            rc = self.lib.lvbgpu_create(C.byref(h), device, n, nwords, m, nwords)
+        elif text_rows is not None:
+            n, mm = len(text_rows), len(text_rows[0])
+            arr = (C.c_char_p * n)(*text_rows)
+            rc = self.lib.lvbgpu_create_from_text(C.byref(h), device, n, mm, arr)
+        else:
+            raise ValueError("leaf_matrix or text_rows required")
+        if rc != 0:
+            raise LvbGpuError(rc, (self.lib.lvbgpu_last_error(None) or b"").decode()
+                              or self.lib.lvbgpu_strerror(rc).decode())
+        self.h = h
+        self.n = int(self.lib.lvbgpu_n(h))
+        self.nwords = int(self.lib.lvbgpu_nwords(h))
+        self.nbranches = 2 * self.n - 3
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            msg = (self.lib.lvbgpu_last_error(self.h) or b"").decode() or self.lib.lvbgpu_strerror(rc).decode()
+            raise LvbGpuError(rc, msg)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.lvbgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- resident tree
+    def set_tree(self, left, right, root: int) -> int:
+        l = np.ascontiguousarray(left, dtype=np.int32)
+        r = np.ascontiguousarray(right, dtype=np.int32)
+        out = C.c_int64()
+        self._chk(self.lib.lvbgpu_set_tree(self.h, l, r, int(root), C.byref(out)))
+        return out.value
+
+    def current_length(self) -> int:
+        out = C.c_int64()
+        self._chk(self.lib.lvbgpu_current_length(self.h, C.byref(out)))
+        return out.value
+
+    def topology(self):
+        nb = self.nbranches
+        p, l, r = (np.zeros(nb, dtype=np.int32) for _ in range(3))
+        root = C.c_int32()
+        self._chk(self.lib.lvbgpu_get_topology(self.h, p, l, r, C.byref(root)))
+        return p, l, r, root.value
+
+    def changes(self) -> np.ndarray:
+        out = np.zeros(self.nbranches, dtype=np.int64)
+        self._chk(self.lib.lvbgpu_get_changes(self.h, out))
+        return out
+
+    def sets(self, node: int) -> np.ndarray:
+        out = np.zeros(self.nwords, dtype=np.uint64)
+        self._chk(self.lib.lvbgpu_get_sets(self.h, int(node), out))
+        return out
+
+    def all_sets(self) -> np.ndarray:
+        return np.stack([self.sets(i) for i in range(self.nbranches)])
+
+    # ---- batches of candidates (edits relative to the resident tree)
+    @staticmethod
+    def _pack(cands, roots):
+        offs = np.zeros(len(cands) + 1, dtype=np.int32)
+        flat = []
+        for i, e in enumerate(cands):
+            e = _edits_array(e)
+            flat.append(e)
+            offs[i + 1] = offs[i] + len(e)
+        edits = np.concatenate(flat) if flat and offs[-1] > 0 else np.zeros(0, dtype=EDIT_DTYPE)
+        rts = None if roots is None else np.ascontiguousarray(roots, dtype=np.int32)
+        return offs, np.ascontiguousarray(edits), rts
+
+    def score_batch(self, cands, roots=None) -> np.ndarray:
+        offs, edits, rts = self._pack(cands, roots)
+        out = np.zeros(len(cands), dtype=np.int64)
+        self._chk(self.lib.lvbgpu_score_batch(self.h, len(cands), offs, edits.ctypes.data,
+                                               None if rts is None else rts.ctypes.data, out))
+        return out
+
+    def build_batch(self, cands, roots=None) -> Batch:
+        offs, edits, rts = self._pack(cands, roots)
+        bh = C.c_void_p()
+        self._chk(self.lib.lvbgpu_batch_build(self.h, len(cands), offs, edits.ctypes.data,
+                                               None if rts is None else rts.ctypes.data, C.byref(bh)))
+        return Batch(self, bh, len(cands))
+
+    def score_full_batch(self, lefts, rights, roots=None) -> np.ndarray:
+        l = np.ascontiguousarray(lefts, dtype=np.int32)
+        r = np.ascontiguousarray(rights, dtype=np.int32)
+        B = l.shape[0]
+        rts = None if roots is None else np.ascontiguousarray(roots, dtype=np.int32)
+        out = np.zeros(B, dtype=np.int64)
+        self._chk(self.lib.lvbgpu_score_full_batch(self.h, B, l.reshape(-1), r.reshape(-1),
+                                                    None if rts is None else rts.ctypes.data, out))
+        return out
+
+    def commit(self, edits, root: int = -1) -> int:
+        e = _edits_array(edits)
+        out = C.c_int64()
+        self._chk(self.lib.lvbgpu_commit(self.h, len(e), e.ctypes.data, int(root), C.byref(out)))
+        return out.value
+
+    # ---- strict compat on a reference-layout tree block
+    def getplen_compat(self, tree_block, root: int) -> int:
+        out = C.c_int64()
+        ptr = tree_block if isinstance(tree_block, int) else C.cast(tree_block, C.c_void_p)
+        self._chk(self.lib.lvbgpu_getplen_compat(self.h, ptr, int(root), C.byref(out)))
+        return out.value
+
+    # ---- timing / sync
+    def timer_start(self) -> None:
+        self._chk(self.lib.lvbgpu_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.lvbgpu_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self) -> None:
+        self._chk(self.lib.lvbgpu_synchronize(self.h))
+
+    # ---- multi-GPU
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes) -> None:
+        buf = C.create_string_buffer(unique_id, 128)
+        self._chk(self.lib.lvbgpu_comm_init(self.h, nranks, rank, buf))
+
+    def allreduce_min(self, value: int) -> tuple[int, int]:
+        v = C.c_int64(value)
+        who = C.c_int32()
+        self._chk(self.lib.lvbgpu_allreduce_min(self.h, C.byref(v), C.byref(who)))
+        return v.value, who.value
+
+
+def comm_unique_id() -> bytes:
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.lvbgpu_comm_unique_id(buf)
+    if rc != 0:
+        raise LvbGpuError(rc, (lib.lvbgpu_last_error(None) or b"").decode())
+    return buf.raw
+
+
+def edits_between(cur_left, cur_right, new_left, new_right) -> np.ndarray:
+    """The child-pair rewrites that turn one topology into another (same node numbering)."""
+    cl, cr = np.asarray(cur_left), np.asarray(cur_right)
+    nl, nr = np.asarray(new_left), np.asarray(new_right)
+    # a node whose two children merely swapped sides is unchanged (Fitch is symmetric)
+    changed = np.nonzero((np.minimum(cl, cr) != np.minimum(nl, nr)) | (np.maximum(cl, cr) != np.maximum(nl, nr)))[0]
+    out = np.zeros(len(changed), dtype=EDIT_DTYPE)
+    out["node"] = changed
+    out["left"] = nl[changed]
+    out["right"] = nr[changed]
+    return out

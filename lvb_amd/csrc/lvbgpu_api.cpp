@@ -1,0 +1,1105 @@
+// lvbgpu_api.cpp - the C ABI of include/lvbgpu.h over the HIP kernels (fitch_kernels.hip) and
+// the host-side program builder (program.cpp).  Compiled by hipcc into lvb_amd/liblvbgpu.so.
+//
+// There is deliberately no CPU implementation of any scoring entry point in this file: without
+// a working HIP device every one of them fails with LVBGPU_E_NODEVICE / LVBGPU_E_HIP.
+#include "../../include/lvbgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "program.hpp"
+
+using namespace lvbgpu;
+
+namespace
+{
+
+constexpr int ABI_VERSION = 1;
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// growable device buffer
+struct DevBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)4096);
+        want = want + want / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// growable pinned host buffer
+struct PinBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)4096);
+        want = want + want / 4;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// the reference's node record (LVB.h:121-128), as the strict-compat entry sees it
+struct RefNode
+{
+    long parent, left, right, changes;
+    uint64_t *sitestate;
+};
+static_assert(sizeof(RefNode) == 40, "reference node record is 40 bytes");
+
+// RCCL is loaded on demand so that the scoring library does not depend on it at load time
+struct Id128
+{
+    char bytes[128]; // ncclUniqueId
+};
+struct Rccl
+{
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128 /* ncclUniqueId by value */, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+} // namespace
+
+struct lvbgpu_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    long n = 0, nwords = 0;
+    int32_t nb = 0;
+    uint32_t stride_words = 0, stride4 = 0, ntiles = 0;
+
+    uint64_t *d_rows = nullptr;              // [nb][stride_words]
+    unsigned long long *d_changes = nullptr; // [nb + 1]; slot nb = the two root combines
+    long long *d_scalars = nullptr;          // [0] S_all, [1] current length
+    bool have_tree = false;
+    int64_t cur_length = 0;
+
+    Topology topo;
+    ProgramBuilder pb;
+
+    DevBuf d_prog, d_len; // scratch for single-program launches (set_tree, commit)
+    PinBuf h_pin;
+    DevBuf d_cin, d_cout; // strict-compat arenas
+    PinBuf h_cin, h_cout;
+    std::vector<int32_t> slot_of;
+    std::vector<uint32_t> slot_epoch;
+    uint32_t slot_gen = 0;
+
+    void *comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    DevBuf d_comm;
+
+    std::string last_error;
+
+    int fail_hip(hipError_t e, const char *what)
+    {
+        last_error = std::string(what) + ": " + hipGetErrorString(e);
+        return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+                   ? LVBGPU_E_NODEVICE
+                   : (e == hipErrorOutOfMemory ? LVBGPU_E_NOMEM : LVBGPU_E_HIP);
+    }
+    int fail(int code, const std::string &why)
+    {
+        last_error = why;
+        return code;
+    }
+};
+
+struct lvbgpu_batch
+{
+    lvbgpu_ctx *ctx = nullptr;
+    int32_t B = 0;
+    DevBuf d_prog; // [cands][toks][dsts]
+    DevBuf d_len;
+    size_t off_toks = 0, off_dsts = 0;
+    lvbgpu_batch_stats stats{};
+    bool full_mode = false; // whole topologies: reads leaf rows only
+};
+
+#define HIPCHK(ctx, call)                                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e__ = (call);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return (ctx)->fail_hip(e__, #call);                                                                        \
+    } while (0)
+
+namespace
+{
+
+static Rccl g_rccl;
+static thread_local std::string g_last_error_noctx;
+
+int hip_status_noctx(hipError_t e, const char *what)
+{
+    g_last_error_noctx = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+               ? LVBGPU_E_NODEVICE
+               : (e == hipErrorOutOfMemory ? LVBGPU_E_NOMEM : LVBGPU_E_HIP);
+}
+
+// pack programs -> one host blob [CandDesc x B][toks][dsts] (16-byte aligned sections)
+struct Packed
+{
+    std::vector<CandDesc> cands;
+    std::vector<uint32_t> toks;
+    std::vector<int32_t> dsts;
+    int32_t max_stack = 0;
+    int64_t dirty = 0;
+    void add(const Program &p, size_t tok0, size_t dst0, long long base, uint32_t flags)
+    {
+        CandDesc cd{};
+        cd.tok_off = (uint32_t)tok0;
+        cd.ntok = (uint32_t)(p.toks.size() - tok0);
+        cd.dst_off = (uint32_t)dst0;
+        cd.ncomb = (uint32_t)(p.dsts.size() - dst0);
+        cd.base = base;
+        cd.flags = flags;
+        cands.push_back(cd);
+    }
+};
+
+size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+int upload_program(lvbgpu_ctx *ctx, DevBuf &dev, const std::vector<CandDesc> &cands,
+                   const std::vector<uint32_t> &toks, const std::vector<int32_t> &dsts, size_t *off_toks,
+                   size_t *off_dsts)
+{
+    const size_t o_t = align16(cands.size() * sizeof(CandDesc));
+    const size_t o_d = o_t + align16(toks.size() * 4);
+    const size_t total = o_d + align16(dsts.size() * 4);
+    HIPCHK(ctx, dev.reserve(total));
+    HIPCHK(ctx, ctx->h_pin.reserve(total));
+    char *h = (char *)ctx->h_pin.p;
+    memcpy(h, cands.data(), cands.size() * sizeof(CandDesc));
+    memcpy(h + o_t, toks.data(), toks.size() * 4);
+    memcpy(h + o_d, dsts.data(), dsts.size() * 4);
+    HIPCHK(ctx, hipMemcpyAsync(dev.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+    // h_pin is reused by the next upload: make sure the copy has left it
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *off_toks = o_t;
+    *off_dsts = o_d;
+    return LVBGPU_OK;
+}
+
+WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, size_t off_dsts, void *d_len,
+                       uint32_t B, int32_t max_stack)
+{
+    WalkArgs a{};
+    a.rows_in = (const uint4 *)ctx->d_rows;
+    a.rows_out = (uint4 *)ctx->d_rows;
+    a.cands = (const CandDesc *)prog.p;
+    a.toks = (const uint32_t *)((const char *)prog.p + off_toks);
+    a.dsts = (const int32_t *)((const char *)prog.p + off_dsts);
+    a.node_changes = (const long long *)ctx->d_changes;
+    a.s_all = ctx->d_scalars;
+    a.len_out = (unsigned long long *)d_len;
+    a.changes_out = ctx->d_changes;
+    a.in_stride4 = ctx->stride4;
+    a.out_stride4 = ctx->stride4;
+    a.B = B;
+    a.ntiles = ctx->ntiles;
+    a.nitems = B * ctx->ntiles;
+    a.stack_depth = (uint32_t)std::max(max_stack, 1);
+    a.root_slot = (uint32_t)ctx->nb;
+    return a;
+}
+
+int check_depth(lvbgpu_ctx *ctx, int32_t max_stack)
+{
+    if ((size_t)max_stack * WALK_WAVES * 64 * sizeof(uint4) > MAX_LDS_BYTES)
+        return ctx->fail(LVBGPU_E_ARG, "postorder program needs a deeper operand stack than LDS holds");
+    return LVBGPU_OK;
+}
+
+int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
+{
+    if (n < 3 || nwords < 1 || 2 * n - 3 > MAX_ROWS)
+        return ctx->fail(LVBGPU_E_ARG, "n or nwords out of range");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return ctx->fail(LVBGPU_E_NODEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return ctx->fail(LVBGPU_E_ARG, "device index out of range");
+    ctx->device = device;
+    HIPCHK(ctx, hipSetDevice(device));
+    ctx->n = n;
+    ctx->nwords = nwords;
+    ctx->nb = (int32_t)(2 * n - 3);
+    ctx->stride_words = round_up((uint32_t)nwords, TILE_WORDS);
+    ctx->stride4 = ctx->stride_words / 2;
+    ctx->ntiles = ctx->stride_words / TILE_WORDS;
+    if ((uint64_t)ctx->nb * ctx->stride4 >= (1ull << 32))
+        return ctx->fail(LVBGPU_E_ARG, "tree block exceeds 64 GiB");
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev0));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)ctx->nb * ctx->stride_words * 8));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_changes, (size_t)(ctx->nb + 1) * 8));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_scalars, 2 * 8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
+    HIPCHK(ctx, upload_iupac_table());
+    HIPCHK(ctx, raise_lds_limit());
+    ctx->pb.resize(ctx->nb);
+    return LVBGPU_OK;
+}
+
+// everything that is not a leaf word becomes all-ones (inert under fitch)
+int finish_rows(lvbgpu_ctx *ctx)
+{
+    HIPCHK(ctx, launch_fill_pad(ctx->d_rows, (uint32_t)ctx->nb, (uint32_t)ctx->nwords, ctx->stride_words,
+                                (uint32_t)ctx->n, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+} // namespace
+
+// =================================================================================== library
+
+extern "C" const char *lvbgpu_strerror(int status)
+{
+    switch (status)
+    {
+    case LVBGPU_OK: return "ok";
+    case LVBGPU_E_ARG: return "bad argument";
+    case LVBGPU_E_NODEVICE: return "no usable HIP device";
+    case LVBGPU_E_HIP: return "HIP call failed";
+    case LVBGPU_E_NOMEM: return "out of memory";
+    case LVBGPU_E_STATE: return "call order violated";
+    case LVBGPU_E_TOPOLOGY: return "not a binary tree rooted at a leaf";
+    case LVBGPU_E_SYMBOL: return "bad base symbol in data matrix";
+    case LVBGPU_E_ZEROLEN: return "tree length is not positive";
+    case LVBGPU_E_COMM: return "RCCL failure";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *lvbgpu_last_error(const lvbgpu_ctx *ctx)
+{
+    return ctx ? ctx->last_error.c_str() : g_last_error_noctx.c_str();
+}
+
+extern "C" int lvbgpu_device_count(void)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess)
+        return hip_status_noctx(e, "hipGetDeviceCount");
+    return count;
+}
+
+extern "C" int lvbgpu_abi_version(void) { return ABI_VERSION; }
+
+extern "C" long lvbgpu_words_per_row(long m)
+{
+    // reference DataOperations.c:446-458: m/16 rounded up
+    return (m >> 4) + ((m & 15) ? 1 : 0);
+}
+
+// =================================================================================== encoding
+
+namespace
+{
+int encode_into(lvbgpu_ctx *ctx, long n, long m, const char *const *rows, uint64_t *d_rows, uint32_t stride_words)
+{
+    const long nwords = lvbgpu_words_per_row(m);
+    DevBuf d_text, d_bad;
+    PinBuf h_text;
+    int rc = LVBGPU_OK;
+    const size_t tbytes = (size_t)n * (size_t)m;
+    hipError_t e;
+    if ((e = h_text.reserve(tbytes)) != hipSuccess || (e = d_text.reserve(tbytes)) != hipSuccess ||
+        (e = d_bad.reserve(8)) != hipSuccess)
+        rc = ctx->fail_hip(e, "encode staging");
+    unsigned long long bad = ~0ull;
+    if (rc == LVBGPU_OK)
+    {
+        for (long i = 0; i < n; i++)
+            memcpy((char *)h_text.p + (size_t)i * m, rows[i], (size_t)m);
+        if ((e = hipMemcpyAsync(d_text.p, h_text.p, tbytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(d_bad.p, &bad, 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+            (e = launch_encode_text((const uint8_t *)d_text.p, (uint32_t)n, (uint64_t)m, (uint32_t)nwords,
+                                    stride_words, d_rows, (unsigned long long *)d_bad.p, ctx->stream)) !=
+                hipSuccess ||
+            (e = hipMemcpyAsync(&bad, d_bad.p, 8, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            rc = ctx->fail_hip(e, "encode_text");
+    }
+    if (rc == LVBGPU_OK && bad != ~0ull)
+    {
+        const unsigned long long pos = bad - 1;
+        char msg[160];
+        snprintf(msg, sizeof msg, "bad base symbol in data MSA: '%c' (row %llu, column %llu)",
+                 rows[pos / m][pos % m], pos / m, pos % m);
+        rc = ctx->fail(LVBGPU_E_SYMBOL, msg);
+    }
+    d_text.release();
+    d_bad.release();
+    h_text.release();
+    return rc;
+}
+} // namespace
+
+extern "C" int lvbgpu_encode_text(int device, long n, long m, const char *const *rows, uint64_t *out)
+{
+    if (!rows || !out || n < 1 || m < 1)
+        return LVBGPU_E_ARG;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return hip_status_noctx(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount");
+    if (device < 0 || device >= count)
+        return LVBGPU_E_ARG;
+    lvbgpu_ctx tmp;
+    tmp.device = device;
+    int rc = LVBGPU_OK;
+    const long nwords = lvbgpu_words_per_row(m);
+    DevBuf d_out;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&tmp.stream)) != hipSuccess ||
+        (e = upload_iupac_table()) != hipSuccess || (e = d_out.reserve((size_t)n * nwords * 8)) != hipSuccess)
+        rc = tmp.fail_hip(e, "encode setup");
+    if (rc == LVBGPU_OK)
+        rc = encode_into(&tmp, n, m, rows, (uint64_t *)d_out.p, (uint32_t)nwords);
+    if (rc == LVBGPU_OK &&
+        (e = hipMemcpy(out, d_out.p, (size_t)n * nwords * 8, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = tmp.fail_hip(e, "encode download");
+    g_last_error_noctx = tmp.last_error;
+    d_out.release();
+    if (tmp.stream)
+        (void)hipStreamDestroy(tmp.stream);
+    return rc;
+}
+
+// =================================================================================== context
+
+extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm)
+        (void)lvbgpu_comm_destroy(ctx);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_rows)
+        (void)hipFree(ctx->d_rows);
+    if (ctx->d_changes)
+        (void)hipFree(ctx->d_changes);
+    if (ctx->d_scalars)
+        (void)hipFree(ctx->d_scalars);
+    ctx->d_prog.release();
+    ctx->d_len.release();
+    ctx->h_pin.release();
+    ctx->d_cin.release();
+    ctx->d_cout.release();
+    ctx->h_cin.release();
+    ctx->h_cout.release();
+    ctx->d_comm.release();
+    if (ctx->ev0)
+        (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1)
+        (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int lvbgpu_create(lvbgpu_ctx **out, int device, long n, long nwords, const uint64_t *leaf_matrix,
+                             long row_stride_words)
+{
+    if (!out || !leaf_matrix || row_stride_words < nwords)
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    lvbgpu_ctx *ctx = new (std::nothrow) lvbgpu_ctx();
+    if (!ctx)
+        return LVBGPU_E_NOMEM;
+    int rc = context_common_init(ctx, device, n, nwords);
+    if (rc == LVBGPU_OK)
+    {
+        hipError_t e = hipMemcpy2DAsync(ctx->d_rows, (size_t)ctx->stride_words * 8, leaf_matrix,
+                                        (size_t)row_stride_words * 8, (size_t)nwords * 8, (size_t)n,
+                                        hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess)
+            rc = ctx->fail_hip(e, "upload leaf matrix");
+    }
+    if (rc == LVBGPU_OK)
+        rc = finish_rows(ctx);
+    if (rc != LVBGPU_OK)
+    {
+        g_last_error_noctx = ctx->last_error;
+        lvbgpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_create_from_text(lvbgpu_ctx **out, int device, long n, long m, const char *const *rows)
+{
+    if (!out || !rows || m < 1)
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    lvbgpu_ctx *ctx = new (std::nothrow) lvbgpu_ctx();
+    if (!ctx)
+        return LVBGPU_E_NOMEM;
+    int rc = context_common_init(ctx, device, n, lvbgpu_words_per_row(m));
+    if (rc == LVBGPU_OK)
+        rc = encode_into(ctx, n, m, rows, ctx->d_rows, ctx->stride_words);
+    if (rc == LVBGPU_OK)
+        rc = finish_rows(ctx);
+    if (rc != LVBGPU_OK)
+    {
+        g_last_error_noctx = ctx->last_error;
+        lvbgpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return LVBGPU_OK;
+}
+
+extern "C" long lvbgpu_n(const lvbgpu_ctx *ctx) { return ctx ? ctx->n : 0; }
+extern "C" long lvbgpu_nwords(const lvbgpu_ctx *ctx) { return ctx ? ctx->nwords : 0; }
+
+// =================================================================================== resident tree
+
+namespace
+{
+// run one stored-result program (full evaluation or commit) against the resident rows and
+// refresh S_all / current length.  `prog` holds node ids.
+int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all)
+{
+    int rc = check_depth(ctx, prog.max_stack);
+    if (rc != LVBGPU_OK)
+        return rc;
+    Packed pk;
+    pk.add(prog, 0, 0, 0, 0);
+    size_t o_t = 0, o_d = 0;
+    rc = upload_program(ctx, ctx->d_prog, pk.cands, prog.toks, prog.dsts, &o_t, &o_d);
+    if (rc != LVBGPU_OK)
+        return rc;
+    HIPCHK(ctx, ctx->d_len.reserve(8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
+    if (zero_all)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
+    else
+    {
+        HIPCHK(ctx, launch_zero_changes(ctx->d_changes, (const int32_t *)((const char *)ctx->d_prog.p + o_d),
+                                        (uint32_t)prog.dsts.size(), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes + ctx->nb, 0, 8, ctx->stream));
+    }
+    WalkArgs a = resident_args(ctx, ctx->d_prog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
+    HIPCHK(ctx, launch_walk(a, prog.max_stack > (int32_t)REG_STACK_LEVELS, true, ctx->stream));
+    HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
+    long long scal[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(scal, ctx->d_scalars, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cur_length = scal[1];
+    return LVBGPU_OK;
+}
+} // namespace
+
+extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32_t *right, int32_t root,
+                               int64_t *length_out)
+{
+    if (!ctx || !left || !right)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string why;
+    Topology t;
+    if (!t.assign((int32_t)ctx->n, left, right, root, &why))
+        return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    ctx->topo = std::move(t);
+    ctx->have_tree = false;
+    Program prog;
+    ctx->pb.build_full(ctx->topo, prog);
+    int rc = run_commit_program(ctx, prog, true);
+    if (rc != LVBGPU_OK)
+        return rc;
+    ctx->have_tree = true;
+    if (length_out)
+        *length_out = ctx->cur_length;
+    if (ctx->cur_length <= 0)
+        return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_current_length(lvbgpu_ctx *ctx, int64_t *length_out)
+{
+    if (!ctx || !length_out)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    *length_out = ctx->cur_length;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_get_topology(lvbgpu_ctx *ctx, int32_t *parent, int32_t *left, int32_t *right, int32_t *root)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    if (parent)
+        memcpy(parent, ctx->topo.parent.data(), (size_t)ctx->nb * 4);
+    if (left)
+        memcpy(left, ctx->topo.left.data(), (size_t)ctx->nb * 4);
+    if (right)
+        memcpy(right, ctx->topo.right.data(), (size_t)ctx->nb * 4);
+    if (root)
+        *root = ctx->topo.root;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_get_changes(lvbgpu_ctx *ctx, int64_t *changes)
+{
+    if (!ctx || !changes)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(changes, ctx->d_changes, (size_t)ctx->nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out)
+{
+    if (!ctx || !out || node < 0 || node >= ctx->nb)
+        return LVBGPU_E_ARG;
+    if (node >= ctx->n && !ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_rows + (size_t)node * ctx->stride_words, (size_t)ctx->nwords * 8,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+// =================================================================================== batches
+
+extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
+{
+    if (!b)
+        return;
+    if (b->ctx)
+    {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+    }
+    b->d_prog.release();
+    b->d_len.release();
+    delete b;
+}
+
+namespace
+{
+int finish_batch(lvbgpu_ctx *ctx, lvbgpu_batch *b, const Packed &pk, bool full_mode)
+{
+    int rc = check_depth(ctx, pk.max_stack);
+    if (rc != LVBGPU_OK)
+        return rc;
+    if ((uint64_t)b->B * ctx->ntiles >= (1ull << 31))
+        return ctx->fail(LVBGPU_E_ARG, "batch too large: B * tiles must stay below 2^31");
+    rc = upload_program(ctx, b->d_prog, pk.cands, pk.toks, pk.dsts, &b->off_toks, &b->off_dsts);
+    if (rc != LVBGPU_OK)
+        return rc;
+    HIPCHK(ctx, b->d_len.reserve((size_t)b->B * 8));
+    b->full_mode = full_mode;
+    b->stats.candidates = b->B;
+    b->stats.combines = (int64_t)pk.dsts.size();
+    b->stats.rows_read = (int64_t)pk.toks.size();
+    b->stats.dirty_nodes = pk.dirty;
+    b->stats.max_stack = pk.max_stack;
+    b->stats.algorithmic_bytes = b->stats.rows_read * ctx->nwords * 8;
+    return LVBGPU_OK;
+}
+} // namespace
+
+extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
+                                  const int32_t *roots, lvbgpu_batch **out)
+{
+    if (!ctx || !out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    static_assert(sizeof(lvbgpu_edit) == sizeof(Edit), "edit layout");
+    Packed pk;
+    Program prog; // all candidates appended into one token/dst stream
+    std::string why;
+    for (int32_t b = 0; b < B; b++)
+    {
+        const int32_t e0 = edit_offsets[b], e1 = edit_offsets[b + 1];
+        if (e1 < e0)
+            return ctx->fail(LVBGPU_E_ARG, "edit_offsets not monotone");
+        const size_t tok0 = prog.toks.size(), dst0 = prog.dsts.size();
+        prog.max_stack = 0;
+        if (!ctx->pb.build_candidate(ctx->topo, reinterpret_cast<const Edit *>(edits) + e0, e1 - e0,
+                                     roots ? roots[b] : -1, prog, &why))
+            return ctx->fail(LVBGPU_E_TOPOLOGY, "candidate " + std::to_string(b) + ": " + why);
+        pk.add(prog, tok0, dst0, 0, CAND_RESIDENT_BASE);
+        pk.max_stack = std::max(pk.max_stack, prog.max_stack);
+        pk.dirty += prog.dirty;
+    }
+    pk.toks.swap(prog.toks);
+    pk.dsts.swap(prog.dsts);
+    lvbgpu_batch *bt = new (std::nothrow) lvbgpu_batch();
+    if (!bt)
+        return LVBGPU_E_NOMEM;
+    bt->ctx = ctx;
+    bt->B = B;
+    int rc = finish_batch(ctx, bt, pk, false);
+    if (rc != LVBGPU_OK)
+    {
+        lvbgpu_batch_free(bt);
+        return rc;
+    }
+    *out = bt;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
+{
+    if (!ctx || !b || b->ctx != ctx)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, (size_t)b->B * 8, ctx->stream));
+    WalkArgs a = resident_args(ctx, b->d_prog, b->off_toks, b->off_dsts, b->d_len.p, (uint32_t)b->B,
+                               (int32_t)b->stats.max_stack);
+    HIPCHK(ctx, launch_walk(a, b->stats.max_stack > (int64_t)REG_STACK_LEVELS, false, ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *lengths_out)
+{
+    if (!ctx || !b || b->ctx != ctx || !lengths_out)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(lengths_out, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t i = 0; i < b->B; i++)
+        if (lengths_out[i] <= 0)
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_batch_get_stats(const lvbgpu_batch *b, lvbgpu_batch_stats *out)
+{
+    if (!b || !out)
+        return LVBGPU_E_ARG;
+    *out = b->stats;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
+                                  const int32_t *roots, int64_t *lengths_out)
+{
+    lvbgpu_batch *b = nullptr;
+    int rc = lvbgpu_batch_build(ctx, B, edit_offsets, edits, roots, &b);
+    if (rc != LVBGPU_OK)
+        return rc;
+    rc = lvbgpu_batch_launch(ctx, b);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_lengths(ctx, b, lengths_out);
+    lvbgpu_batch_free(b);
+    return rc;
+}
+
+extern "C" int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *left, const int32_t *right,
+                                       const int32_t *roots, int64_t *lengths_out)
+{
+    if (!ctx || B < 1 || !left || !right || !lengths_out)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Packed pk;
+    Program prog;
+    std::string why;
+    Topology t;
+    ProgramBuilder pb(ctx->nb);
+    for (int32_t b = 0; b < B; b++)
+    {
+        if (!t.assign((int32_t)ctx->n, left + (size_t)b * ctx->nb, right + (size_t)b * ctx->nb, roots ? roots[b] : 0,
+                      &why))
+            return ctx->fail(LVBGPU_E_TOPOLOGY, "tree " + std::to_string(b) + ": " + why);
+        const size_t tok0 = prog.toks.size(), dst0 = prog.dsts.size();
+        prog.max_stack = 0;
+        pb.build_full(t, prog);
+        pk.add(prog, tok0, dst0, 0, 0);
+        pk.max_stack = std::max(pk.max_stack, prog.max_stack);
+        pk.dirty += prog.dirty;
+    }
+    pk.toks.swap(prog.toks);
+    pk.dsts.swap(prog.dsts);
+    lvbgpu_batch *bt = new (std::nothrow) lvbgpu_batch();
+    if (!bt)
+        return LVBGPU_E_NOMEM;
+    bt->ctx = ctx;
+    bt->B = B;
+    int rc = finish_batch(ctx, bt, pk, true);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_launch(ctx, bt);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_lengths(ctx, bt, lengths_out);
+    lvbgpu_batch_free(bt);
+    return rc;
+}
+
+extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit *edits, int32_t root,
+                             int64_t *length_out)
+{
+    if (!ctx || n_edits < 0 || (n_edits > 0 && !edits))
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string why;
+    Program prog;
+    if (!ctx->pb.build_candidate(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, prog, &why))
+        return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    if (!ctx->pb.apply_edits(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, &why))
+        return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    int rc = run_commit_program(ctx, prog, false);
+    if (rc != LVBGPU_OK)
+    {
+        ctx->have_tree = false; // resident state is no longer trustworthy
+        return rc;
+    }
+    if (length_out)
+        *length_out = ctx->cur_length;
+    if (ctx->cur_length <= 0)
+        return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    return LVBGPU_OK;
+}
+
+// =================================================================================== strict compat
+
+extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, int64_t *length_out)
+{
+    if (!ctx || !tree_v || !length_out)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    RefNode *tree = (RefNode *)tree_v;
+    const int32_t nb = ctx->nb, n = (int32_t)ctx->n;
+    const uint32_t W = (uint32_t)ctx->nwords, Wp = ctx->stride_words;
+
+    // topology + dirty flags + cached changes of clean nodes (TreeEvaluation.c:191-202)
+    std::vector<int32_t> l(nb), r(nb);
+    std::vector<uint8_t> dirty(nb, 0);
+    long long base = 0;
+    for (int32_t i = 0; i < nb; i++)
+    {
+        l[i] = (int32_t)tree[i].left;
+        r[i] = (int32_t)tree[i].right;
+        if (i >= n)
+        {
+            if (tree[i].sitestate[0] == 0)
+                dirty[i] = 1;
+            else
+                base += tree[i].changes;
+        }
+    }
+    std::string why;
+    Topology t;
+    if (!t.assign(n, l.data(), r.data(), (int32_t)root, &why))
+        return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    Program prog;
+    ctx->pb.build_flagged(t, dirty.data(), prog);
+    int rc = check_depth(ctx, prog.max_stack);
+    if (rc != LVBGPU_OK)
+        return rc;
+
+    // operand rows -> input slots, produced nodes -> output slots
+    if ((int32_t)ctx->slot_of.size() != nb)
+    {
+        ctx->slot_of.assign(nb, 0);
+        ctx->slot_epoch.assign(nb, 0);
+        ctx->slot_gen = 0;
+    }
+    if (++ctx->slot_gen == 0)
+    {
+        std::fill(ctx->slot_epoch.begin(), ctx->slot_epoch.end(), 0u);
+        ctx->slot_gen = 1;
+    }
+    std::vector<int32_t> in_nodes;
+    for (uint32_t &tk : prog.toks)
+    {
+        const int32_t node = (int32_t)(tk & TOK_ROW_MASK);
+        if (ctx->slot_epoch[node] != ctx->slot_gen)
+        {
+            ctx->slot_epoch[node] = ctx->slot_gen;
+            ctx->slot_of[node] = (int32_t)in_nodes.size();
+            in_nodes.push_back(node);
+        }
+        tk = (tk & ~TOK_ROW_MASK) | (uint32_t)ctx->slot_of[node];
+    }
+    std::vector<int32_t> out_nodes;
+    for (int32_t &d : prog.dsts)
+        if (d >= 0)
+        {
+            out_nodes.push_back(d);
+            d = (int32_t)out_nodes.size() - 1;
+        }
+    const uint32_t n_in = (uint32_t)in_nodes.size(), n_out = (uint32_t)out_nodes.size();
+
+    // one input arena [cand][toks][dsts][rows], one output arena [len][changes x (n_out+1)][rows]
+    const size_t o_t = align16(sizeof(CandDesc));
+    const size_t o_d = o_t + align16(prog.toks.size() * 4);
+    const size_t o_rows = o_d + align16(prog.dsts.size() * 4);
+    const size_t in_bytes = o_rows + (size_t)n_in * Wp * 8;
+    const size_t oo_ch = 16;
+    const size_t oo_rows = align16(oo_ch + (size_t)(n_out + 1) * 8);
+    const size_t out_bytes = oo_rows + (size_t)n_out * Wp * 8;
+    HIPCHK(ctx, ctx->h_cin.reserve(in_bytes));
+    HIPCHK(ctx, ctx->d_cin.reserve(in_bytes));
+    HIPCHK(ctx, ctx->h_cout.reserve(out_bytes));
+    HIPCHK(ctx, ctx->d_cout.reserve(out_bytes));
+
+    char *hin = (char *)ctx->h_cin.p;
+    CandDesc cd{};
+    cd.tok_off = 0;
+    cd.ntok = (uint32_t)prog.toks.size();
+    cd.dst_off = 0;
+    cd.ncomb = (uint32_t)prog.dsts.size();
+    cd.base = base;
+    cd.flags = 0;
+    memcpy(hin, &cd, sizeof cd);
+    memcpy(hin + o_t, prog.toks.data(), prog.toks.size() * 4);
+    memcpy(hin + o_d, prog.dsts.data(), prog.dsts.size() * 4);
+    for (uint32_t s = 0; s < n_in; s++)
+    {
+        uint64_t *dst = (uint64_t *)(hin + o_rows) + (size_t)s * Wp;
+        memcpy(dst, tree[in_nodes[s]].sitestate, (size_t)W * 8);
+        for (uint32_t w = W; w < Wp; w++)
+            dst[w] = ~0ull;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_cin.p, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cout.p, 0, oo_rows, ctx->stream));
+
+    WalkArgs a{};
+    a.rows_in = (const uint4 *)((const char *)ctx->d_cin.p + o_rows);
+    a.rows_out = (uint4 *)((char *)ctx->d_cout.p + oo_rows);
+    a.cands = (const CandDesc *)ctx->d_cin.p;
+    a.toks = (const uint32_t *)((const char *)ctx->d_cin.p + o_t);
+    a.dsts = (const int32_t *)((const char *)ctx->d_cin.p + o_d);
+    a.node_changes = nullptr;
+    a.s_all = nullptr;
+    a.len_out = (unsigned long long *)ctx->d_cout.p;
+    a.changes_out = (unsigned long long *)((char *)ctx->d_cout.p + oo_ch);
+    a.root_slot = n_out;
+    a.in_stride4 = Wp / 2;
+    a.out_stride4 = Wp / 2;
+    a.B = 1;
+    a.ntiles = ctx->ntiles;
+    a.nitems = ctx->ntiles;
+    a.stack_depth = (uint32_t)std::max(prog.max_stack, 1);
+    HIPCHK(ctx, launch_walk(a, prog.max_stack > (int32_t)REG_STACK_LEVELS, true, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_cout.p, ctx->d_cout.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+
+    // write back exactly what the reference's getplen leaves behind (TreeEvaluation.c:228-229)
+    const char *hout = (const char *)ctx->h_cout.p;
+    const long long total = *(const long long *)hout;
+    const unsigned long long *och = (const unsigned long long *)(hout + oo_ch);
+    for (uint32_t s = 0; s < n_out; s++)
+    {
+        const int32_t node = out_nodes[s];
+        memcpy(tree[node].sitestate, (const uint64_t *)(hout + oo_rows) + (size_t)s * Wp, (size_t)W * 8);
+        tree[node].changes = (long)och[s];
+    }
+    *length_out = total;
+    if (total <= 0)
+        return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    return LVBGPU_OK;
+}
+
+// =================================================================================== timing
+
+extern "C" int lvbgpu_timer_start(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_synchronize(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" void *lvbgpu_stream(lvbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// =================================================================================== RCCL
+
+namespace
+{
+bool load_rccl(std::string *why)
+{
+    if (g_rccl.lib)
+        return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *nm : names)
+        if ((g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!g_rccl.lib)
+    {
+        *why = std::string("dlopen librccl.so: ") + dlerror();
+        return false;
+    }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    {
+        *why = "librccl.so lacks the nccl* entry points";
+        return false;
+    }
+    return true;
+}
+constexpr int NCCL_INT64 = 4; // ncclInt64
+constexpr int NCCL_MIN = 3;   // ncclMin
+} // namespace
+
+extern "C" int lvbgpu_comm_unique_id(void *id128)
+{
+    if (!id128)
+        return LVBGPU_E_ARG;
+    std::string why;
+    if (!load_rccl(&why))
+    {
+        g_last_error_noctx = why;
+        return LVBGPU_E_COMM;
+    }
+    const int r = g_rccl.GetUniqueId(id128);
+    if (r != 0)
+    {
+        g_last_error_noctx = std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        return LVBGPU_E_COMM;
+    }
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const void *id128)
+{
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
+        return LVBGPU_E_ARG;
+    std::string why;
+    if (!load_rccl(&why))
+        return ctx->fail(LVBGPU_E_COMM, why);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Id128 id;
+    memcpy(id.bytes, id128, 128);
+    const int r = g_rccl.CommInitRank(&ctx->comm, nranks, id, rank);
+    if (r != 0)
+        return ctx->fail(LVBGPU_E_COMM,
+                         std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    ctx->comm_rank = rank;
+    ctx->comm_size = nranks;
+    HIPCHK(ctx, ctx->d_comm.reserve(16));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value, int32_t *argmin_rank)
+{
+    if (!ctx || !value)
+        return LVBGPU_E_ARG;
+    if (!ctx->comm)
+        return ctx->fail(LVBGPU_E_STATE, "no communicator: call lvbgpu_comm_init first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // one 8-byte min over xGMI finds the best length; a second one over (length, rank) keys
+    // names a rank that holds it.  Lengths are < 2^47 (MAX_M * 2 * MAX_N), ranks < 2^16.
+    long long vals[2] = {(long long)*value, ((long long)*value << 16) | (long long)ctx->comm_rank};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm.p, vals, 16, hipMemcpyHostToDevice, ctx->stream));
+    const int r = g_rccl.AllReduce(ctx->d_comm.p, ctx->d_comm.p, 2, NCCL_INT64, NCCL_MIN, ctx->comm, ctx->stream);
+    if (r != 0)
+        return ctx->fail(LVBGPU_E_COMM,
+                         std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    HIPCHK(ctx, hipMemcpyAsync(vals, ctx->d_comm.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *value = vals[0];
+    if (argmin_rank)
+        *argmin_rank = (int32_t)(vals[1] & 0xFFFF);
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_comm_destroy(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    if (ctx->comm && g_rccl.CommDestroy)
+        (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    return LVBGPU_OK;
+}

@@ -253,7 +253,27 @@ def load_ref():
     lib.refh_time_full.restype = C.c_double
     lib.refh_time_full.argtypes = [vp, C.c_long, C.POINTER(C.c_long)]
     _ref = lib
+    _prime_reference_statics(lib)
     return lib
+
+
+PRIME_TAXA = 4096
+
+
+def _prime_reference_statics(lib) -> None:
+    """The reference keeps function-local statics sized by the FIRST alignment it sees
+    (`oldparent` in lvb_reroot, TreeOperations.c:585-592, and in mutate_tbr, :360/:445): a later,
+    larger alignment in the same process would overrun them.  Touch both once with more taxa
+    than any test uses, so one process can host many shapes."""
+    n, m = PRIME_TAXA, 4
+    rows = [bytes(b"ACGT"[(i >> (2 * k)) & 3] for k in range(m)) for i in range(n)]
+    arr = (C.c_char_p * n)(*rows)
+    h = lib.refh_new_from_rows(n, m, arr, 1, 1)
+    lib.refh_getplen(h, 0)
+    lib.refh_arbreroot(h)
+    for _ in range(8):
+        lib.refh_mutate(h, 2)
+    lib.refh_free(h)
 
 
 class RefRun:
