@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py - candidate trees scored per second by the HIP Fitch path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the headline metric is quoted on):
+synthetic 500-taxon x 50 000-site DNA alignment, SPR neighbourhood; one "step" = one launch of
+the scoring kernel over one resident batch of B candidate topologies (edits against the resident
+current tree).  Alignment, tree and candidate programs are already in HBM when the timed region
+starts.  For N > 1 every rank is an independent restart (own seed, own start tree, own
+candidates) on its own GPU; the only collective is an RCCL min-reduce of the best length.
+
+Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).  `cpu_baseline` times LVB's
+own CPU path (the reference compiled into oracle/_ref, or our C restatement if that did not
+travel) on the host cores, on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MOVES = {"nni": 0, "spr": 1, "tbr": 2}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--taxa", type=int, default=500)
+    ap.add_argument("--sites", type=int, default=50000)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--move", choices=list(MOVES), default="spr")
+    ap.add_argument("--nbatches", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--walk", type=int, default=75, help="accepted random moves applied to the start tree "
+                    "before measuring (BASELINE.md: 300 proposals, every 4th accepted)")
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def synth_rows(n: int, m: int, seed: int) -> list[bytes]:
+    """Generator T of SURVEY.md 8(d): taxon 0 uniform, taxon i copies taxon (i-1)//2 with 10 % substitutions."""
+    from tests.synth import treelike_rows
+    return treelike_rows(n, m, seed)
+
+
+def cpu_baseline(rows, kind: int, budget_s: float, spot):
+    """LVB's CPU path on this host: reference mutate_* + getplen (incl. its per-proposal treecopy)."""
+    from oracle import binding as ob
+    cores = 1
+    if ob.load_ref() is not None:
+        rr = ob.RefRun(rows=rows, seed=12345, nproc=1)
+        try:
+            rr.getplen(0)
+            # calibrate on a few proposals, then size the sample to the budget
+            tg, tm, _, _ = rr.time_proposals(kind, 20, 4)
+            per = max((tg + tm) / 20, 1e-6)
+            reps = int(max(50, min(20000, budget_s / per)))
+            tg, tm, cs, ds = rr.time_proposals(kind, reps, 4)
+            tfull, _ = rr.time_full(3)
+            # spot parity: the reference's full evaluation of the bench's own start tree
+            check = None
+            if spot is not None:
+                left, right, root, length = spot
+                ot = ob.OracleTree(rr.n, rr.nwords, rr.enc())
+                from tests.helpers import parents_of
+                l64, r64 = np.asarray(left, np.int64), np.asarray(right, np.int64)
+                ot.set_topology(parents_of(l64, r64), l64, r64, root)
+                check = bool(ot.getplen() == length)
+            return {
+                "value": reps / (tg + tm), "unit": "trees/s", "cores": cores, "kind": "reference",
+                "sample": f"{reps} {['NNI', 'SPR', 'TBR'][kind]} proposals (mutate incl. treecopy + incremental "
+                          f"getplen, serial branch), every 4th accepted, same alignment; getplen alone "
+                          f"{reps / tg:.0f}/s ({1e3 * tg / reps:.3f} ms), mutate {1e3 * tm / reps:.3f} ms, "
+                          f"full getplen {1e3 * tfull / 3:.2f} ms, mean dirty {ds / reps:.1f}",
+                "getplen_only_trees_per_s": reps / tg,
+                "start_tree_length_matches_cpu": check,
+            }
+        finally:
+            rr.close()
+    # fallback: our C restatement (the reference did not travel)
+    from lvb_amd import host
+    enc = ob.encode_rows(rows)
+    n, nwords = enc.shape
+    tree = host.HostTree(n, seed=12345)
+    _, left, right = tree.arrays()
+    from tests.helpers import apply_edits, parents_of
+    cur = ob.OracleTree(n, nwords, enc)
+    l64, r64 = left.astype(np.int64), right.astype(np.int64)
+    cur.set_topology(parents_of(l64, r64), l64, r64, tree.root)
+    cur.getplen()
+    prop = ob.OracleTree(n, nwords)
+    t_total, reps = 0.0, 0
+    while t_total < budget_s and reps < 20000:
+        edits = tree.propose(kind)
+        prog = tree.program(mode=0, edits=edits)
+        nl, nr = apply_edits(left, right, edits)
+        par = parents_of(nl, nr)
+        t0 = time.perf_counter()
+        prop.copy_from(cur)  # the reference's per-proposal treecopy
+        prop.set_topology(par, nl, nr, tree.root)
+        prop.mark_dirty([d for d in prog["dsts"] if d >= 0])
+        prop.getplen()
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"value": reps / t_total, "unit": "trees/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} proposals through oracle/fitch_oracle.c (treecopy + incremental getplen)"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lvb_amd import api, host
+
+    kind = MOVES[args.move]
+    t_setup = time.perf_counter()
+    rows, min_len = host.prepare_alignment(synth_rows(args.taxa, args.sites, args.seed))
+    ctx = api.FitchContext(text_rows=rows, device=local_rank)      # encode on the device
+    tree = host.HostTree(args.taxa, seed=args.seed * 1000 + rank + 1)  # each rank: its own restart
+    length = tree.upload(ctx)
+    for _ in range(args.walk):                                      # short random walk, as BASELINE.md
+        e = tree.propose(kind)
+        length = ctx.commit(e)
+        tree.apply(e)
+    spot = (tree.arrays()[1].copy(), tree.arrays()[2].copy(), tree.root, length)
+
+    batches = []
+    for b in range(args.nbatches):
+        offs, edits = tree.propose_batch(kind, args.batch)
+        bh = api.C.c_void_p()
+        ctx._chk(ctx.lib.lvbgpu_batch_build(ctx.h, args.batch, offs, edits.ctypes.data, None, api.C.byref(bh)))
+        batches.append(api.Batch(ctx, bh, args.batch))
+    stats = [b.stats() for b in batches]
+    setup_s = time.perf_counter() - t_setup
+
+    if world > 1:
+        # RCCL communicator of the scoring library itself (not torch's): id from rank 0
+        uid = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        batches[i % len(batches)].launch()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for i in range(args.steps):
+        batches[i % len(batches)].launch()
+    kernel_ms = ctx.timer_stop()  # HIP events on the stream the kernels run on
+    best_local = min(int(b.lengths().min()) for b in batches)
+    best_global = best_local
+    if world > 1:
+        best_global, _ = ctx.allreduce_min(best_local)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-launch accounting for the roofline: average over the batches actually launched
+    launched = [stats[i % len(batches)] for i in range(args.steps)]
+    alg_bytes = float(np.mean([s["algorithmic_bytes"] for s in launched]))
+    mean_dirty = float(np.mean([s["dirty_nodes"] / s["candidates"] for s in launched]))
+    launch_ms = kernel_ms / args.steps
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+
+    total_trees = args.batch * args.steps * world
+    out = {
+        "metric": "candidate trees scored/sec (Fitch getplen), 500 taxa x 50k sites",
+        "value": total_trees / elapsed,
+        "unit": "trees/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.taxa} taxa x {args.sites} sites synthetic DNA (tree-like, 10% substitutions), "
+                        f"{args.move.upper()} neighbourhood, incremental getplen semantics, "
+                        f"B={args.batch} candidates per step, {args.nbatches} resident batches cycled",
+            "taxa": args.taxa, "sites_after_constant_cut": len(rows[0]), "nwords": ctx.nwords,
+            "batch": args.batch, "move": args.move, "mean_dirty_nodes": round(mean_dirty, 2),
+            "parallelism": f"{world} independent restart(s), one per GPU; RCCL min-reduce of best length",
+            "best_length": best_global, "min_len_tree": min_len, "setup_seconds": round(setup_s, 2),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "fitch_walk<false,false>", "launch_ms": launch_ms,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "algorithmic bytes = (D+3) clean rows x nwords x 8 per candidate; rows are re-read from "
+                    "the XCD L2 / Infinity Cache, so achieved may exceed the HBM figure",
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(rows, kind, args.cpu_seconds, spot)
+    for b in batches:
+        b.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/* lvbhost.h - C ABI of the host-side search mirror (lvb_amd/liblvbhost.so).
+ *
+ * The reference's search host (Solve.c Anneal, TreeOperations.c mutate_*) stays on the CPU.  This
+ * library is our own C++ restatement of just enough of it to drive and measure the device path
+ * behind include/lvbgpu.h: a topology object, NNI/SPR/TBR proposal generators that emit EDITS
+ * (not tree copies), a re-root, and a batched simulated-annealing loop with the reference's
+ * acceptance rule and cooling schedule.  It contains no scoring code: every length comes from
+ * lvbgpu_* calls.
+ *
+ * Reference interfaces mirrored (file:line under the reference's src/):
+ *   TreeOperations.c:160-209  mutate_nni   -> lvbhost_propose(kind 0)
+ *   TreeOperations.c:236-335  mutate_spr   -> lvbhost_propose(kind 1)
+ *   TreeOperations.c:337-541  mutate_tbr   -> lvbhost_propose(kind 2)
+ *   TreeOperations.c:576-656  lvb_reroot / arbreroot -> lvbhost_reroot_edits
+ *   TreeOperations.c:799-811  PullRandomTree -> lvbhost_tree_random
+ *   Solve.c:144-479           Anneal       -> lvbhost_anneal
+ *   StartingTemperature.c:49-195            -> lvbhost_starting_temperature
+ */
+#ifndef LVBHOST_H
+#define LVBHOST_H
+
+#include <stdint.h>
+
+#include "lvbgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lvbhost_tree lvbhost_tree;
+
+enum lvbhost_move
+{
+    LVBHOST_NNI = 0,
+    LVBHOST_SPR = 1,
+    LVBHOST_TBR = 2
+};
+
+/* ---- topology object (own random stream: xorshift64*) --------------------------------- */
+lvbhost_tree *lvbhost_tree_random(int32_t n, uint64_t seed);
+lvbhost_tree *lvbhost_tree_from_arrays(int32_t n, const int32_t *left, const int32_t *right, int32_t root,
+                                       uint64_t seed);
+void lvbhost_tree_free(lvbhost_tree *t);
+int32_t lvbhost_tree_n(const lvbhost_tree *t);
+int32_t lvbhost_tree_root(const lvbhost_tree *t);
+void lvbhost_tree_arrays(const lvbhost_tree *t, int32_t *parent, int32_t *left, int32_t *right);
+void lvbhost_tree_reseed(lvbhost_tree *t, uint64_t seed);
+
+/* one random move of `kind` as edits against the tree (tree unchanged); returns the number of
+ * edits written (<= cap) or a negative lvbgpu status */
+int lvbhost_propose(lvbhost_tree *t, int kind, lvbgpu_edit *edits, int32_t cap);
+/* B random moves; edit_offsets[B+1]; returns total edits or negative status.  kind -1 = cycle
+ * NNI, SPR, TBR */
+int lvbhost_propose_batch(lvbhost_tree *t, int kind, int32_t B, int32_t *edit_offsets, lvbgpu_edit *edits,
+                          int32_t cap);
+/* deterministic forms */
+int lvbhost_nni_edits(const lvbhost_tree *t, int32_t u, int swap_right, lvbgpu_edit *edits, int32_t cap);
+int lvbhost_spr_edits(const lvbhost_tree *t, int32_t src, int32_t dest, lvbgpu_edit *edits, int32_t cap);
+int lvbhost_tbr_edits(const lvbhost_tree *t, int32_t src, int32_t dest, int32_t newroot_leaf, lvbgpu_edit *edits,
+                      int32_t cap);
+int lvbhost_reroot_edits(const lvbhost_tree *t, int32_t newroot, lvbgpu_edit *edits, int32_t cap);
+/* apply edits (+ new root, or -1) to the tree: what SwapTrees achieves after an accept */
+int lvbhost_tree_apply(lvbhost_tree *t, const lvbgpu_edit *edits, int32_t n_edits, int32_t new_root);
+
+/* ---- alignment preparation (reference matchange, DataOperations.c:272-405, 53-105) ---- */
+/* keep[k] = 1 for columns whose raw characters are not all equal to row 0's (constchar); returns
+ * the number kept.  The caller drops the others before encoding, as cutcols does. */
+int64_t lvbhost_variable_columns(int64_t n, int64_t m, const char *const *rows, uint8_t *keep);
+/* MinimumTreeLength: sum over columns of (#distinct characters other than - ? N X) - 1, 5 when
+ * more than MAXSTATES (5) distinct ones occur */
+int64_t lvbhost_min_tree_length(int64_t n, int64_t m, const char *const *rows);
+
+/* ---- program introspection (what the device will walk), for tests --------------------- */
+/* mode 0: edits relative to the tree, mode 1: whole tree (all dirty), mode 2: explicit dirty flags.
+ * Writes tokens/dsts (caps in elements); returns 0 or a negative lvbgpu status. */
+int lvbhost_program(const lvbhost_tree *t, int mode, const lvbgpu_edit *edits, int32_t n_edits, int32_t new_root,
+                    const uint8_t *dirty_flags, uint32_t *toks, int32_t tok_cap, int32_t *ntok, int32_t *dsts,
+                    int32_t dst_cap, int32_t *ndst, int32_t *max_stack, int32_t *n_dirty);
+
+/* ---- batched simulated annealing over the device path --------------------------------- */
+typedef struct
+{
+    uint64_t seed;
+    int32_t algorithm;        /* 0: alternate NNI/SPR (reference -a 0, Solve.c:288-297);
+                                 1: TBR with probability t/t0, else NNI/SPR (-a 1, Solve.c:421-426);
+                                 10/11/12: NNI only / SPR only / TBR only */
+    int32_t cooling_schedule; /* 0 geometric (0.99^n t0), 1 linear (Solve.c:409-443) */
+    int32_t batch;            /* candidates scored per device step (speculative) */
+    int32_t reroot_interval;  /* REROOT_INTERVAL, LVB.h:99 (1000); 0 = never */
+    double t0;                /* starting temperature; <= 0: lvbhost_starting_temperature() */
+    int64_t maxaccept;        /* LVB.h:146-150: 5 */
+    int64_t maxpropose;       /* 2000 */
+    int64_t maxfail;          /* 40 */
+    int64_t min_len_tree;     /* MinimumTreeLength of the alignment (energy scale, Solve.c:233,303) */
+    int64_t max_proposals;    /* stop after this many consumed proposals (0 = until frozen) */
+    double max_seconds;       /* stop after this wall time (0 = no limit) */
+    int64_t max_device_steps; /* stop after this many batches (0 = no limit) */
+    int32_t sync_every;       /* every this many device steps: RCCL min-reduce of the best length (0 = never).
+                                 Lockstep mode: every rank must then run exactly max_device_steps (> 0)
+                                 batches, so the other stop criteria are ignored */
+    int32_t log_cap;          /* capacity of log_seconds/log_best */
+} lvbhost_anneal_params;
+
+typedef struct
+{
+    int64_t start_length;
+    int64_t best_length;
+    int64_t final_length;
+    int64_t global_best_length; /* after the last RCCL min-reduce (== best_length without a communicator) */
+    int64_t scored;             /* candidates scored on the device */
+    int64_t consumed;           /* proposals the serial-equivalent chain consumed ("rearrangements evaluated") */
+    int64_t accepted;           /* accepted moves (commits) */
+    int64_t device_steps;       /* batches launched */
+    int64_t reroots;
+    int64_t dirty_nodes;        /* sum of D over all scored candidates */
+    int64_t temperatures;       /* cooling steps taken */
+    double t_final;
+    double seconds;
+    double seconds_device;      /* inside lvbgpu_* calls */
+    int32_t n_log;              /* entries written to the log arrays */
+    int32_t frozen;             /* 1 if the freezing criterion ended the run */
+} lvbhost_anneal_result;
+
+void lvbhost_anneal_defaults(lvbhost_anneal_params *p);
+/* Starts from (and updates) `tree`, which must be the tree resident in ctx (lvbgpu_set_tree).
+ * log_seconds/log_best receive one (wall time, best length) pair per improvement. */
+int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost_anneal_params *params,
+                   lvbhost_anneal_result *result, double *log_seconds, int64_t *log_best);
+int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost_anneal_params *params,
+                                 double *t0_out);
+/* make `tree` resident in ctx (full evaluation) */
+int lvbhost_tree_upload(lvbgpu_ctx *ctx, const lvbhost_tree *tree, int64_t *length_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVBHOST_H */

@@ -1,0 +1,237 @@
+"""Python face of include/lvbhost.h: topology object, NNI/SPR/TBR proposals as edits, batched SA.
+
+The library (lvb_amd/liblvbhost.so) links liblvbgpu.so; it holds no scoring code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import api
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "liblvbhost.so"
+
+NNI, SPR, TBR = 0, 1, 2
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class AnnealParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("algorithm", C.c_int32), ("cooling_schedule", C.c_int32),
+                ("batch", C.c_int32), ("reroot_interval", C.c_int32), ("t0", C.c_double),
+                ("maxaccept", C.c_int64), ("maxpropose", C.c_int64), ("maxfail", C.c_int64),
+                ("min_len_tree", C.c_int64), ("max_proposals", C.c_int64), ("max_seconds", C.c_double),
+                ("max_device_steps", C.c_int64), ("sync_every", C.c_int32), ("log_cap", C.c_int32)]
+
+
+class AnnealResult(C.Structure):
+    _fields_ = [("start_length", C.c_int64), ("best_length", C.c_int64), ("final_length", C.c_int64),
+                ("global_best_length", C.c_int64), ("scored", C.c_int64), ("consumed", C.c_int64),
+                ("accepted", C.c_int64), ("device_steps", C.c_int64), ("reroots", C.c_int64),
+                ("dirty_nodes", C.c_int64), ("temperatures", C.c_int64), ("t_final", C.c_double),
+                ("seconds", C.c_double), ("seconds_device", C.c_double), ("n_log", C.c_int32),
+                ("frozen", C.c_int32)]
+
+
+SIGNATURES = {
+    "lvbhost_tree_random": (C.c_void_p, [C.c_int32, C.c_uint64]),
+    "lvbhost_tree_from_arrays": (C.c_void_p, [C.c_int32, _i32p, _i32p, C.c_int32, C.c_uint64]),
+    "lvbhost_tree_free": (None, [C.c_void_p]),
+    "lvbhost_tree_n": (C.c_int32, [C.c_void_p]),
+    "lvbhost_tree_root": (C.c_int32, [C.c_void_p]),
+    "lvbhost_tree_arrays": (None, [C.c_void_p, _i32p, _i32p, _i32p]),
+    "lvbhost_tree_reseed": (None, [C.c_void_p, C.c_uint64]),
+    "lvbhost_propose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]),
+    "lvbhost_propose_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, _i32p, C.c_void_p, C.c_int32]),
+    "lvbhost_nni_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_int32]),
+    "lvbhost_spr_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "lvbhost_tbr_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "lvbhost_reroot_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "lvbhost_tree_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "lvbhost_program": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lvbhost_variable_columns": (C.c_int64, [C.c_int64, C.c_int64, C.POINTER(C.c_char_p), C.c_void_p]),
+    "lvbhost_min_tree_length": (C.c_int64, [C.c_int64, C.c_int64, C.POINTER(C.c_char_p)]),
+    "lvbhost_anneal_defaults": (None, [C.POINTER(AnnealParams)]),
+    "lvbhost_anneal": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AnnealParams), C.POINTER(AnnealResult),
+                                 C.c_void_p, C.c_void_p]),
+    "lvbhost_starting_temperature": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AnnealParams),
+                                               C.POINTER(C.c_double)]),
+    "lvbhost_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    api.load_library()  # liblvbhost links liblvbgpu: make the failure message the useful one
+    if not LIB_PATH.exists():
+        raise api.LvbGpuError(-2, f"{LIB_PATH} is not built (run `python -m lvb_amd.build`)")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+TOK_ROW_MASK = 0x00FFFFFF
+TOK_MERGE_SHIFT = 24
+TOK_MERGE_MASK = 0x3F
+TOK_FRESH = 1 << 30
+TOK_PUSH = 1 << 31
+
+
+class HostTree:
+    """Topology + random stream (lvbhost_tree)."""
+
+    def __init__(self, n: int | None = None, *, seed: int = 1, left=None, right=None, root: int = 0):
+        self.lib = load_library()
+        if left is not None:
+            l = np.ascontiguousarray(left, dtype=np.int32)
+            r = np.ascontiguousarray(right, dtype=np.int32)
+            n = (len(l) + 3) // 2
+            self.h = self.lib.lvbhost_tree_from_arrays(n, l, r, int(root), seed)
+        else:
+            self.h = self.lib.lvbhost_tree_random(int(n), seed)
+        if not self.h:
+            raise ValueError("not a binary tree rooted at a leaf")
+        self.n = int(self.lib.lvbhost_tree_n(self.h))
+        self.nbranches = 2 * self.n - 3
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lvbhost_tree_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def root(self) -> int:
+        return int(self.lib.lvbhost_tree_root(self.h))
+
+    def arrays(self):
+        p, l, r = (np.zeros(self.nbranches, dtype=np.int32) for _ in range(3))
+        self.lib.lvbhost_tree_arrays(self.h, p, l, r)
+        return p, l, r
+
+    def reseed(self, seed: int) -> None:
+        self.lib.lvbhost_tree_reseed(self.h, seed)
+
+    def _edits(self, fn, *args, cap: int | None = None) -> np.ndarray:
+        cap = cap or (2 * self.nbranches + 8)
+        buf = np.zeros(cap, dtype=api.EDIT_DTYPE)
+        k = fn(self.h, *args, buf.ctypes.data, cap)
+        if k < 0:
+            raise api.LvbGpuError(k, "proposal rejected")
+        return buf[:k].copy()
+
+    def propose(self, kind: int) -> np.ndarray:
+        return self._edits(self.lib.lvbhost_propose, kind)
+
+    def propose_batch(self, kind: int, B: int):
+        """-> (edit_offsets[B+1], edits) ready for lvbgpu_batch_build."""
+        cap = B * 64 + 1024
+        while True:
+            offs = np.zeros(B + 1, dtype=np.int32)
+            buf = np.zeros(cap, dtype=api.EDIT_DTYPE)
+            state = self.lib.lvbhost_propose_batch(self.h, kind, B, offs, buf.ctypes.data, cap)
+            if state >= 0:
+                return offs, buf[:state].copy()
+            if cap > B * (2 * self.nbranches + 8):
+                raise api.LvbGpuError(state, "propose_batch failed")
+            cap *= 4  # note: the random stream has advanced; callers that need determinism reseed
+
+    def nni_edits(self, u: int, swap_right: bool) -> np.ndarray:
+        return self._edits(self.lib.lvbhost_nni_edits, int(u), int(bool(swap_right)))
+
+    def spr_edits(self, src: int, dest: int) -> np.ndarray:
+        return self._edits(self.lib.lvbhost_spr_edits, int(src), int(dest))
+
+    def tbr_edits(self, src: int, dest: int, newroot_leaf: int) -> np.ndarray:
+        return self._edits(self.lib.lvbhost_tbr_edits, int(src), int(dest), int(newroot_leaf))
+
+    def reroot_edits(self, newroot: int) -> np.ndarray:
+        return self._edits(self.lib.lvbhost_reroot_edits, int(newroot))
+
+    def apply(self, edits, new_root: int = -1) -> None:
+        e = api._edits_array(edits)
+        rc = self.lib.lvbhost_tree_apply(self.h, e.ctypes.data, len(e), int(new_root))
+        if rc != 0:
+            raise api.LvbGpuError(rc, "edits do not give a tree")
+
+    def program(self, mode: int = 0, edits=None, new_root: int = -1, dirty=None):
+        """The token program the device would walk -> dict(toks, dsts, max_stack, dirty)."""
+        cap = 2 * self.nbranches + 16
+        toks = np.zeros(cap, dtype=np.uint32)
+        dsts = np.zeros(cap, dtype=np.int32)
+        ntok, ndst, mstack, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        e = api._edits_array(edits) if edits is not None else np.zeros(0, dtype=api.EDIT_DTYPE)
+        d = None if dirty is None else np.ascontiguousarray(dirty, dtype=np.uint8)
+        rc = self.lib.lvbhost_program(self.h, mode, e.ctypes.data, len(e), int(new_root),
+                                      None if d is None else d.ctypes.data, toks.ctypes.data, cap, C.byref(ntok),
+                                      dsts.ctypes.data, cap, C.byref(ndst), C.byref(mstack), C.byref(nd))
+        if rc != 0:
+            raise api.LvbGpuError(rc, "program build failed")
+        return {"toks": toks[: ntok.value].copy(), "dsts": dsts[: ndst.value].copy(), "max_stack": mstack.value,
+                "dirty": nd.value}
+
+    def upload(self, ctx: api.FitchContext) -> int:
+        out = C.c_int64()
+        ctx._chk(self.lib.lvbhost_tree_upload(ctx.h, self.h, C.byref(out)))
+        return out.value
+
+
+def anneal_defaults() -> AnnealParams:
+    p = AnnealParams()
+    load_library().lvbhost_anneal_defaults(C.byref(p))
+    return p
+
+
+def anneal(ctx: api.FitchContext, tree: HostTree, params: AnnealParams):
+    """Run the batched SA loop; -> (result dict, [(seconds, best_length), ...])."""
+    lib = load_library()
+    cap = max(int(params.log_cap), 0)
+    secs = np.zeros(max(cap, 1), dtype=np.float64)
+    best = np.zeros(max(cap, 1), dtype=np.int64)
+    res = AnnealResult()
+    ctx._chk(lib.lvbhost_anneal(ctx.h, tree.h, C.byref(params), C.byref(res), secs.ctypes.data, best.ctypes.data))
+    out = {k: getattr(res, k) for k, _ in AnnealResult._fields_}
+    log = [(float(secs[i]), int(best[i])) for i in range(res.n_log)]
+    return out, log
+
+
+def starting_temperature(ctx: api.FitchContext, tree: HostTree, params: AnnealParams) -> float:
+    t0 = C.c_double()
+    ctx._chk(load_library().lvbhost_starting_temperature(ctx.h, tree.h, C.byref(params), C.byref(t0)))
+    return t0.value
+
+
+def prepare_alignment(rows: list[bytes]) -> tuple[list[bytes], int]:
+    """matchange (reference DataOperations.c:309-360): drop constant columns, then
+    MinimumTreeLength of what is left.  -> (rows after the cut, min_len_tree)."""
+    lib = load_library()
+    n, m = len(rows), len(rows[0])
+    arr = (C.c_char_p * n)(*rows)
+    keep = np.zeros(m, dtype=np.uint8)
+    kept = lib.lvbhost_variable_columns(n, m, arr, keep.ctypes.data)
+    if kept < 0:
+        raise api.LvbGpuError(int(kept), "variable_columns")
+    if kept != m:
+        idx = np.nonzero(keep)[0]
+        rows = [np.frombuffer(r, dtype=np.uint8)[idx].tobytes() for r in rows]
+        arr = (C.c_char_p * n)(*rows)
+    if kept < 1:
+        raise ValueError("after constant columns are ignored, the data matrix has no columns left")
+    return rows, int(lib.lvbhost_min_tree_length(n, int(kept), arr))

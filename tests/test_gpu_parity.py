@@ -188,3 +188,40 @@ def test_device_encoder_rejects_what_the_reference_rejects(api):
         api.encode_text(rows)
     assert ei.value.status == -7
     assert "bad base symbol" in str(ei.value)
+
+
+# ------------------------------------------------------------------ committed golden vectors
+
+from tests import goldenlib, helpers  # noqa: E402
+
+
+@pytest.mark.parametrize("name", goldenlib.names())
+def test_device_reproduces_golden_vectors(api, ob, name):
+    """tests/golden/vectors/*.npz (from the real reference): encode on the device, full
+    evaluations via set_tree, incremental cases via score_batch + commit."""
+    g = goldenlib.Golden(name)
+    rows = g.rows()
+    ctx = api.FitchContext(text_rows=rows)            # device DNAToBinary
+    enc = np.stack([ctx.sets(i) for i in range(g.n)])
+    assert goldenlib.crc(enc) == int(g.z["enc_crc"])
+    resident = None
+    for k in range(g.cases):
+        c = g.case(k)
+        base = int(c["base"])
+        if base < 0:
+            assert ctx.set_tree(c["left"], c["right"], int(c["root"])) == int(c["length"])
+            resident = k
+        else:
+            b = g.case(base)
+            if resident != base:
+                ctx.set_tree(b["left"], b["right"], int(b["root"]))
+                resident = base
+            ed = api.edits_between(b["left"], b["right"], c["left"], c["right"])
+            got = ctx.score_batch([ed], roots=[int(c["root"])])[0]
+            assert got == int(c["length"]), f"{name} case {k}"
+            assert ctx.commit(ed, root=int(c["root"])) == int(c["length"])
+            resident = k
+        assert np.array_equal(ctx.changes()[g.n:], c["changes"][g.n:])
+        if g.nwords <= 1000 or k % 6 == 0:
+            assert goldenlib.crc(ctx.all_sets()) == int(c["sets_crc"])
+    ctx.close()
