@@ -47,6 +47,10 @@ def parse_args():
                     "before measuring (BASELINE.md: 300 proposals, every 4th accepted)")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--anneal-seconds", type=float, default=4.0,
+                    help="after the timed region, run the batched SA host end to end for this long and report "
+                         "best-length-vs-wallclock (0 = skip)")
+    ap.add_argument("--anneal-batch", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -122,18 +126,11 @@ def cpu_baseline(rows, kind: int, budget_s: float, spot):
 
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from lvb_amd.launch import Ranks
+    ranks = Ranks()                       # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
+    rank, world, local_rank = ranks.rank, ranks.world, ranks.local_rank
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from lvb_amd import api, host
 
@@ -141,7 +138,7 @@ def main():
     t_setup = time.perf_counter()
     rows, min_len = host.prepare_alignment(synth_rows(args.taxa, args.sites, args.seed))
     ctx = api.FitchContext(text_rows=rows, device=local_rank)      # encode on the device
-    tree = host.HostTree(args.taxa, seed=args.seed * 1000 + rank + 1)  # each rank: its own restart
+    tree = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed))  # each rank: its own restart
     length = tree.upload(ctx)
     for _ in range(args.walk):                                      # short random walk, as BASELINE.md
         e = tree.propose(kind)
@@ -160,16 +157,12 @@ def main():
 
     if world > 1:
         # RCCL communicator of the scoring library itself (not torch's): id from rank 0
-        uid = [api.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
+        uid = ranks.share_bytes(api.comm_unique_id() if rank == 0 else None)
+        ctx.comm_init(world, rank, uid)
 
     def barrier():
         ctx.synchronize()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        ranks.barrier()
 
     for i in range(args.warmup):
         batches[i % len(batches)].launch()
@@ -186,11 +179,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = ranks.max_over_ranks(elapsed)   # the slowest rank defines the step time
 
     # per-launch accounting for the roofline: average over the batches actually launched
     launched = [stats[i % len(batches)] for i in range(args.steps)]
@@ -198,6 +187,13 @@ def main():
     mean_dirty = float(np.mean([s["dirty_nodes"] / s["candidates"] for s in launched]))
     launch_ms = kernel_ms / args.steps
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        t = json.loads(tfile.read_text())
+        if (t.get("taxa"), t.get("sites"), t.get("batch"), t.get("move")) == (args.taxa, args.sites, args.batch, args.move):
+            traffic = t["hbm_bytes_per_launch"]   # rocprofv3 PMC passes (profiles/collect.sh), gfx950-corrected
 
     total_trees = args.batch * args.steps * world
     out = {
@@ -224,20 +220,42 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "fitch_walk<false,false>", "launch_ms": launch_ms,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "lvbgpu::fitch_walk<false>", "launch_ms": launch_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "algorithmic bytes = (D+3) clean rows x nwords x 8 per candidate; rows are re-read from "
                     "the XCD L2 / Infinity Cache, so achieved may exceed the HBM figure",
         },
     }
+    if args.anneal_seconds > 0:
+        # second half of the metric: best length vs wall clock, whole host loop included
+        # (proposal generation, program build, H2D, kernels, D2H, accept/commit) - not part of `value`
+        p = host.anneal_defaults()
+        p.seed = args.seed * 7919 + rank + 1
+        p.algorithm = {"nni": 10, "spr": 11, "tbr": 12}[args.move]
+        p.batch = args.anneal_batch
+        p.t0 = 0.0   # estimated as StartingTemperature() does (65 % of uphill moves accepted)
+        p.min_len_tree = min_len
+        p.max_seconds = args.anneal_seconds
+        p.log_cap = 4096
+        res, log = host.anneal(ctx, tree, p)
+        keep = log[:: max(1, len(log) // 12)] + log[-1:]
+        out["anneal"] = {
+            "seconds": round(res["seconds"], 3), "start_length": res["start_length"],
+            "best_length": res["best_length"], "scored": res["scored"], "consumed": res["consumed"],
+            "accepted": res["accepted"], "device_steps": res["device_steps"],
+            "scored_per_s": round(res["scored"] / res["seconds"]), "consumed_per_s": round(res["consumed"] / res["seconds"]),
+            "device_fraction": round(res["seconds_device"] / res["seconds"], 3), "batch": args.anneal_batch,
+            "t_final": res["t_final"], "temperatures": res["temperatures"], "frozen": res["frozen"],
+            "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, kind, args.cpu_seconds, spot)
     for b in batches:
         b.free()
+    tree.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
     if rank == 0:
         print(json.dumps(out))
 

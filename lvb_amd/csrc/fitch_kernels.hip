@@ -1,26 +1,36 @@
 // fitch_kernels.hip - hand-written gfx950 (MI355X, CDNA4) kernels of the Fitch scoring path.
 //
 // What is computed is exactly getplen's arithmetic (reference TreeEvaluation.c:204-264): for a
-// list of dirty nodes in postorder, z = fitch(x, y) per packed word with the number of sites
-// that needed a union counted, plus the two root combines.  How it is laid out is native:
+// list of dirty nodes in postorder, z = fitch(x, y) per site with the number of sites that needed
+// a union counted, plus the two root combines.  How it is laid out is native:
 //
-//   * one wavefront (64 lanes) walks one candidate's postorder program for one 128-word site
-//     tile: a lane owns 16 bytes (two 64-bit reference words = 32 sites) so every state-set row
-//     load is one coalesced 1 KiB global_load_dwordx4 per wave;
-//   * the running node set lives in 4 VGPRs ("acc"); sibling sets that must wait for the other
-//     subtree sit on an operand stack - two register levels for NNI/SPR/TBR deltas, LDS
-//     (ds_write_b128 / ds_read_b128, one 1 KiB level per wave) for whole-tree programs;
-//   * the 64-bit SWAR step is split into independent 32-bit halves (no carry crosses a nibble,
-//     so the split is exact): 11 VALU ops per half incl. v_bcnt_u32_b32 accumulation and one
-//     v_bfi_b32 select;
-//   * union counts are reduced across the wave with ballot + scalar popcount bit-slices (all
-//     SALU, result lands in an SGPR) and added with one integer atomic per (candidate, tile):
-//     integer addition commutes, so lengths are bit-exact whatever the arrival order;
+//   * BIT-PLANE state sets in HBM.  The reference packs one 4-bit set per nibble (LVB.h:72-89)
+//     and needs ~9 ALU ops per 8 sites to find empty intersections inside nibbles.  On the
+//     device each 16-byte group of a row holds the SAME 32 sites as the reference's two 64-bit
+//     words, but transposed: four 32-bit planes (A, C, G, T), bit s = site s.  The Fitch step is
+//     then 9 VALU ops per 32 sites: three v_bitop3 build any = OR_b(x_b & y_b), one v_bcnt
+//     accumulates the non-empty count, four v_bitop3 select (any ? x&y : x|y) per plane.
+//     The transposition is a per-lane bit shuffle applied once on the way in (leaf rows, strict-
+//     compat operands) and on the way out (lvbgpu_get_sets, strict-compat results); lengths and
+//     change counts do not depend on it.
+//   * one wavefront (64 lanes) walks one candidate's postorder program for one 2048-site tile:
+//     a lane owns one 16-byte group, so every row load is one coalesced 1 KiB
+//     global_load_dwordx4 per wave;
+//   * the program's tokens are fetched once per 64 with a coalesced vector load (lane k holds
+//     token k and its row offset) and handed to the scalar unit with v_readlane; row loads run
+//     four tokens ahead of the arithmetic in a 4-slot register ring (they depend only on the
+//     program, never on computed values), waited for with counted vmcnt;
+//   * the running node set lives in 4 VGPRs; sibling sets that must wait for the other subtree sit
+//     on an operand stack in LDS (ds_write_b128 / ds_read_b128, 1 KiB per level per wave: two
+//     levels for NNI/SPR/TBR deltas, up to log2(n)+1 for whole-tree programs);
+//   * union counts are reduced across the wave with ballot + scalar popcount bit-slices (SALU,
+//     result in an SGPR) and added with one integer atomic per (candidate, tile): integer addition
+//     commutes, so lengths are bit-exact whatever the arrival order;
 //   * blockIdx -> work mapping is XCD-aware: items are ordered tile-major and each of the 8 XCDs
-//     takes a contiguous eighth, so the waves resident on one XCD at any moment read the same
-//     column slice of the resident tree and hit that XCD's private 4 MiB L2.
+//     takes a contiguous eighth, so the waves resident on one XCD read the same column slice of
+//     the resident tree and hit that XCD's private 4 MiB L2 (measured hit rate 97 %).
 //
-// No MFMA: this is bitwise integer streaming, bound by L2/HBM bandwidth and VALU issue.
+// No MFMA: bitwise integer streaming, bound by L2/HBM bandwidth and VALU issue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,30 +40,67 @@ namespace lvbgpu
 {
 
 // ---------------------------------------------------------------------------------------------
-// Fitch step on one 32-bit half (8 sites).  x, y: child state sets; returns the parent's set and
-// adds the number of sites with a NON-empty intersection to `nonempty` (changes = 8 - that).
-// Reference: TreeEvaluation.c:219-230 with MASK_SEVEN/MASK_EIGHT of LVB.h:88-89.
-__device__ __forceinline__ uint32_t fitch32(uint32_t x, uint32_t y, uint32_t &nonempty)
+// Fitch step on one 16-byte bit-plane group (32 sites).  x, y: child state sets (planes A,C,G,T
+// in .x .y .z .w); returns the parent's set; adds the number of sites with a NON-empty
+// intersection to `nonempty` (changes = 32 - that).  Per site this is the reference's word step
+// (TreeEvaluation.c:219-230): intersection if non-empty, else union and one change.
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c)
 {
-    const uint32_t M7 = 0x77777777u, M8 = 0x88888888u;
-    const uint32_t both = x & y;
-    const uint32_t either = x | y;
-    uint32_t u = (both & M7) + M7;      // bit 3 of a nibble: its low three bits are not all zero
-    u = (u | both) & M8;                // ... or bit 3 itself is set  => intersection non-empty
-    nonempty += __builtin_popcount(u);  // v_bcnt_u32_b32 accumulates
-    const uint32_t full = (u << 1) - (u >> 3); // 0xF in every non-empty nibble (mod 2^32 is exact)
-    // non-empty: keep the intersection; empty: take the union          (one v_bfi_b32)
-    return (full & both) | (~full & either);
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); // (a & b) | c
+}
+__device__ __forceinline__ uint32_t pick(uint32_t a, uint32_t b, uint32_t any)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, any, 0xD4); // any ? a & b : a | b
 }
 
-__device__ __forceinline__ uint4 fitch128(const uint4 x, const uint4 y, uint32_t &nonempty)
+__device__ __forceinline__ uint4 fitch_planes(const uint4 x, const uint4 y, uint32_t &nonempty)
 {
+    uint32_t any = x.w & y.w;
+    any = and_or(x.z, y.z, any);
+    any = and_or(x.y, y.y, any);
+    any = and_or(x.x, y.x, any);
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(nonempty) : "v"(any)); // nonempty += popcount(any)
     uint4 z;
-    z.x = fitch32(x.x, y.x, nonempty);
-    z.y = fitch32(x.y, y.y, nonempty);
-    z.z = fitch32(x.z, y.z, nonempty);
-    z.w = fitch32(x.w, y.w, nonempty);
+    z.x = pick(x.x, y.x, any);
+    z.y = pick(x.y, y.y, any);
+    z.z = pick(x.z, y.z, any);
+    z.w = pick(x.w, y.w, any);
     return z;
+}
+
+// nibble layout (reference: nibble k of the 128-bit group = site k, bit0=A..bit3=T) <-> planes
+__device__ __forceinline__ uint32_t gather_bit(uint32_t w, uint32_t b)
+{
+    uint32_t x = (w >> b) & 0x11111111u; // bit b of each of 8 nibbles, at positions 0,4,..,28
+    x = (x | (x >> 3)) & 0x03030303u;
+    x = (x | (x >> 6)) & 0x000F000Fu;
+    x = (x | (x >> 12)) & 0xFFu;
+    return x; // 8 sites
+}
+__device__ __forceinline__ uint32_t scatter_bits(uint32_t byte, uint32_t b)
+{
+    uint32_t x = byte & 0xFFu;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x << b;
+}
+__device__ __forceinline__ uint4 nibbles_to_planes(const uint4 w)
+{
+    uint32_t p[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++)
+        p[b] = gather_bit(w.x, b) | (gather_bit(w.y, b) << 8) | (gather_bit(w.z, b) << 16) | (gather_bit(w.w, b) << 24);
+    return make_uint4(p[0], p[1], p[2], p[3]);
+}
+__device__ __forceinline__ uint4 planes_to_nibbles(const uint4 p)
+{
+    uint32_t w[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++)
+        w[q] = scatter_bits(p.x >> (8 * q), 0) | scatter_bits(p.y >> (8 * q), 1) | scatter_bits(p.z >> (8 * q), 2) |
+               scatter_bits(p.w >> (8 * q), 3);
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Sum of a small per-lane value over the 64 lanes of the wave, computed on the scalar unit:
@@ -70,13 +117,12 @@ __device__ __forceinline__ uint32_t wave_sum_bits(uint32_t v, uint32_t nbits)
 }
 
 // ---------------------------------------------------------------------------------------------
-// The walk.  LDS_STACK: operand stack in LDS (any depth) instead of two register levels.
-// COMMIT: store every produced node set to rows_out[dst] and add its change count to
+// The walk.  COMMIT: store every produced node set to rows_out[dst] and add its change count to
 // changes_out[dst] (accepting a candidate / full evaluation / strict-compat write-back).
-template <bool LDS_STACK, bool COMMIT>
+template <bool COMMIT>
 __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 {
-    extern __shared__ uint4 lds_stack[]; // [wave][level][lane], LDS_STACK only
+    extern __shared__ uint4 lds_stack[]; // operand stack: [wave][level][lane]
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,94 +134,138 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     const uint32_t item = pos * WALK_WAVES + wave;
     if (item >= a.nitems)
         return;
-    const uint32_t tile = item / a.B;
-    const uint32_t cand = item - tile * a.B;
+    // an item = (tile group, candidate): the wave walks the candidate's program once per tile of
+    // its group, so descriptor/token fetches and the final reduction are paid once per group
+    const uint32_t group = item / a.B;
+    const uint32_t cand = item - group * a.B;
+    const uint32_t tile_begin = (group * a.ntiles) / a.ngroups;
+    const uint32_t tile_end = ((group + 1u) * a.ntiles) / a.ngroups;
 
     const CandDesc cd = a.cands[cand];
     const uint32_t *__restrict__ tk = a.toks + cd.tok_off;
     const int32_t *__restrict__ ds = a.dsts + cd.dst_off;
-    const size_t col = (size_t)tile * 64u + lane;
-    const uint4 *__restrict__ in = a.rows_in + col;
+    uint32_t col = tile_begin * 64u + lane;          // 16-byte group within a row
+    uint32_t voff = col * 16u;                       // its byte offset (a row is far below 4 GiB)
+    const char *__restrict__ in = reinterpret_cast<const char *>(a.rows_in);
 
-    uint4 acc = make_uint4(0, 0, 0, 0), s0 = acc, s1 = acc;
-    uint32_t sp = 0;        // LDS stack pointer (levels)
-    uint32_t nonempty = 0;  // sites with non-empty intersection, this lane, whole program
-    uint32_t k_comb = 0;    // combines done (index into ds[])
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint32_t sp = 0;       // stack pointer (levels)
+    uint32_t nonempty = 0; // sites with non-empty intersection, this lane, whole program
+    uint32_t k_comb = 0;   // combines done (index into ds[])
     uint4 *const my_stack = lds_stack + (size_t)wave * a.stack_depth * 64u + lane;
 
-    auto produce = [&](uint32_t ne_before) {
-        if constexpr (COMMIT)
-        {
-            const int32_t dst = ds[k_comb];
-            const uint32_t ch = 32u - (nonempty - ne_before); // <= 32: 6 bits
-            const uint32_t s = wave_sum_bits(ch, 6);
-            if (dst >= 0)
-                a.rows_out[(size_t)dst * a.out_stride4 + col] = acc;
-            if (lane == 0 && s)
-                atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
-        }
+    // row `off16` (in 16-byte units from rows_in) -> this lane's group: scalar base + VGPR offset
+    auto load_row = [&](uint32_t off16) -> uint4 {
+        const char *row = in + ((size_t)off16 << 4);
+        return *reinterpret_cast<const uint4 *>(row + voff);
+    };
+
+    // COMMIT: the combine just done produced node ds[k_comb] with `ch` changes in this lane
+    auto produce = [&](uint32_t ch) {
+        const int32_t dst = ds[k_comb];
+        const uint32_t s = wave_sum_bits(ch, 6); // ch <= 32
+        if (dst >= 0)
+            a.rows_out[(size_t)dst * a.out_stride4 + col] = acc;
+        if (lane == 0 && s)
+            atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
         k_comb++;
     };
 
-    uint32_t tok = tk[0];
-    uint4 cur = in[(size_t)(tok & TOK_ROW_MASK) * a.in_stride4];
-    for (uint32_t k = 0; k < cd.ntok; k++)
-    {
-        // prefetch the next token's row before working on this one: the row stream depends only
-        // on the program, never on computed values
-        const uint32_t tok_next = tk[(k + 1 < cd.ntok) ? k + 1 : k];
-        const uint4 nxt = in[(size_t)(tok_next & TOK_ROW_MASK) * a.in_stride4];
-
-        if (tok & TOK_FRESH)
+    // one token: tok is wave-uniform (SGPR), cur is the row it names.  The common case (no flag
+    // bits) is a single combine; chain starts and merges are rare (2-3 per NNI/SPR/TBR program).
+    // A chain start sets acc = cur and still runs the common combine: fitch(cur, cur) = cur and
+    // counts 32 non-empty sites (every valid set is non-empty), which cd.nfresh accounts for.
+    uint32_t nonempty_rare = 0; // kept apart so the hot path's counter has a single definition
+    auto step = [&](uint32_t tok, const uint4 cur) {
+        const bool special = (tok >> TOK_MERGE_SHIFT) != 0u;
+        const bool fresh = special && (tok & TOK_FRESH);
+        if (__builtin_expect(fresh, 0))
         {
             if (tok & TOK_PUSH)
             {
-                if constexpr (LDS_STACK)
-                {
-                    my_stack[(size_t)sp * 64u] = acc;
-                    sp++;
-                }
-                else
-                {
-                    s1 = s0;
-                    s0 = acc;
-                }
+                my_stack[(size_t)sp * 64u] = acc;
+                sp++;
             }
             acc = cur;
         }
-        else
+        const uint32_t before = nonempty;
+        acc = fitch_planes(acc, cur, nonempty);
+        if constexpr (COMMIT)
         {
-            const uint32_t before = nonempty;
-            acc = fitch128(acc, cur, nonempty);
-            produce(before);
+            if (!fresh)
+                produce(32u - (nonempty - before));
         }
-        for (uint32_t m = (tok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK; m != 0; m--)
+        if (__builtin_expect(special, 0))
         {
-            uint4 other;
-            if constexpr (LDS_STACK)
+            for (uint32_t m = (tok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK; m != 0; m--)
             {
                 sp--;
-                other = my_stack[(size_t)sp * 64u];
+                const uint4 other = my_stack[(size_t)sp * 64u];
+                const uint32_t b2 = nonempty_rare;
+                acc = fitch_planes(other, acc, nonempty_rare);
+                if constexpr (COMMIT)
+                    produce(32u - (nonempty_rare - b2));
             }
-            else
-            {
-                other = s0;
-                s0 = s1;
-            }
-            const uint32_t before = nonempty;
-            acc = fitch128(other, acc, nonempty);
-            produce(before);
         }
-        tok = tok_next;
-        cur = nxt;
+    };
+
+    for (uint32_t tile = tile_begin; tile < tile_end; tile++, col += 64u, voff += 1024u)
+    for (uint32_t c0 = 0; c0 < cd.ntok; c0 += 64u)
+    {
+        const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
+        // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
+        const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
+        const uint32_t myoff = (mytok & TOK_ROW_MASK) * a.in_stride4;
+        auto tok_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)mytok, (int)j); };
+        auto off_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)myoff, (int)j); };
+
+        if (cnt < 4u)
+        {
+            for (uint32_t j = 0; j < cnt; j++)
+                step(tok_at(j), load_row(off_at(j)));
+            continue;
+        }
+        // 4-slot ring: slot q holds the row of token j+q
+        uint4 ra = load_row(off_at(0)), rb = load_row(off_at(1)), rc = load_row(off_at(2)), rd = load_row(off_at(3));
+        uint32_t j = 0;
+        for (; j + 8u <= cnt; j += 4u) // every refill below is in range: no branches, counted vmcnt
+        {
+            step(tok_at(j), ra);
+            ra = load_row(off_at(j + 4u));
+            step(tok_at(j + 1u), rb);
+            rb = load_row(off_at(j + 5u));
+            step(tok_at(j + 2u), rc);
+            rc = load_row(off_at(j + 6u));
+            step(tok_at(j + 3u), rd);
+            rd = load_row(off_at(j + 7u));
+        }
+        // 4..7 tokens left, the first four already in the ring
+        const uint32_t left = cnt - j;
+        step(tok_at(j), ra);
+        if (left > 4u)
+            ra = load_row(off_at(j + 4u));
+        step(tok_at(j + 1u), rb);
+        if (left > 5u)
+            rb = load_row(off_at(j + 5u));
+        step(tok_at(j + 2u), rc);
+        if (left > 6u)
+            rc = load_row(off_at(j + 6u));
+        step(tok_at(j + 3u), rd);
+        if (left > 4u)
+            step(tok_at(j + 4u), ra);
+        if (left > 5u)
+            step(tok_at(j + 5u), rb);
+        if (left > 6u)
+            step(tok_at(j + 6u), rc);
     }
 
-    // changes of this lane = 32 sites per combine minus the non-empty ones
-    const uint32_t lane_changes = 32u * cd.ncomb - nonempty;
-    const uint32_t nbits = 32u - __builtin_clz(32u * cd.ncomb | 1u);
+    // changes of this lane = 32 sites per combine (and per chain start, see step) minus the non-empty ones
+    const uint32_t per_lane = 32u * (cd.ncomb + cd.nfresh) * (tile_end - tile_begin);
+    const uint32_t lane_changes = per_lane - nonempty - nonempty_rare;
+    const uint32_t nbits = 32u - __builtin_clz(per_lane | 1u);
     unsigned long long total = wave_sum_bits(lane_changes, nbits);
 
-    if (tile == 0)
+    if (group == 0)
     {
         // clean nodes contribute their cached changes (TreeEvaluation.c:191-202):
         // base = cd.base + [resident: S_all - sum over this candidate's dirty nodes of changes]
@@ -232,8 +322,9 @@ __global__ __launch_bounds__(256) void sum_changes_kernel(const unsigned long lo
     }
 }
 
-// fill the padding of every row (words [nwords, stride)) and whole rows [first_row, nrows) with
-// all-ones: an all-N column never adds length and fitch(F, F) = F, so padded lanes stay inert
+// fill the padding of every row (words [nwords, stride)) and whole rows [first_full_row, nrows)
+// with all-ones: an all-N column never adds length and fitch(all, all) = all in either layout,
+// so padded lanes stay inert
 __global__ void fill_pad_kernel(uint64_t *rows, uint32_t nrows, uint32_t nwords, uint32_t stride_words,
                                 uint32_t first_full_row)
 {
@@ -245,9 +336,30 @@ __global__ void fill_pad_kernel(uint64_t *rows, uint32_t nrows, uint32_t nwords,
             rows[(size_t)row * stride_words + w] = ~0ull;
 }
 
-// DNAToBinary on the device (reference DataOperations.c:164-249): one thread = one packed word.
-// text: n rows of m bytes (row-major, no terminators).  *bad is set to 1 + the first offending
-// flat position seen by some thread if a symbol is not one the reference accepts.
+// in-place layout change of rows [0, nrows): to_planes ? reference nibbles -> bit planes : back
+__global__ void relayout_kernel(uint4 *rows, uint32_t nrows, uint32_t stride4, uint32_t to_planes)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= stride4)
+        return;
+    for (uint32_t row = blockIdx.y; row < nrows; row += gridDim.y)
+    {
+        uint4 *p = rows + (size_t)row * stride4 + g;
+        *p = to_planes ? nibbles_to_planes(*p) : planes_to_nibbles(*p);
+    }
+}
+
+// one resident row -> reference nibble layout in a scratch buffer (lvbgpu_get_sets)
+__global__ void export_row_kernel(const uint4 *row, uint4 *out, uint32_t stride4)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < stride4)
+        out[g] = planes_to_nibbles(row[g]);
+}
+
+// DNAToBinary on the device (reference DataOperations.c:164-249): one thread = one packed word in
+// the reference's nibble layout.  text: n rows of m bytes (row-major, no terminators).  *bad
+// becomes 1 + the smallest offending flat position if a symbol is not one the reference accepts.
 __constant__ int8_t k_iupac[256];
 
 __global__ void encode_text_kernel(const uint8_t *text, uint32_t n, uint64_t m, uint32_t nwords,
@@ -314,39 +426,31 @@ hipError_t upload_iupac_table()
     return hipMemcpyToSymbol(HIP_SYMBOL(k_iupac), tab, sizeof(tab));
 }
 
-hipError_t launch_walk(const WalkArgs &a, bool lds_stack, bool commit, hipStream_t stream)
+hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream)
 {
     if (a.nitems == 0)
         return hipSuccess;
+    if (a.ngroups == 0 || a.ngroups > a.ntiles || a.nitems != a.B * a.ngroups)
+        return hipErrorInvalidValue;
     uint32_t nblk = (a.nitems + WALK_WAVES - 1) / WALK_WAVES;
     nblk = (nblk + 7u) & ~7u; // the XCD remap needs a multiple of 8
-    const size_t lds = lds_stack ? (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4) : 0;
+    const size_t lds = (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4);
     const dim3 grid(nblk), block(WALK_THREADS);
-    if (lds_stack)
-    {
-        if (commit)
-            hipLaunchKernelGGL((fitch_walk<true, true>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((fitch_walk<true, false>), grid, block, lds, stream, a);
-    }
+    if (commit)
+        hipLaunchKernelGGL((fitch_walk<true>), grid, block, lds, stream, a);
     else
-    {
-        if (commit)
-            hipLaunchKernelGGL((fitch_walk<false, true>), grid, block, 0, stream, a);
-        else
-            hipLaunchKernelGGL((fitch_walk<false, false>), grid, block, 0, stream, a);
-    }
+        hipLaunchKernelGGL((fitch_walk<false>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t raise_lds_limit()
 {
     // whole-tree programs may want more than the default 64 KiB of dynamic LDS
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fitch_walk<true, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fitch_walk<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess)
         return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&fitch_walk<true, false>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&fitch_walk<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
 }
 
@@ -368,16 +472,31 @@ hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first,
 hipError_t launch_fill_pad(uint64_t *rows, uint32_t nrows, uint32_t nwords, uint32_t stride_words,
                            uint32_t first_full_row, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fill_pad_kernel, dim3((stride_words + 255) / 256, nrows < 65535u ? nrows : 65535u), dim3(256), 0, stream, rows, nrows,
-                       nwords, stride_words, first_full_row);
+    hipLaunchKernelGGL(fill_pad_kernel, dim3((stride_words + 255) / 256, nrows < 65535u ? nrows : 65535u), dim3(256), 0,
+                       stream, rows, nrows, nwords, stride_words, first_full_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_relayout(uint4 *rows, uint32_t nrows, uint32_t stride4, bool to_planes, hipStream_t stream)
+{
+    if (nrows == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(relayout_kernel, dim3((stride4 + 255) / 256, nrows < 65535u ? nrows : 65535u), dim3(256), 0,
+                       stream, rows, nrows, stride4, to_planes ? 1u : 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_row(const uint4 *row, uint4 *out, uint32_t stride4, hipStream_t stream)
+{
+    hipLaunchKernelGGL(export_row_kernel, dim3((stride4 + 255) / 256), dim3(256), 0, stream, row, out, stride4);
     return hipGetLastError();
 }
 
 hipError_t launch_encode_text(const uint8_t *text, uint32_t n, uint64_t m, uint32_t nwords, uint32_t stride_words,
                               uint64_t *rows, unsigned long long *bad, hipStream_t stream)
 {
-    hipLaunchKernelGGL(encode_text_kernel, dim3((nwords + 255) / 256, n < 65535u ? n : 65535u), dim3(256), 0, stream, text, n, m, nwords,
-                       stride_words, rows, bad);
+    hipLaunchKernelGGL(encode_text_kernel, dim3((nwords + 255) / 256, n < 65535u ? n : 65535u), dim3(256), 0, stream,
+                       text, n, m, nwords, stride_words, rows, bad);
     return hipGetLastError();
 }
 

@@ -10,7 +10,7 @@
 //                          numberofpossiblebranches @40, nwords @72)
 //   LVB.h:121-128          TREESTACK_TREE_NODES (40 bytes)
 //   DataStructure.h:86-97  Parameters (4040 bytes, passed BY VALUE, unused by getplen)
-// (sizes/offsets are asserted against the compiled reference in tests/test_layout.py).
+// (sizes/offsets are asserted against the compiled reference by the layout test under tests/).
 //
 // Semantics kept: dirty == sitestate[0]==0; dirty nodes' sitestate and changes are rewritten in
 // the caller's tree block; the three scratch arrays are accepted and ignored; failure prints

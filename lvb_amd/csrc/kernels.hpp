@@ -11,9 +11,11 @@ namespace lvbgpu
 
 constexpr uint32_t WALK_WAVES = 4;                // waves per workgroup
 constexpr uint32_t WALK_THREADS = 64 * WALK_WAVES;
-constexpr uint32_t TILE_WORDS = 128;              // 64 lanes x 16 B = 128 reference words per wave tile
+constexpr uint32_t TILE_WORDS = 128;              // 64 lanes x 16 B = 128 reference words (2048 sites) per wave tile
 constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
-constexpr uint32_t REG_STACK_LEVELS = 2;          // operand-stack levels kept in VGPRs
+
+constexpr uint32_t TARGET_WAVES = 32768;          // aim for at least this many (group, candidate) waves per launch
+constexpr uint32_t MAX_TILES_PER_WAVE = 8;
 
 constexpr uint32_t CAND_RESIDENT_BASE = 1u;       // base += *s_all - sum(node_changes[dst])
 
@@ -22,13 +24,14 @@ struct CandDesc
     uint32_t tok_off, ntok;   // tokens of this candidate in WalkArgs::toks
     uint32_t dst_off, ncomb;  // produced nodes (one per combine) in WalkArgs::dsts
     long long base;           // changes of clean nodes supplied by the host (strict compat) or 0
-    uint32_t flags, pad;
+    uint32_t flags;
+    uint32_t nfresh;          // chain starts (tokens with TOK_FRESH) in this program
 };
 static_assert(sizeof(CandDesc) == 32, "CandDesc layout");
 
 struct WalkArgs
 {
-    const uint4 *rows_in;       // state-set rows, row r at rows_in + r * in_stride4
+    const uint4 *rows_in;       // state-set rows (BIT-PLANE layout), row r at rows_in + r * in_stride4
     uint4 *rows_out;            // COMMIT: where produced sets go (may alias rows_in)
     const uint32_t *toks;
     const int32_t *dsts;
@@ -39,20 +42,36 @@ struct WalkArgs
     unsigned long long *changes_out;    // COMMIT: per-node change accumulators, zeroed for dsts
     uint32_t in_stride4, out_stride4;   // row strides in 16-byte units
     uint32_t B, ntiles;
-    uint32_t nitems;                    // B * ntiles
-    uint32_t stack_depth;               // LDS levels per wave (LDS_STACK)
+    uint32_t ngroups;                   // tiles are dealt to this many groups; one wave walks one (group, candidate)
+    uint32_t nitems;                    // B * ngroups
+    uint32_t stack_depth;               // operand-stack levels per wave in LDS (>= 1)
     uint32_t root_slot;                 // COMMIT: changes_out slot that collects the two root combines
 };
 
+// how many tile groups to cut ntiles into for a batch of B candidates
+inline uint32_t choose_groups(uint32_t B, uint32_t ntiles)
+{
+    uint32_t per_wave = (uint32_t)(((uint64_t)B * ntiles) / TARGET_WAVES);
+    if (per_wave < 1)
+        per_wave = 1;
+    if (per_wave > MAX_TILES_PER_WAVE)
+        per_wave = MAX_TILES_PER_WAVE;
+    return (ntiles + per_wave - 1) / per_wave;
+}
+
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
-hipError_t launch_walk(const WalkArgs &a, bool lds_stack, bool commit, hipStream_t stream);
+hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);
 hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, hipStream_t stream);
 // scalars[0] = sum of changes[first, last), scalars[1] = scalars[0] + changes[last] (tree length)
 hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first, uint32_t last, long long *scalars,
                               hipStream_t stream);
 hipError_t launch_fill_pad(uint64_t *rows, uint32_t nrows, uint32_t nwords, uint32_t stride_words,
                            uint32_t first_full_row, hipStream_t stream);
+// reference nibble layout <-> device bit-plane layout, in place, rows [0, nrows)
+hipError_t launch_relayout(uint4 *rows, uint32_t nrows, uint32_t stride4, bool to_planes, hipStream_t stream);
+// one bit-plane row -> nibble layout in `out`
+hipError_t launch_export_row(const uint4 *row, uint4 *out, uint32_t stride4, hipStream_t stream);
 hipError_t launch_encode_text(const uint8_t *text, uint32_t n, uint64_t m, uint32_t nwords, uint32_t stride_words,
                               uint64_t *rows, unsigned long long *bad, hipStream_t stream);
 

@@ -128,6 +128,8 @@ struct lvbgpu_ctx
     ProgramBuilder pb;
 
     DevBuf d_prog, d_len; // scratch for single-program launches (set_tree, commit)
+    DevBuf d_export;      // one row in nibble layout (lvbgpu_get_sets)
+    lvbgpu_batch *step_batch = nullptr; // recycled by lvbgpu_score_batch
     PinBuf h_pin;
     DevBuf d_cin, d_cout; // strict-compat arenas
     PinBuf h_cin, h_cout;
@@ -161,6 +163,7 @@ struct lvbgpu_batch
     int32_t B = 0;
     DevBuf d_prog; // [cands][toks][dsts]
     DevBuf d_len;
+    PinBuf h_len;  // lengths land here after every launch (async copy on the context's stream)
     size_t off_toks = 0, off_dsts = 0;
     lvbgpu_batch_stats stats{};
     bool full_mode = false; // whole topologies: reads leaf rows only
@@ -205,6 +208,8 @@ struct Packed
         cd.ncomb = (uint32_t)(p.dsts.size() - dst0);
         cd.base = base;
         cd.flags = flags;
+        for (size_t i = tok0; i < p.toks.size(); i++)
+            cd.nfresh += (p.toks[i] & TOK_FRESH) ? 1u : 0u;
         cands.push_back(cd);
     }
 };
@@ -249,7 +254,8 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, siz
     a.out_stride4 = ctx->stride4;
     a.B = B;
     a.ntiles = ctx->ntiles;
-    a.nitems = B * ctx->ntiles;
+    a.ngroups = choose_groups(B, ctx->ntiles);
+    a.nitems = B * a.ngroups;
     a.stack_depth = (uint32_t)std::max(max_stack, 1);
     a.root_slot = (uint32_t)ctx->nb;
     return a;
@@ -296,11 +302,13 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     return LVBGPU_OK;
 }
 
-// everything that is not a leaf word becomes all-ones (inert under fitch)
+// everything that is not a leaf word becomes all-ones (inert under fitch); then the leaf rows go
+// from the reference's nibble layout to the device's bit-plane layout (all-ones stays all-ones)
 int finish_rows(lvbgpu_ctx *ctx)
 {
     HIPCHK(ctx, launch_fill_pad(ctx->d_rows, (uint32_t)ctx->nb, (uint32_t)ctx->nwords, ctx->stride_words,
                                 (uint32_t)ctx->n, ctx->stream));
+    HIPCHK(ctx, launch_relayout((uint4 *)ctx->d_rows, (uint32_t)ctx->n, ctx->stride4, true, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return LVBGPU_OK;
 }
@@ -440,8 +448,14 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipFree(ctx->d_changes);
     if (ctx->d_scalars)
         (void)hipFree(ctx->d_scalars);
+    if (ctx->step_batch)
+    {
+        ctx->step_batch->ctx = nullptr;
+        lvbgpu_batch_free(ctx->step_batch);
+    }
     ctx->d_prog.release();
     ctx->d_len.release();
+    ctx->d_export.release();
     ctx->h_pin.release();
     ctx->d_cin.release();
     ctx->d_cout.release();
@@ -541,7 +555,7 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_changes + ctx->nb, 0, 8, ctx->stream));
     }
     WalkArgs a = resident_args(ctx, ctx->d_prog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
-    HIPCHK(ctx, launch_walk(a, prog.max_stack > (int32_t)REG_STACK_LEVELS, true, ctx->stream));
+    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
     long long scal[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(scal, ctx->d_scalars, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -622,8 +636,11 @@ extern "C" int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out)
     if (node >= ctx->n && !ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_rows + (size_t)node * ctx->stride_words, (size_t)ctx->nwords * 8,
-                               hipMemcpyDeviceToHost, ctx->stream));
+    // resident rows are bit planes; hand back the reference's nibble layout
+    HIPCHK(ctx, ctx->d_export.reserve((size_t)ctx->stride_words * 8));
+    HIPCHK(ctx, launch_export_row((const uint4 *)(ctx->d_rows + (size_t)node * ctx->stride_words),
+                                  (uint4 *)ctx->d_export.p, ctx->stride4, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_export.p, (size_t)ctx->nwords * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return LVBGPU_OK;
 }
@@ -641,6 +658,7 @@ extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
     }
     b->d_prog.release();
     b->d_len.release();
+    b->h_len.release();
     delete b;
 }
 
@@ -657,6 +675,7 @@ int finish_batch(lvbgpu_ctx *ctx, lvbgpu_batch *b, const Packed &pk, bool full_m
     if (rc != LVBGPU_OK)
         return rc;
     HIPCHK(ctx, b->d_len.reserve((size_t)b->B * 8));
+    HIPCHK(ctx, b->h_len.reserve((size_t)b->B * 8));
     b->full_mode = full_mode;
     b->stats.candidates = b->B;
     b->stats.combines = (int64_t)pk.dsts.size();
@@ -668,19 +687,17 @@ int finish_batch(lvbgpu_ctx *ctx, lvbgpu_batch *b, const Packed &pk, bool full_m
 }
 } // namespace
 
-extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
-                                  const int32_t *roots, lvbgpu_batch **out)
+namespace
 {
-    if (!ctx || !out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
-        return LVBGPU_E_ARG;
-    *out = nullptr;
-    if (!ctx->have_tree)
-        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+// fill `bt` (new or recycled: its buffers only ever grow) with the programs of B candidates
+int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
+               const int32_t *roots)
+{
     static_assert(sizeof(lvbgpu_edit) == sizeof(Edit), "edit layout");
     Packed pk;
     Program prog; // all candidates appended into one token/dst stream
     std::string why;
+    pk.cands.reserve(B);
     for (int32_t b = 0; b < B; b++)
     {
         const int32_t e0 = edit_offsets[b], e1 = edit_offsets[b + 1];
@@ -697,12 +714,25 @@ extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
     }
     pk.toks.swap(prog.toks);
     pk.dsts.swap(prog.dsts);
+    bt->ctx = ctx;
+    bt->B = B;
+    return finish_batch(ctx, bt, pk, false);
+}
+} // namespace
+
+extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
+                                  const int32_t *roots, lvbgpu_batch **out)
+{
+    if (!ctx || !out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     lvbgpu_batch *bt = new (std::nothrow) lvbgpu_batch();
     if (!bt)
         return LVBGPU_E_NOMEM;
-    bt->ctx = ctx;
-    bt->B = B;
-    int rc = finish_batch(ctx, bt, pk, false);
+    const int rc = build_into(ctx, bt, B, edit_offsets, edits, roots);
     if (rc != LVBGPU_OK)
     {
         lvbgpu_batch_free(bt);
@@ -720,7 +750,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
     HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, (size_t)b->B * 8, ctx->stream));
     WalkArgs a = resident_args(ctx, b->d_prog, b->off_toks, b->off_dsts, b->d_len.p, (uint32_t)b->B,
                                (int32_t)b->stats.max_stack);
-    HIPCHK(ctx, launch_walk(a, b->stats.max_stack > (int64_t)REG_STACK_LEVELS, false, ctx->stream));
+    HIPCHK(ctx, launch_walk(a, false, ctx->stream));
     return LVBGPU_OK;
 }
 
@@ -729,8 +759,10 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
     if (!ctx || !b || b->ctx != ctx || !lengths_out)
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(lengths_out, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // through pinned memory: one DMA, no staging
+    HIPCHK(ctx, hipMemcpyAsync(b->h_len.p, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(lengths_out, b->h_len.p, (size_t)b->B * 8);
     for (int32_t i = 0; i < b->B; i++)
         if (lengths_out[i] <= 0)
             return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
@@ -748,14 +780,24 @@ extern "C" int lvbgpu_batch_get_stats(const lvbgpu_batch *b, lvbgpu_batch_stats 
 extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
                                   const int32_t *roots, int64_t *lengths_out)
 {
-    lvbgpu_batch *b = nullptr;
-    int rc = lvbgpu_batch_build(ctx, B, edit_offsets, edits, roots, &b);
-    if (rc != LVBGPU_OK)
-        return rc;
-    rc = lvbgpu_batch_launch(ctx, b);
+    if (!ctx || !lengths_out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // one recycled batch per context: a search calls this every step, so no allocation here
+    if (!ctx->step_batch)
+    {
+        ctx->step_batch = new (std::nothrow) lvbgpu_batch();
+        if (!ctx->step_batch)
+            return LVBGPU_E_NOMEM;
+    }
+    lvbgpu_batch *b = ctx->step_batch;
+    int rc = build_into(ctx, b, B, edit_offsets, edits, roots);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_launch(ctx, b);
     if (rc == LVBGPU_OK)
         rc = lvbgpu_batch_lengths(ctx, b, lengths_out);
-    lvbgpu_batch_free(b);
     return rc;
 }
 
@@ -916,6 +958,8 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     cd.ncomb = (uint32_t)prog.dsts.size();
     cd.base = base;
     cd.flags = 0;
+    for (uint32_t tk : prog.toks)
+        cd.nfresh += (tk & TOK_FRESH) ? 1u : 0u;
     memcpy(hin, &cd, sizeof cd);
     memcpy(hin + o_t, prog.toks.data(), prog.toks.size() * 4);
     memcpy(hin + o_d, prog.dsts.data(), prog.dsts.size() * 4);
@@ -928,6 +972,8 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_cin.p, hin, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cout.p, 0, oo_rows, ctx->stream));
+    // operands arrive in the reference's nibble layout; the walk works on bit planes
+    HIPCHK(ctx, launch_relayout((uint4 *)((char *)ctx->d_cin.p + o_rows), n_in, Wp / 2, true, ctx->stream));
 
     WalkArgs a{};
     a.rows_in = (const uint4 *)((const char *)ctx->d_cin.p + o_rows);
@@ -944,9 +990,11 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     a.out_stride4 = Wp / 2;
     a.B = 1;
     a.ntiles = ctx->ntiles;
+    a.ngroups = ctx->ntiles;
     a.nitems = ctx->ntiles;
     a.stack_depth = (uint32_t)std::max(prog.max_stack, 1);
-    HIPCHK(ctx, launch_walk(a, prog.max_stack > (int32_t)REG_STACK_LEVELS, true, ctx->stream));
+    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+    HIPCHK(ctx, launch_relayout((uint4 *)((char *)ctx->d_cout.p + oo_rows), n_out, Wp / 2, false, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_cout.p, ctx->d_cout.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 

@@ -1,0 +1,90 @@
+"""One process per GPU: the small amount of multi-process plumbing around the scoring library.
+
+torch.distributed is used for rendezvous, barriers and the max-over-ranks of the timing only (backend
+"nccl" = RCCL on the GPU box, "gloo" in CPU tests).  The data-path collective - the min-reduce of the
+best tree length over independent restarts - is the library's own RCCL call (lvbgpu_allreduce_min);
+the communicator id is created on rank 0 and shared through `share_bytes`.
+"""
+from __future__ import annotations
+
+import os
+
+
+class Ranks:
+    def __init__(self, backend: str | None = None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+
+    def restart_seed(self, base: int) -> int:
+        """Every rank is an independent restart: distinct, reproducible seeds."""
+        return base * 1000 + self.rank + 1
+
+    def share_bytes(self, payload: bytes | None, src: int = 0) -> bytes:
+        if self.dist is None:
+            return payload
+        box = [payload if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def _tensor(self, value, dtype):
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        return torch.tensor([value], dtype=dtype, device=dev)
+
+    def max_over_ranks(self, value: float) -> float:
+        if self.dist is None:
+            return value
+        import torch
+        t = self._tensor(value, torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value: int) -> int:
+        if self.dist is None:
+            return value
+        import torch
+        t = self._tensor(value, torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
+
+    def close(self) -> None:
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def _selftest() -> None:
+    """Run under 2+ processes (gloo): prints one line per rank for tests/test_launch_gloo.py."""
+    import json
+    r = Ranks(backend="gloo")
+    token = r.share_bytes(b"id-from-rank-0" if r.rank == 0 else None)
+    slow = r.max_over_ranks(1.0 + r.rank)
+    total = r.sum_over_ranks(10 + r.rank)
+    r.barrier()
+    print(json.dumps({"rank": r.rank, "world": r.world, "seed": r.restart_seed(3), "token": token.decode(),
+                      "max": slow, "sum": total}), flush=True)
+    r.close()
+
+
+if __name__ == "__main__":
+    _selftest()
