@@ -61,7 +61,32 @@ def synth_rows(n: int, m: int, seed: int) -> list[bytes]:
     return treelike_rows(n, m, seed)
 
 
-def cpu_baseline(rows, kind: int, budget_s: float, spot):
+def cpu_all_cores(taxa: int, sites_seed, kind: int, seconds: float):
+    """One independent reference chain per host core, at the same time (separate processes: the
+    reference is non-reentrant).  -> aggregate trees/s and the core count used."""
+    import subprocess
+    sites, seed = sites_seed
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 32))
+    cmd = [sys.executable, "-m", "oracle.cpu_bench", "--taxa", str(taxa), "--sites", str(sites), "--seed", str(seed),
+           "--kind", str(kind), "--seconds", str(seconds)]
+    procs = [subprocess.Popen(cmd + ["--chain", str(c)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              text=True) for c in range(cores)]
+    rate = 0.0
+    done = 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=seconds * 6 + 120)
+            d = json.loads(out.strip().splitlines()[-1])
+            rate += d["reps"] / (d["t_getplen"] + d["t_mutate"])
+            done += 1
+        except Exception:
+            p.kill()
+    return {"value": rate, "unit": "trees/s", "cores": done,
+            "sample": f"{done} concurrent single-threaded reference chains, {seconds:.0f} s each"}
+
+
+def cpu_baseline(rows, kind: int, budget_s: float, spot, args_sites_seed=None):
     """LVB's CPU path on this host: reference mutate_* + getplen (incl. its per-proposal treecopy)."""
     from oracle import binding as ob
     cores = 1
@@ -84,8 +109,10 @@ def cpu_baseline(rows, kind: int, budget_s: float, spot):
                 l64, r64 = np.asarray(left, np.int64), np.asarray(right, np.int64)
                 ot.set_topology(parents_of(l64, r64), l64, r64, root)
                 check = bool(ot.getplen() == length)
+            all_cores = cpu_all_cores(len(rows), args_sites_seed, kind, min(budget_s, 8.0))
             return {
                 "value": reps / (tg + tm), "unit": "trees/s", "cores": cores, "kind": "reference",
+                "all_cores": all_cores,
                 "sample": f"{reps} {['NNI', 'SPR', 'TBR'][kind]} proposals (mutate incl. treecopy + incremental "
                           f"getplen, serial branch), every 4th accepted, same alignment; getplen alone "
                           f"{reps / tg:.0f}/s ({1e3 * tg / reps:.3f} ms), mutate {1e3 * tm / reps:.3f} ms, "
@@ -155,10 +182,17 @@ def main():
     stats = [b.stats() for b in batches]
     setup_s = time.perf_counter() - t_setup
 
+    own_comm = False
     if world > 1:
         # RCCL communicator of the scoring library itself (not torch's): id from rank 0
-        uid = ranks.share_bytes(api.comm_unique_id() if rank == 0 else None)
-        ctx.comm_init(world, rank, uid)
+        try:
+            uid = ranks.share_bytes(api.comm_unique_id() if rank == 0 else None)
+            ctx.comm_init(world, rank, uid)
+            own_comm = True
+        except api.LvbGpuError as exc:   # keep the scaling run alive: same reduction through torch's RCCL
+            print(f"[rank {rank}] lvbgpu_comm_init failed ({exc}); min-reduce falls back to torch.distributed",
+                  file=sys.stderr)
+        own_comm = bool(ranks.sum_over_ranks(int(own_comm)) == world)
 
     def barrier():
         ctx.synchronize()
@@ -166,18 +200,29 @@ def main():
 
     for i in range(args.warmup):
         batches[i % len(batches)].launch()
+    for b in batches:          # first read-back of each batch maps its pinned buffer: not a per-step cost
+        b.lengths()
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
     for i in range(args.steps):
         batches[i % len(batches)].launch()
     kernel_ms = ctx.timer_stop()  # HIP events on the stream the kernels run on
+    t_gpu_done = time.perf_counter()
     best_local = min(int(b.lengths().min()) for b in batches)
     best_global = best_local
     if world > 1:
-        best_global, _ = ctx.allreduce_min(best_local)
+        if own_comm:
+            best_global, _ = ctx.allreduce_min(best_local)
+        else:
+            best_global = -ranks.max_over_ranks(-float(best_local))
+            best_global = int(best_global)
+    t_reduced = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    print(f"[rank {rank}] timed region: launches+sync {1e3 * (t_gpu_done - t0):.2f} ms (events {kernel_ms:.2f} ms), "
+          f"lengths+min-reduce {1e3 * (t_reduced - t_gpu_done):.2f} ms, barrier {1e3 * (t0 + elapsed - t_reduced):.2f} ms",
+          file=sys.stderr)
 
     elapsed = ranks.max_over_ranks(elapsed)   # the slowest rank defines the step time
 
@@ -215,7 +260,8 @@ def main():
                         f"B={args.batch} candidates per step, {args.nbatches} resident batches cycled",
             "taxa": args.taxa, "sites_after_constant_cut": len(rows[0]), "nwords": ctx.nwords,
             "batch": args.batch, "move": args.move, "mean_dirty_nodes": round(mean_dirty, 2),
-            "parallelism": f"{world} independent restart(s), one per GPU; RCCL min-reduce of best length",
+            "parallelism": f"{world} independent restart(s), one per GPU; RCCL min-reduce of best length"
+                           + ("" if world == 1 else (" (lvbgpu_allreduce_min)" if own_comm else " (torch fallback)")),
             "best_length": best_global, "min_len_tree": min_len, "setup_seconds": round(setup_s, 2),
         },
         "roofline": {
@@ -250,7 +296,7 @@ def main():
             "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rows, kind, args.cpu_seconds, spot)
+        out["cpu_baseline"] = cpu_baseline(rows, kind, args.cpu_seconds, spot, (args.sites, args.seed))
     for b in batches:
         b.free()
     tree.close()

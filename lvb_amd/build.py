@@ -51,7 +51,7 @@ def build_gpu(force: bool = False) -> Path:
     srcs = [CSRC / s for s in GPU_SOURCES]
     deps = srcs + [CSRC / h for h in GPU_HEADERS] + [INCLUDE / "lvbgpu.h"]
     if force or _stale(out, deps):
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-x", "hip", *map(str, srcs), "-o", str(out), "-ldl"])
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-x", "hip", *map(str, srcs), "-o", str(out), "-ldl", "-pthread"])
     return out
 
 

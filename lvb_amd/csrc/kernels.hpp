@@ -14,7 +14,7 @@ constexpr uint32_t WALK_THREADS = 64 * WALK_WAVES;
 constexpr uint32_t TILE_WORDS = 128;              // 64 lanes x 16 B = 128 reference words (2048 sites) per wave tile
 constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
 
-constexpr uint32_t TARGET_WAVES = 32768;          // aim for at least this many (group, candidate) waves per launch
+constexpr uint32_t TARGET_WAVES = 65536;          // aim for at least this many (group, candidate) waves per launch
 constexpr uint32_t MAX_TILES_PER_WAVE = 8;
 
 constexpr uint32_t CAND_RESIDENT_BASE = 1u;       // base += *s_all - sum(node_changes[dst])
@@ -49,9 +49,9 @@ struct WalkArgs
 };
 
 // how many tile groups to cut ntiles into for a batch of B candidates
-inline uint32_t choose_groups(uint32_t B, uint32_t ntiles)
+inline uint32_t choose_groups(uint32_t B, uint32_t ntiles, uint32_t target_waves = TARGET_WAVES)
 {
-    uint32_t per_wave = (uint32_t)(((uint64_t)B * ntiles) / TARGET_WAVES);
+    uint32_t per_wave = (uint32_t)(((uint64_t)B * ntiles) / target_waves);
     if (per_wave < 1)
         per_wave = 1;
     if (per_wave > MAX_TILES_PER_WAVE)

@@ -8,11 +8,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -98,6 +103,87 @@ struct Id128
 {
     char bytes[128]; // ncclUniqueId
 };
+// a few persistent host threads: building B postorder programs is the host-side cost of a step
+class Pool
+{
+  public:
+    explicit Pool(int n)
+    {
+        for (int t = 0; t < n; t++)
+            threads_.emplace_back([this, t] { loop(t); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            gen_++;
+        }
+        start_.notify_all();
+        for (auto &t : threads_)
+            t.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    // run fn(t) for t in [0, active) on the workers and wait for all of them
+    void run(int active, const std::function<void(int)> &fn)
+    {
+        std::unique_lock<std::mutex> g(m_);
+        job_ = &fn;
+        active_ = active;
+        pending_ = active;
+        gen_++;
+        start_.notify_all();
+        done_.wait(g, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop(int t)
+    {
+        uint64_t seen = 0;
+        for (;;)
+        {
+            const std::function<void(int)> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                start_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_)
+                    return;
+                if (t < active_)
+                    job = job_;
+            }
+            if (job)
+            {
+                (*job)(t);
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0)
+                    done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable start_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    int active_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+struct BuildWorker
+{
+    Topology topo;
+    uint64_t topo_version = ~0ull;
+    ProgramBuilder pb;
+    Program prog;
+    std::vector<CandDesc> cands;
+    int32_t max_stack = 0;
+    int64_t dirty = 0;
+    int rc = 0;
+    std::string why;
+};
+
 struct Rccl
 {
     void *lib = nullptr;
@@ -117,6 +203,7 @@ struct lvbgpu_ctx
     long n = 0, nwords = 0;
     int32_t nb = 0;
     uint32_t stride_words = 0, stride4 = 0, ntiles = 0;
+    uint32_t target_waves = TARGET_WAVES; // tuning knob (env LVBGPU_TARGET_WAVES)
 
     uint64_t *d_rows = nullptr;              // [nb][stride_words]
     unsigned long long *d_changes = nullptr; // [nb + 1]; slot nb = the two root combines
@@ -125,7 +212,10 @@ struct lvbgpu_ctx
     int64_t cur_length = 0;
 
     Topology topo;
+    uint64_t topo_version = 0; // bumped whenever topo changes (workers keep private copies)
     ProgramBuilder pb;
+    Pool *pool = nullptr;
+    std::vector<BuildWorker> workers;
 
     DevBuf d_prog, d_len; // scratch for single-program launches (set_tree, commit)
     DevBuf d_export;      // one row in nibble layout (lvbgpu_get_sets)
@@ -254,7 +344,7 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, siz
     a.out_stride4 = ctx->stride4;
     a.B = B;
     a.ntiles = ctx->ntiles;
-    a.ngroups = choose_groups(B, ctx->ntiles);
+    a.ngroups = choose_groups(B, ctx->ntiles, ctx->target_waves);
     a.nitems = B * a.ngroups;
     a.stack_depth = (uint32_t)std::max(max_stack, 1);
     a.root_slot = (uint32_t)ctx->nb;
@@ -283,9 +373,13 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     ctx->n = n;
     ctx->nwords = nwords;
     ctx->nb = (int32_t)(2 * n - 3);
-    ctx->stride_words = round_up((uint32_t)nwords, TILE_WORDS);
+    ctx->ntiles = round_up((uint32_t)nwords, TILE_WORDS) / TILE_WORDS;
+    // tuning knobs for experiments: extra row padding (in tiles) and the wave-count target
+    const char *pad = getenv("LVBGPU_STRIDE_PAD_TILES");
+    ctx->stride_words = (ctx->ntiles + (pad ? (uint32_t)atoi(pad) : 0u)) * TILE_WORDS;
     ctx->stride4 = ctx->stride_words / 2;
-    ctx->ntiles = ctx->stride_words / TILE_WORDS;
+    if (const char *tw = getenv("LVBGPU_TARGET_WAVES"))
+        ctx->target_waves = (uint32_t)std::max(1, atoi(tw));
     if ((uint64_t)ctx->nb * ctx->stride4 >= (1ull << 32))
         return ctx->fail(LVBGPU_E_ARG, "tree block exceeds 64 GiB");
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -448,6 +542,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipFree(ctx->d_changes);
     if (ctx->d_scalars)
         (void)hipFree(ctx->d_scalars);
+    delete ctx->pool;
+    ctx->pool = nullptr;
     if (ctx->step_batch)
     {
         ctx->step_batch->ctx = nullptr;
@@ -576,6 +672,7 @@ extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32
     if (!t.assign((int32_t)ctx->n, left, right, root, &why))
         return ctx->fail(LVBGPU_E_TOPOLOGY, why);
     ctx->topo = std::move(t);
+    ctx->topo_version++;
     ctx->have_tree = false;
     Program prog;
     ctx->pb.build_full(ctx->topo, prog);
@@ -689,34 +786,158 @@ int finish_batch(lvbgpu_ctx *ctx, lvbgpu_batch *b, const Packed &pk, bool full_m
 
 namespace
 {
-// fill `bt` (new or recycled: its buffers only ever grow) with the programs of B candidates
+constexpr int32_t PARALLEL_BUILD_MIN = 512; // below this one thread is faster than waking the pool
+
+int build_threads()
+{
+    const char *e = getenv("LVBGPU_THREADS");
+    int n = e ? atoi(e) : 8;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && n > hw)
+        n = hw;
+    return n < 1 ? 1 : n;
+}
+
+// programs of candidates [b0, b1) with one worker's private topology copy
+void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const int32_t *edit_offsets,
+                 const lvbgpu_edit *edits, const int32_t *roots)
+{
+    if (w.topo_version != ctx->topo_version)
+    {
+        w.topo = ctx->topo;
+        w.topo_version = ctx->topo_version;
+        w.pb.resize(w.topo.nb);
+    }
+    w.prog.toks.clear();
+    w.prog.dsts.clear();
+    w.cands.clear();
+    w.max_stack = 0;
+    w.dirty = 0;
+    w.rc = LVBGPU_OK;
+    for (int32_t b = b0; b < b1; b++)
+    {
+        const int32_t e0 = edit_offsets[b], e1 = edit_offsets[b + 1];
+        if (e1 < e0)
+        {
+            w.rc = LVBGPU_E_ARG;
+            w.why = "edit_offsets not monotone";
+            return;
+        }
+        const size_t tok0 = w.prog.toks.size(), dst0 = w.prog.dsts.size();
+        w.prog.max_stack = 0;
+        if (!w.pb.build_candidate(w.topo, reinterpret_cast<const Edit *>(edits) + e0, e1 - e0, roots ? roots[b] : -1,
+                                  w.prog, &w.why))
+        {
+            w.rc = LVBGPU_E_TOPOLOGY;
+            w.why = "candidate " + std::to_string(b) + ": " + w.why;
+            return;
+        }
+        CandDesc cd{};
+        cd.tok_off = (uint32_t)tok0;
+        cd.ntok = (uint32_t)(w.prog.toks.size() - tok0);
+        cd.dst_off = (uint32_t)dst0;
+        cd.ncomb = (uint32_t)(w.prog.dsts.size() - dst0);
+        cd.flags = CAND_RESIDENT_BASE;
+        for (size_t i = tok0; i < w.prog.toks.size(); i++)
+            cd.nfresh += (w.prog.toks[i] & TOK_FRESH) ? 1u : 0u;
+        w.cands.push_back(cd);
+        w.max_stack = std::max(w.max_stack, w.prog.max_stack);
+        w.dirty += w.prog.dirty;
+    }
+}
+
+// fill `bt` (new or recycled: its buffers only ever grow) with the programs of B candidates:
+// slices of the batch are built on the pool's threads straight into the pinned upload buffer
 int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
                const int32_t *roots)
 {
     static_assert(sizeof(lvbgpu_edit) == sizeof(Edit), "edit layout");
-    Packed pk;
-    Program prog; // all candidates appended into one token/dst stream
-    std::string why;
-    pk.cands.reserve(B);
-    for (int32_t b = 0; b < B; b++)
+    int T = 1;
+    if (B >= PARALLEL_BUILD_MIN)
     {
-        const int32_t e0 = edit_offsets[b], e1 = edit_offsets[b + 1];
-        if (e1 < e0)
-            return ctx->fail(LVBGPU_E_ARG, "edit_offsets not monotone");
-        const size_t tok0 = prog.toks.size(), dst0 = prog.dsts.size();
-        prog.max_stack = 0;
-        if (!ctx->pb.build_candidate(ctx->topo, reinterpret_cast<const Edit *>(edits) + e0, e1 - e0,
-                                     roots ? roots[b] : -1, prog, &why))
-            return ctx->fail(LVBGPU_E_TOPOLOGY, "candidate " + std::to_string(b) + ": " + why);
-        pk.add(prog, tok0, dst0, 0, CAND_RESIDENT_BASE);
-        pk.max_stack = std::max(pk.max_stack, prog.max_stack);
-        pk.dirty += prog.dirty;
+        if (!ctx->pool)
+        {
+            const int n = build_threads();
+            if (n > 1)
+                ctx->pool = new (std::nothrow) Pool(n);
+        }
+        if (ctx->pool)
+            T = std::min(ctx->pool->size(), B / (PARALLEL_BUILD_MIN / 2));
     }
-    pk.toks.swap(prog.toks);
-    pk.dsts.swap(prog.dsts);
+    if ((int)ctx->workers.size() < T)
+        ctx->workers.resize(T);
+    auto slice = [&](int t) {
+        build_slice(ctx, ctx->workers[t], (int32_t)((int64_t)B * t / T), (int32_t)((int64_t)B * (t + 1) / T),
+                    edit_offsets, edits, roots);
+    };
+    if (T == 1)
+        slice(0);
+    else
+        ctx->pool->run(T, slice);
+
+    size_t ntok = 0, ndst = 0;
+    std::vector<size_t> tok_base(T), dst_base(T), cand_base(T);
+    int32_t max_stack = 0;
+    int64_t dirty = 0;
+    size_t ncand = 0;
+    for (int t = 0; t < T; t++)
+    {
+        BuildWorker &w = ctx->workers[t];
+        if (w.rc != LVBGPU_OK)
+            return ctx->fail(w.rc, w.why);
+        tok_base[t] = ntok;
+        dst_base[t] = ndst;
+        cand_base[t] = ncand;
+        ntok += w.prog.toks.size();
+        ndst += w.prog.dsts.size();
+        ncand += w.cands.size();
+        max_stack = std::max(max_stack, w.max_stack);
+        dirty += w.dirty;
+    }
+    int rc = check_depth(ctx, max_stack);
+    if (rc != LVBGPU_OK)
+        return rc;
+    if ((uint64_t)B * ctx->ntiles >= (1ull << 31) || ntok >= (1ull << 32))
+        return ctx->fail(LVBGPU_E_ARG, "batch too large: B * tiles must stay below 2^31");
+
+    const size_t o_t = align16((size_t)B * sizeof(CandDesc));
+    const size_t o_d = o_t + align16(ntok * 4);
+    const size_t total = o_d + align16(ndst * 4);
+    HIPCHK(ctx, bt->d_prog.reserve(total));
+    HIPCHK(ctx, ctx->h_pin.reserve(total));
+    char *h = (char *)ctx->h_pin.p;
+    auto gather = [&](int t) {
+        BuildWorker &w = ctx->workers[t];
+        CandDesc *cd = (CandDesc *)h + cand_base[t];
+        for (size_t i = 0; i < w.cands.size(); i++)
+        {
+            cd[i] = w.cands[i];
+            cd[i].tok_off += (uint32_t)tok_base[t];
+            cd[i].dst_off += (uint32_t)dst_base[t];
+        }
+        memcpy(h + o_t + tok_base[t] * 4, w.prog.toks.data(), w.prog.toks.size() * 4);
+        memcpy(h + o_d + dst_base[t] * 4, w.prog.dsts.data(), w.prog.dsts.size() * 4);
+    };
+    if (T == 1)
+        gather(0);
+    else
+        ctx->pool->run(T, gather);
+    HIPCHK(ctx, hipMemcpyAsync(bt->d_prog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // h_pin is reused by the next upload
     bt->ctx = ctx;
     bt->B = B;
-    return finish_batch(ctx, bt, pk, false);
+    bt->off_toks = o_t;
+    bt->off_dsts = o_d;
+    HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
+    HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
+    bt->full_mode = false;
+    bt->stats.candidates = B;
+    bt->stats.combines = (int64_t)ndst;
+    bt->stats.rows_read = (int64_t)ntok;
+    bt->stats.dirty_nodes = dirty;
+    bt->stats.max_stack = max_stack;
+    bt->stats.algorithmic_bytes = bt->stats.rows_read * ctx->nwords * 8;
+    return LVBGPU_OK;
 }
 } // namespace
 
@@ -854,6 +1075,7 @@ extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit
         return ctx->fail(LVBGPU_E_TOPOLOGY, why);
     if (!ctx->pb.apply_edits(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, &why))
         return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    ctx->topo_version++;
     int rc = run_commit_program(ctx, prog, false);
     if (rc != LVBGPU_OK)
     {

@@ -225,3 +225,16 @@ def test_device_reproduces_golden_vectors(api, ob, name):
         if g.nwords <= 1000 or k % 6 == 0:
             assert goldenlib.crc(ctx.all_sets()) == int(c["sets_crc"])
     ctx.close()
+
+
+def test_rccl_communicator_single_rank(api):
+    """lvbgpu_comm_* loads librccl on demand and runs the min-reduce; with one rank the value
+    must come back unchanged and the arg-min rank is 0.  (The 8-GPU run belongs to the driver.)"""
+    enc = np.full((5, 3), 0x1248124812481248, dtype=np.uint64)
+    ctx = api.FitchContext(enc)
+    uid = api.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(1, 0, uid)
+    assert ctx.allreduce_min(123456789012) == (123456789012, 0)
+    assert ctx.allreduce_min(7) == (7, 0)
+    ctx.close()
