@@ -62,6 +62,22 @@ int lvbhost_reroot_edits(const lvbhost_tree *t, int32_t newroot, lvbgpu_edit *ed
 /* apply edits (+ new root, or -1) to the tree: what SwapTrees achieves after an accept */
 int lvbhost_tree_apply(lvbhost_tree *t, const lvbgpu_edit *edits, int32_t n_edits, int32_t new_root);
 
+/* ---- alignment input / tree output (reference MSAInput.cpp:274-432 read_phylip,
+ *      TreeOperations.c:1156-1220 ur_print) ------------------------------------------- */
+typedef struct lvbhost_alignment lvbhost_alignment;
+/* PHYLIP, sequential or interleaved: header "n m", 10-character name field, digits and blanks
+ * inside sequences ignored, text upper-cased (MSAInput.cpp:829).  NULL + message on error. */
+lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, char *err, int32_t errcap);
+void lvbhost_alignment_free(lvbhost_alignment *a);
+int64_t lvbhost_alignment_n(const lvbhost_alignment *a);
+int64_t lvbhost_alignment_m(const lvbhost_alignment *a);
+const char *lvbhost_alignment_row(const lvbhost_alignment *a, int64_t i);
+const char *lvbhost_alignment_name(const lvbhost_alignment *a, int64_t i);
+/* the tree as one line of bracketed text in the reference's unrooted form:
+ * "(rootname,<left subtree>,<right subtree>);\n", names right-trimmed, no branch lengths.
+ * Returns the number of bytes written (excluding the terminator) or a negative status. */
+int64_t lvbhost_tree_newick(const lvbhost_tree *t, const char *const *names, char *out, int64_t cap);
+
 /* ---- alignment preparation (reference matchange, DataOperations.c:272-405, 53-105) ---- */
 /* keep[k] = 1 for columns whose raw characters are not all equal to row 0's (constchar); returns
  * the number kept.  The caller drops the others before encoding, as cutcols does. */
@@ -69,6 +85,14 @@ int64_t lvbhost_variable_columns(int64_t n, int64_t m, const char *const *rows, 
 /* MinimumTreeLength: sum over columns of (#distinct characters other than - ? N X) - 1, 5 when
  * more than MAXSTATES (5) distinct ones occur */
 int64_t lvbhost_min_tree_length(int64_t n, int64_t m, const char *const *rows);
+
+/* the distinct best topologies the last lvbhost_anneal run found (the reference's treestack,
+ * Treestack.c:231-306): how many, how many of them were kept (first 1024), and their arrays */
+/* rooting- and numbering-independent identity of the topology (sum of hashed bipartition keys) */
+uint64_t lvbhost_tree_topology_hash(const lvbhost_tree *t);
+int32_t lvbhost_tree_best_count(const lvbhost_tree *t);
+int32_t lvbhost_tree_best_kept(const lvbhost_tree *t);
+int lvbhost_tree_best_get(const lvbhost_tree *t, int32_t i, int32_t *left, int32_t *right, int32_t *root);
 
 /* ---- program introspection (what the device will walk), for tests --------------------- */
 /* mode 0: edits relative to the tree, mode 1: whole tree (all dirty), mode 2: explicit dirty flags.
@@ -110,6 +134,7 @@ typedef struct
     int64_t scored;             /* candidates scored on the device */
     int64_t consumed;           /* proposals the serial-equivalent chain consumed ("rearrangements evaluated") */
     int64_t accepted;           /* accepted moves (commits) */
+    int64_t topologies;         /* distinct topologies of the best length ("Topologies recovered") */
     int64_t device_steps;       /* batches launched */
     int64_t reroots;
     int64_t dirty_nodes;        /* sum of D over all scored candidates */

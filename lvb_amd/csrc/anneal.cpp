@@ -12,8 +12,9 @@
 //     change or a re-root tick.
 //   * the re-root is an edit along the old-root..new-root path (the reference re-evaluates the
 //     whole tree, TreeOperations.c:631-635); lengths and node sets come out the same.
-//   * no treestack: "accepted" counts accepted proposals that are <= the best length seen, where
-//     the reference counts those that were also new to its treestack (Solve.c:309-320).
+//   * the treestack is a set of topology hashes (bipartition keys, host_tree.hpp) instead of stored
+//     object sets; as in the reference (Solve.c:309-320) "accepted" counts proposals that tie or
+//     beat the best length AND are a topology not yet in it.
 //   * the random stream is xorshift64*, not the reference's Marsaglia generator.
 // No length is computed here: all come from lvbgpu_* (HIP).
 #include "../../include/lvbhost.h"
@@ -254,6 +255,8 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
     };
     log_point();
 
+    tree->best.clear();
+    tree->best.insert(tree->topo); // the initial tree is initially the best (Solve.c:208)
     bool done = false;
     while (!done)
     {
@@ -306,19 +309,36 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
         {
             current_iter++;
             const int64_t len = ch.lens[b];
+            // accept / reject (Solve.c:303-378)
             bool take;
             if (len <= cur)
-            {
                 take = true;
-                if (len <= best)
-                    accepted++; // see header: no treestack to tell new topologies from revisits
-            }
             else
                 take = accept_worse(energy_delta(minlen, cur, len), t, tree->rng);
+            if (take)
+            {
+                const bool stack_it = len <= cur && len <= best; // ties or beats the best (Solve.c:309)
+                rc = ch.commit(b, &cur);
+                if (rc != LVBGPU_OK)
+                    return rc;
+                res->accepted++;
+                if (stack_it)
+                {
+                    if (cur < best)
+                        tree->best.clear(); // discard old bests (Solve.c:312-315)
+                    if (tree->best.insert(tree->topo))
+                        accepted++; // only topologies new to the treestack count (316-319)
+                }
+                if (cur < best)
+                {
+                    best = cur;
+                    log_point();
+                }
+            }
             proposed++;
             iter++;
 
-            bool dect = false; // Solve.c:380-407
+            bool dect = false; // decide whether to reduce temperature (Solve.c:380-407)
             if (accepted >= p.maxaccept)
             {
                 failedcnt = 0;
@@ -359,19 +379,6 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
                 accepted = 0;
                 res->temperatures++;
             }
-
-            if (take)
-            {
-                rc = ch.commit(b, &cur);
-                if (rc != LVBGPU_OK)
-                    return rc;
-                res->accepted++;
-                if (cur < best)
-                {
-                    best = cur;
-                    log_point();
-                }
-            }
             if (p.max_proposals > 0 && iter >= p.max_proposals)
                 done = true;
             if (take || dect)
@@ -398,6 +405,7 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
     if (p.sync_every <= 0)
         res->global_best_length = best;
     res->scored = ch.scored;
+    res->topologies = (int64_t)tree->best.seen.size();
     res->consumed = iter;
     res->t_final = t;
     res->seconds = since(wall0);

@@ -2,7 +2,10 @@
 // introspection.  The SA loop lives in anneal.cpp.  No scoring happens in this library.
 #include "../../include/lvbhost.h"
 
+#include <cctype>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <new>
 #include <string>
 #include <vector>
@@ -24,6 +27,90 @@ int copy_out(const std::vector<Edit> &v, lvbgpu_edit *edits, int32_t cap)
 }
 } // namespace
 
+// ------------------------------------------------------------------ best-topology set
+
+void BestSet::reset(int32_t n)
+{
+    key.resize(n);
+    Rng r(0xD1B54A32D192ED03ull);
+    for (int32_t i = 0; i < n; i++)
+        key[i] = r.next();
+    clear();
+}
+
+uint64_t BestSet::hash(const Topology &t, std::vector<uint64_t> &sub) const
+{
+    // subtree key = XOR of the keys of its taxa, children before parents (explicit postorder)
+    sub.assign(t.nb, 0);
+    uint64_t all = 0;
+    for (int32_t i = 0; i < t.n; i++)
+    {
+        sub[i] = key[i];
+        all ^= key[i];
+    }
+    std::vector<int32_t> order;
+    order.reserve(t.nb);
+    std::vector<int32_t> st{t.left[t.root], t.right[t.root]};
+    while (!st.empty())
+    {
+        const int32_t v = st.back();
+        st.pop_back();
+        order.push_back(v);
+        if (t.left[v] >= 0)
+        {
+            st.push_back(t.left[v]);
+            st.push_back(t.right[v]);
+        }
+    }
+    uint64_t h = 0;
+    for (auto it = order.rbegin(); it != order.rend(); ++it)
+    {
+        const int32_t v = *it;
+        if (t.left[v] < 0)
+            continue;
+        sub[v] = sub[t.left[v]] ^ sub[t.right[v]];
+        // one bipartition = two complementary sides: canonicalise on the numerically smaller key
+        const uint64_t side = sub[v];
+        const uint64_t other = all ^ side;
+        const uint64_t canon = side < other ? side : other;
+        uint64_t z = canon + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h += z ^ (z >> 31);
+    }
+    return h;
+}
+
+bool BestSet::insert(const Topology &t)
+{
+    std::vector<uint64_t> sub;
+    const uint64_t h = hash(t, sub);
+    if (!seen.insert(h).second)
+        return false;
+    if (kept.size() < cap)
+        kept.push_back({t.left, t.right, t.root});
+    return true;
+}
+
+extern "C" uint64_t lvbhost_tree_topology_hash(const lvbhost_tree *t)
+{
+    std::vector<uint64_t> sub;
+    return t->best.hash(t->topo, sub);
+}
+
+extern "C" int32_t lvbhost_tree_best_count(const lvbhost_tree *t) { return t ? (int32_t)t->best.seen.size() : 0; }
+extern "C" int32_t lvbhost_tree_best_kept(const lvbhost_tree *t) { return t ? (int32_t)t->best.kept.size() : 0; }
+extern "C" int lvbhost_tree_best_get(const lvbhost_tree *t, int32_t i, int32_t *left, int32_t *right, int32_t *root)
+{
+    if (!t || i < 0 || i >= (int32_t)t->best.kept.size() || !left || !right || !root)
+        return LVBGPU_E_ARG;
+    const BestSet::Kept &k = t->best.kept[i];
+    memcpy(left, k.left.data(), k.left.size() * 4);
+    memcpy(right, k.right.data(), k.right.size() * 4);
+    *root = k.root;
+    return LVBGPU_OK;
+}
+
 extern "C" lvbhost_tree *lvbhost_tree_random(int32_t n, uint64_t seed)
 {
     if (n < 3)
@@ -34,6 +121,7 @@ extern "C" lvbhost_tree *lvbhost_tree_random(int32_t n, uint64_t seed)
     t->rng = Rng(seed);
     random_topology(n, t->rng, t->topo);
     t->pb.resize(t->topo.nb);
+    t->best.reset(n);
     return t;
 }
 
@@ -53,6 +141,7 @@ extern "C" lvbhost_tree *lvbhost_tree_from_arrays(int32_t n, const int32_t *left
         return nullptr;
     }
     t->pb.resize(t->topo.nb);
+    t->best.reset(n);
     return t;
 }
 
@@ -240,4 +329,172 @@ extern "C" int64_t lvbhost_min_tree_length(int64_t n, int64_t m, const char *con
         total += over ? 5 : (int64_t)nseen - 1;
     }
     return total;
+}
+
+// ------------------------------------------------------------------ alignment input / tree output
+
+struct lvbhost_alignment
+{
+    std::vector<std::string> names, rows;
+    int64_t m = 0;
+};
+
+namespace
+{
+std::string trimmed(const std::string &s)
+{
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a]))
+        a++;
+    while (b > a && isspace((unsigned char)s[b - 1]))
+        b--;
+    return s.substr(a, b - a);
+}
+void append_sequence(std::string &dst, const std::string &chunk)
+{
+    for (char c : chunk)
+        if (!isdigit((unsigned char)c) && !isspace((unsigned char)c))
+            dst.push_back((char)toupper((unsigned char)c));
+}
+} // namespace
+
+extern "C" lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, char *err, int32_t errcap)
+{
+    auto fail = [&](const std::string &msg) -> lvbhost_alignment * {
+        if (err && errcap > 0)
+            snprintf(err, (size_t)errcap, "%s", msg.c_str());
+        return nullptr;
+    };
+    std::ifstream in(path);
+    if (!in)
+        return fail(std::string("Failed to open alignment file: ") + path);
+    const int name_field = 10;
+    lvbhost_alignment *a = new (std::nothrow) lvbhost_alignment();
+    if (!a)
+        return fail("out of memory");
+    long n = 0, m = 0;
+    std::string line;
+    std::vector<std::string> lines; // non-empty lines after the header
+    while (std::getline(in, line))
+    {
+        if (!line.empty() && line.back() == '\r')
+            line.pop_back();
+        if (trimmed(line).empty())
+            continue;
+        if (n == 0)
+        {
+            if (sscanf(line.c_str(), "%ld%ld", &n, &m) != 2 || n < 1 || m < 1)
+            {
+                delete a;
+                return fail("Some problem reading the file. Please, check the file format.");
+            }
+            continue;
+        }
+        lines.push_back(line);
+    }
+    if (n == 0 || (long)lines.size() < n)
+    {
+        const std::string msg = "The file has a different number of sequences.\nRead: " + std::to_string(lines.size()) +
+                                "\nIn the header: " + std::to_string(n);
+        delete a;
+        return fail(msg);
+    }
+    // Two layouts share this syntax: interleaved (blocks of n lines, names in the first block) and
+    // sequential (each taxon's lines together, name on its first line).  Assemble both readings
+    // and keep the one in which every sequence has exactly m sites (interleaved wins a tie).
+    auto assemble = [&](bool interleaved, std::vector<std::string> &names, std::vector<std::string> &rows) -> bool {
+        names.clear();
+        rows.clear();
+        const long total = (long)lines.size();
+        if (total % n != 0)
+            return false;
+        const long per = total / n;
+        for (long i = 0; i < n; i++)
+        {
+            const std::string &first = lines[(size_t)(interleaved ? i : i * per)];
+            if ((int)first.size() < name_field)
+                return false;
+            names.push_back(trimmed(first.substr(0, name_field)));
+            rows.emplace_back();
+            append_sequence(rows.back(), first.substr(name_field));
+            for (long k = 1; k < per; k++)
+                append_sequence(rows.back(), lines[(size_t)(interleaved ? k * n + i : i * per + k)]);
+            if ((long)rows.back().size() != m)
+                return false;
+        }
+        return true;
+    };
+    if (!assemble(true, a->names, a->rows) && !assemble(false, a->names, a->rows))
+    {
+        // report what the interleaved reading found, as the reference's message does
+        std::vector<std::string> nm, rw;
+        assemble(true, nm, rw);
+        std::string msg = "Some problem reading the file. Please, check the file format.";
+        if (!rw.empty())
+            msg = "This sequence " + nm.back() + " has a different length " + std::to_string(rw.back().size()) +
+                  " from the one read in the header: " + std::to_string(m);
+        delete a;
+        return fail(msg);
+    }
+    a->m = m;
+    return a;
+}
+
+extern "C" void lvbhost_alignment_free(lvbhost_alignment *a) { delete a; }
+extern "C" int64_t lvbhost_alignment_n(const lvbhost_alignment *a) { return a ? (int64_t)a->rows.size() : 0; }
+extern "C" int64_t lvbhost_alignment_m(const lvbhost_alignment *a) { return a ? a->m : 0; }
+extern "C" const char *lvbhost_alignment_row(const lvbhost_alignment *a, int64_t i) { return a->rows[(size_t)i].c_str(); }
+extern "C" const char *lvbhost_alignment_name(const lvbhost_alignment *a, int64_t i)
+{
+    return a->names[(size_t)i].c_str();
+}
+
+extern "C" int64_t lvbhost_tree_newick(const lvbhost_tree *t, const char *const *names, char *out, int64_t cap)
+{
+    if (!t || !names || !out || cap < 4)
+        return LVBGPU_E_ARG;
+    const Topology &tp = t->topo;
+    std::string s;
+    auto name_of = [&](int32_t v) {
+        std::string nm = names[v];
+        while (!nm.empty() && nm.back() == ' ')
+            nm.pop_back();
+        return nm;
+    };
+    // "(root" then the two subtrees, comma-separated, ")" - explicit stack instead of recursion
+    s += "(" + name_of(tp.root);
+    struct Item
+    {
+        int32_t v;
+        int stage;
+    };
+    std::vector<Item> st;
+    st.push_back({tp.right[tp.root], 0});
+    st.push_back({tp.left[tp.root], 0});
+    while (!st.empty())
+    {
+        Item it = st.back();
+        st.pop_back();
+        if (it.stage == 1)
+        {
+            s += ")";
+            continue;
+        }
+        if (s.back() != '(')
+            s += ",";
+        if (it.v < tp.n)
+            s += name_of(it.v);
+        else
+        {
+            s += "(";
+            st.push_back({it.v, 1});
+            st.push_back({tp.right[it.v], 0});
+            st.push_back({tp.left[it.v], 0});
+        }
+    }
+    s += ");\n";
+    if ((int64_t)s.size() + 1 > cap)
+        return LVBGPU_E_ARG;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int64_t)s.size();
 }

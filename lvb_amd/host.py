@@ -29,7 +29,7 @@ class AnnealParams(C.Structure):
 class AnnealResult(C.Structure):
     _fields_ = [("start_length", C.c_int64), ("best_length", C.c_int64), ("final_length", C.c_int64),
                 ("global_best_length", C.c_int64), ("scored", C.c_int64), ("consumed", C.c_int64),
-                ("accepted", C.c_int64), ("device_steps", C.c_int64), ("reroots", C.c_int64),
+                ("accepted", C.c_int64), ("topologies", C.c_int64), ("device_steps", C.c_int64), ("reroots", C.c_int64),
                 ("dirty_nodes", C.c_int64), ("temperatures", C.c_int64), ("t_final", C.c_double),
                 ("seconds", C.c_double), ("seconds_device", C.c_double), ("n_log", C.c_int32),
                 ("frozen", C.c_int32)]
@@ -50,9 +50,20 @@ SIGNATURES = {
     "lvbhost_tbr_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "lvbhost_reroot_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "lvbhost_tree_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "lvbhost_tree_topology_hash": (C.c_uint64, [C.c_void_p]),
+    "lvbhost_tree_best_count": (C.c_int32, [C.c_void_p]),
+    "lvbhost_tree_best_kept": (C.c_int32, [C.c_void_p]),
+    "lvbhost_tree_best_get": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.POINTER(C.c_int32)]),
     "lvbhost_program": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lvbhost_alignment_read_phylip": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int32]),
+    "lvbhost_alignment_free": (None, [C.c_void_p]),
+    "lvbhost_alignment_n": (C.c_int64, [C.c_void_p]),
+    "lvbhost_alignment_m": (C.c_int64, [C.c_void_p]),
+    "lvbhost_alignment_row": (C.c_char_p, [C.c_void_p, C.c_int64]),
+    "lvbhost_alignment_name": (C.c_char_p, [C.c_void_p, C.c_int64]),
+    "lvbhost_tree_newick": (C.c_int64, [C.c_void_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int64]),
     "lvbhost_variable_columns": (C.c_int64, [C.c_int64, C.c_int64, C.POINTER(C.c_char_p), C.c_void_p]),
     "lvbhost_min_tree_length": (C.c_int64, [C.c_int64, C.c_int64, C.POINTER(C.c_char_p)]),
     "lvbhost_anneal_defaults": (None, [C.POINTER(AnnealParams)]),
@@ -187,6 +198,23 @@ class HostTree:
         return {"toks": toks[: ntok.value].copy(), "dsts": dsts[: ndst.value].copy(), "max_stack": mstack.value,
                 "dirty": nd.value}
 
+    def best_trees(self) -> list["HostTree"]:
+        """The distinct best topologies the last anneal run kept (the reference's treestack)."""
+        out = []
+        for i in range(int(self.lib.lvbhost_tree_best_kept(self.h))):
+            l = np.zeros(self.nbranches, dtype=np.int32)
+            r = np.zeros(self.nbranches, dtype=np.int32)
+            root = C.c_int32()
+            self.lib.lvbhost_tree_best_get(self.h, i, l, r, C.byref(root))
+            out.append(HostTree(left=l, right=r, root=root.value))
+        return out
+
+    def topology_hash(self) -> int:
+        return int(self.lib.lvbhost_tree_topology_hash(self.h))
+
+    def best_count(self) -> int:
+        return int(self.lib.lvbhost_tree_best_count(self.h))
+
     def upload(self, ctx: api.FitchContext) -> int:
         out = C.c_int64()
         ctx._chk(self.lib.lvbhost_tree_upload(ctx.h, self.h, C.byref(out)))
@@ -235,3 +263,30 @@ def prepare_alignment(rows: list[bytes]) -> tuple[list[bytes], int]:
     if kept < 1:
         raise ValueError("after constant columns are ignored, the data matrix has no columns left")
     return rows, int(lib.lvbhost_min_tree_length(n, int(kept), arr))
+
+
+def read_phylip(path) -> tuple[list[bytes], list[bytes]]:
+    """PHYLIP alignment -> (names, rows): what the reference's reader hands to matchange."""
+    import os
+    lib = load_library()
+    err = C.create_string_buffer(512)
+    h = lib.lvbhost_alignment_read_phylip(os.fsencode(path), err, 512)
+    if not h:
+        raise ValueError(err.value.decode())
+    try:
+        n = lib.lvbhost_alignment_n(h)
+        return ([lib.lvbhost_alignment_name(h, i) for i in range(n)], [lib.lvbhost_alignment_row(h, i) for i in range(n)])
+    finally:
+        lib.lvbhost_alignment_free(h)
+
+
+def newick(tree: "HostTree", names: list[bytes]) -> str:
+    """One line, the reference's unrooted bracket form (ur_print)."""
+    lib = load_library()
+    arr = (C.c_char_p * len(names))(*names)
+    cap = sum(len(x) + 4 for x in names) * 2 + 64
+    buf = C.create_string_buffer(cap)
+    k = lib.lvbhost_tree_newick(tree.h, arr, buf, cap)
+    if k < 0:
+        raise api.LvbGpuError(int(k), "newick")
+    return buf.value.decode()

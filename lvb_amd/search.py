@@ -1,0 +1,81 @@
+"""A whole search on the MI355X path: read a PHYLIP alignment, cut constant columns, anneal, write
+the best trees.  Mirrors the reference program's flow (Main.c:60-155) and result lines, with our own
+host (batched SA over the device scorer); it is a convenience around the library, not a port of the CLI.
+
+  python -m lvb_amd.search -i alignment.phy [-s seed] [-a 0|1] [-o outtree] [--batch B] [--device D]
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+
+from . import api, host
+
+
+def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 256, device: int = 0, out: str | None = "outtree",
+        max_seconds: float = 0.0, cooling: int = 0, verbose: bool = True) -> dict:
+    t0 = time.perf_counter()
+    names, rows = host.read_phylip(path)
+    n, m_read = len(rows), len(rows[0])
+    if n < 5:
+        raise ValueError("The data matrix must have at least 5 sequences.")  # Wrapper.c:54 (MIN_N)
+    rows, min_len = host.prepare_alignment(rows)
+    ctx = api.FitchContext(text_rows=rows, device=device)
+    tree = host.HostTree(n, seed=seed)
+    start = tree.upload(ctx)
+    p = host.anneal_defaults()
+    p.seed = seed
+    p.algorithm = algorithm
+    p.cooling_schedule = cooling
+    p.batch = batch
+    p.min_len_tree = min_len
+    p.max_seconds = max_seconds
+    p.t0 = 0.0  # StartingTemperature()
+    p.log_cap = 4096
+    res, log = host.anneal(ctx, tree, p)
+    best = tree.best_trees()
+    if out:
+        with open(out, "w") as f:
+            for t in best:
+                f.write(host.newick(t, names))
+    res.update(taxa=n, sites_read=m_read, sites_used=len(rows[0]), min_len_tree=min_len, start_length=start,
+               wall_seconds=time.perf_counter() - t0, log=log, outtree=out)
+    if verbose:
+        ci = min_len / res["best_length"]
+        print("\nSearch Results:")
+        print(f"  Rearrangements evaluated: {res['consumed']}")
+        print(f"  Candidates scored (GPU):  {res['scored']}")
+        print(f"  Topologies recovered:     {res['topologies']}")
+        print(f"  Tree score:               {res['best_length']}")
+        print(f"  Consistency index:        {ci:.2f}")
+        print(f"  Homoplasy index:          {1 - ci:.2f}")
+        print(f"  Total runtime (seconds):  {res['wall_seconds']:.2f}")
+        if out:
+            print(f"\nAll topologies written to '{out}'")
+    tree.close()
+    ctx.close()
+    return res
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="python -m lvb_amd.search")
+    ap.add_argument("-i", dest="infile", default="infile")
+    ap.add_argument("-o", dest="out", default="outtree")
+    ap.add_argument("-s", dest="seed", type=int, default=int(time.time()) % 900000000)
+    ap.add_argument("-a", dest="algorithm", type=int, default=1)
+    ap.add_argument("-c", dest="cooling", choices=["g", "l"], default="g")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--max-seconds", type=float, default=0.0)
+    a = ap.parse_args(argv)
+    try:
+        run(a.infile, a.seed, a.algorithm, a.batch, a.device, a.out, a.max_seconds, 0 if a.cooling == "g" else 1)
+    except (api.LvbGpuError, ValueError, OSError) as exc:
+        print(f"\nFATAL ERROR: {exc}")
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

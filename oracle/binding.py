@@ -248,6 +248,9 @@ def load_ref():
     lib.refh_tree_bytes.restype = C.c_long
     lib.refh_tree_bytes.argtypes = [vp]
     lib.refh_layout.argtypes = [_longp]
+    lib.refh_treeprint.restype = C.c_int
+    lib.refh_treeprint.argtypes = [vp, C.c_int, C.c_char_p]
+    lib.refh_row_title.argtypes = [vp, C.c_long, C.c_char_p, C.c_long]
     lib.refh_time_proposals.argtypes = [vp, C.c_int, C.c_long, C.c_long, C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     lib.refh_time_full.restype = C.c_double
@@ -363,6 +366,20 @@ class RefRun:
 
     def tree_block(self, which: int):
         return C.cast(self.lib.refh_tree_block(self.h, which), C.POINTER(Node))
+
+    def titles(self) -> list[bytes]:
+        out = []
+        for i in range(self.n):
+            buf = C.create_string_buffer(256)
+            self.lib.refh_row_title(self.h, i, buf, 256)
+            out.append(buf.value)
+        return out
+
+    def treeprint(self, which: int = 0) -> str:
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".tre") as f:
+            assert self.lib.refh_treeprint(self.h, which, os.fsencode(f.name)) == 0
+            return Path(f.name).read_text()
 
     def time_proposals(self, kind: int, reps: int, accept_every: int = 4):
         tg, tm = C.c_double(), C.c_double()

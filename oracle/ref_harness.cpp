@@ -240,6 +240,24 @@ void *refh_tree_block(void *vh, int which) { return ((RefHandle *)vh)->tree[whic
 void *refh_msa(void *vh) { return &((RefHandle *)vh)->msa; }
 long refh_tree_bytes(void *vh) { return ((RefHandle *)vh)->msa.tree_bytes; }
 
+/* the reference's own tree text (lvb_treeprint -> ur_print, TreeOperations.c:1149-1220) and row titles */
+int refh_treeprint(void *vh, int which, const char *path)
+{
+    RefHandle *h = (RefHandle *)vh;
+    FILE *f = fopen(path, "w");
+    if (!f)
+        return -1;
+    lvb_treeprint(&h->msa, f, h->tree[which], h->root[which]);
+    fclose(f);
+    return 0;
+}
+
+void refh_row_title(void *vh, long i, char *out, long cap)
+{
+    RefHandle *h = (RefHandle *)vh;
+    snprintf(out, (size_t)cap, "%s", h->msa.rowtitle[i]);
+}
+
 /* struct layout facts the drop-in adapter relies on */
 void refh_layout(long *out)
 {

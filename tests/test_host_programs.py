@@ -152,3 +152,25 @@ def test_random_topologies_are_valid_and_varied(host):
         assert (l[12:] >= 0).all() and (r[12:] >= 0).all()
         seen.add(helpers.splits_of(l, r, 0, 12))
     assert len(seen) > 30
+
+
+def test_topology_hash_identifies_unrooted_topologies(host):
+    """The treestack mirror: same bipartition set <=> same hash, whatever the root or the moves
+    that led there; different topologies differ."""
+    n = 14
+    tree = host.HostTree(n, seed=21)
+    seen = {}
+    for step in range(400):
+        _, l, r = tree.arrays()
+        key = helpers.splits_of(l, r, tree.root, n)
+        h = tree.topology_hash()
+        assert seen.setdefault(key, h) == h
+        if step % 5 == 4:
+            new_root = (tree.root + 3) % n
+            tree.apply(tree.reroot_edits(new_root), new_root)
+            _, l2, r2 = tree.arrays()
+            assert helpers.splits_of(l2, r2, tree.root, n) == key     # re-rooting keeps the topology
+            assert tree.topology_hash() == h
+        else:
+            tree.apply(tree.propose(step % 3))
+    assert len(set(seen.values())) == len(seen) > 100
