@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--nbatches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--walk", type=int, default=75, help="accepted random moves applied to the start tree "
                     "before measuring (BASELINE.md: 300 proposals, every 4th accepted)")
+    ap.add_argument("--dist", choices=["tree", "uniform"], default="tree",
+                    help="synthetic alignment: tree-like (generator T of SURVEY.md 8d) or i.i.d. uniform (U)")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--anneal-seconds", type=float, default=4.0,
@@ -55,10 +57,11 @@ def parse_args():
     return ap.parse_args()
 
 
-def synth_rows(n: int, m: int, seed: int) -> list[bytes]:
-    """Generator T of SURVEY.md 8(d): taxon 0 uniform, taxon i copies taxon (i-1)//2 with 10 % substitutions."""
-    from tests.synth import treelike_rows
-    return treelike_rows(n, m, seed)
+def synth_rows(n: int, m: int, seed: int, dist: str = "tree") -> list[bytes]:
+    """Generator T of SURVEY.md 8(d): taxon 0 uniform, taxon i copies taxon (i-1)//2 with 10 % substitutions;
+    generator U: every cell i.i.d. uniform over ACGT."""
+    from tests.synth import treelike_rows, uniform_rows
+    return treelike_rows(n, m, seed) if dist == "tree" else uniform_rows(n, m, seed)
 
 
 def cpu_all_cores(taxa: int, sites_seed, kind: int, seconds: float):
@@ -163,7 +166,7 @@ def main():
 
     kind = MOVES[args.move]
     t_setup = time.perf_counter()
-    rows, min_len = host.prepare_alignment(synth_rows(args.taxa, args.sites, args.seed))
+    rows, min_len = host.prepare_alignment(synth_rows(args.taxa, args.sites, args.seed, args.dist))
     ctx = api.FitchContext(text_rows=rows, device=local_rank)      # encode on the device
     tree = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed))  # each rank: its own restart
     length = tree.upload(ctx)
@@ -255,7 +258,8 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.taxa} taxa x {args.sites} sites synthetic DNA (tree-like, 10% substitutions), "
+            "workload": f"{args.taxa} taxa x {args.sites} sites synthetic DNA "
+                        f"({'tree-like, 10% substitutions' if args.dist == 'tree' else 'i.i.d. uniform'}), "
                         f"{args.move.upper()} neighbourhood, incremental getplen semantics, "
                         f"B={args.batch} candidates per step, {args.nbatches} resident batches cycled",
             "taxa": args.taxa, "sites_after_constant_cut": len(rows[0]), "nwords": ctx.nwords,
@@ -295,7 +299,7 @@ def main():
             "t_final": res["t_final"], "temperatures": res["temperatures"], "frozen": res["frozen"],
             "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dist == "tree":
         out["cpu_baseline"] = cpu_baseline(rows, kind, args.cpu_seconds, spot, (args.sites, args.seed))
     for b in batches:
         b.free()
