@@ -220,6 +220,7 @@ struct lvbgpu_ctx
     DevBuf d_prog, d_len; // scratch for single-program launches (set_tree, commit)
     DevBuf d_export;      // one row in nibble layout (lvbgpu_get_sets)
     lvbgpu_batch *step_batch = nullptr; // recycled by lvbgpu_score_batch
+    lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
     PinBuf h_pin;
     DevBuf d_cin, d_cout; // strict-compat arenas
     PinBuf h_cin, h_cout;
@@ -544,11 +545,12 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipFree(ctx->d_scalars);
     delete ctx->pool;
     ctx->pool = nullptr;
-    if (ctx->step_batch)
-    {
-        ctx->step_batch->ctx = nullptr;
-        lvbgpu_batch_free(ctx->step_batch);
-    }
+    for (lvbgpu_batch *rb : {ctx->step_batch, ctx->full_batch})
+        if (rb)
+        {
+            rb->ctx = nullptr;
+            lvbgpu_batch_free(rb);
+        }
     ctx->d_prog.release();
     ctx->d_len.release();
     ctx->d_export.release();
@@ -759,30 +761,6 @@ extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
     delete b;
 }
 
-namespace
-{
-int finish_batch(lvbgpu_ctx *ctx, lvbgpu_batch *b, const Packed &pk, bool full_mode)
-{
-    int rc = check_depth(ctx, pk.max_stack);
-    if (rc != LVBGPU_OK)
-        return rc;
-    if ((uint64_t)b->B * ctx->ntiles >= (1ull << 31))
-        return ctx->fail(LVBGPU_E_ARG, "batch too large: B * tiles must stay below 2^31");
-    rc = upload_program(ctx, b->d_prog, pk.cands, pk.toks, pk.dsts, &b->off_toks, &b->off_dsts);
-    if (rc != LVBGPU_OK)
-        return rc;
-    HIPCHK(ctx, b->d_len.reserve((size_t)b->B * 8));
-    HIPCHK(ctx, b->h_len.reserve((size_t)b->B * 8));
-    b->full_mode = full_mode;
-    b->stats.candidates = b->B;
-    b->stats.combines = (int64_t)pk.dsts.size();
-    b->stats.rows_read = (int64_t)pk.toks.size();
-    b->stats.dirty_nodes = pk.dirty;
-    b->stats.max_stack = pk.max_stack;
-    b->stats.algorithmic_bytes = b->stats.rows_read * ctx->nwords * 8;
-    return LVBGPU_OK;
-}
-} // namespace
 
 namespace
 {
@@ -798,10 +776,60 @@ int build_threads()
     return n < 1 ? 1 : n;
 }
 
-// programs of candidates [b0, b1) with one worker's private topology copy
-void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const int32_t *edit_offsets,
-                 const lvbgpu_edit *edits, const int32_t *roots)
+// what a batch is made from: edits against the resident tree, or whole topologies
+struct BuildJob
 {
+    const int32_t *edit_offsets = nullptr;
+    const lvbgpu_edit *edits = nullptr;
+    const int32_t *roots = nullptr;
+    const int32_t *left = nullptr, *right = nullptr; // full mode: [B][2n-3]
+    bool full = false;
+};
+
+// whole-tree programs of trees [b0, b1)
+void build_slice_full(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const BuildJob &job)
+{
+    w.topo_version = ~0ull; // the private topology is overwritten below
+    w.pb.resize(ctx->nb);
+    w.prog.toks.clear();
+    w.prog.dsts.clear();
+    w.cands.clear();
+    w.max_stack = 0;
+    w.dirty = 0;
+    w.rc = LVBGPU_OK;
+    for (int32_t b = b0; b < b1; b++)
+    {
+        if (!w.topo.assign((int32_t)ctx->n, job.left + (size_t)b * ctx->nb, job.right + (size_t)b * ctx->nb,
+                           job.roots ? job.roots[b] : 0, &w.why))
+        {
+            w.rc = LVBGPU_E_TOPOLOGY;
+            w.why = "tree " + std::to_string(b) + ": " + w.why;
+            return;
+        }
+        const size_t tok0 = w.prog.toks.size(), dst0 = w.prog.dsts.size();
+        w.prog.max_stack = 0;
+        w.pb.build_full(w.topo, w.prog);
+        CandDesc cd{};
+        cd.tok_off = (uint32_t)tok0;
+        cd.ntok = (uint32_t)(w.prog.toks.size() - tok0);
+        cd.dst_off = (uint32_t)dst0;
+        cd.ncomb = (uint32_t)(w.prog.dsts.size() - dst0);
+        for (size_t i = tok0; i < w.prog.toks.size(); i++)
+            cd.nfresh += (w.prog.toks[i] & TOK_FRESH) ? 1u : 0u;
+        w.cands.push_back(cd);
+        w.max_stack = std::max(w.max_stack, w.prog.max_stack);
+        w.dirty += w.prog.dirty;
+    }
+}
+
+// programs of candidates [b0, b1) with one worker's private topology copy
+void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const BuildJob &job)
+{
+    if (job.full)
+        return build_slice_full(ctx, w, b0, b1, job);
+    const int32_t *edit_offsets = job.edit_offsets;
+    const lvbgpu_edit *edits = job.edits;
+    const int32_t *roots = job.roots;
     if (w.topo_version != ctx->topo_version)
     {
         w.topo = ctx->topo;
@@ -848,12 +876,13 @@ void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const 
 
 // fill `bt` (new or recycled: its buffers only ever grow) with the programs of B candidates:
 // slices of the batch are built on the pool's threads straight into the pinned upload buffer
-int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
-               const int32_t *roots)
+int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job)
 {
     static_assert(sizeof(lvbgpu_edit) == sizeof(Edit), "edit layout");
     int T = 1;
-    if (B >= PARALLEL_BUILD_MIN)
+    // whole-tree programs are ~n tokens each: worth the pool from a handful of trees on
+    const int32_t par_min = job.full ? 16 : PARALLEL_BUILD_MIN;
+    if (B >= par_min)
     {
         if (!ctx->pool)
         {
@@ -862,13 +891,12 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const int32_t *edit
                 ctx->pool = new (std::nothrow) Pool(n);
         }
         if (ctx->pool)
-            T = std::min(ctx->pool->size(), B / (PARALLEL_BUILD_MIN / 2));
+            T = std::max(1, std::min(ctx->pool->size(), B / (par_min / 2)));
     }
     if ((int)ctx->workers.size() < T)
         ctx->workers.resize(T);
     auto slice = [&](int t) {
-        build_slice(ctx, ctx->workers[t], (int32_t)((int64_t)B * t / T), (int32_t)((int64_t)B * (t + 1) / T),
-                    edit_offsets, edits, roots);
+        build_slice(ctx, ctx->workers[t], (int32_t)((int64_t)B * t / T), (int32_t)((int64_t)B * (t + 1) / T), job);
     };
     if (T == 1)
         slice(0);
@@ -930,7 +958,7 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const int32_t *edit
     bt->off_dsts = o_d;
     HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
-    bt->full_mode = false;
+    bt->full_mode = job.full;
     bt->stats.candidates = B;
     bt->stats.combines = (int64_t)ndst;
     bt->stats.rows_read = (int64_t)ntok;
@@ -953,7 +981,11 @@ extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
     lvbgpu_batch *bt = new (std::nothrow) lvbgpu_batch();
     if (!bt)
         return LVBGPU_E_NOMEM;
-    const int rc = build_into(ctx, bt, B, edit_offsets, edits, roots);
+    BuildJob job;
+    job.edit_offsets = edit_offsets;
+    job.edits = edits;
+    job.roots = roots;
+    const int rc = build_into(ctx, bt, B, job);
     if (rc != LVBGPU_OK)
     {
         lvbgpu_batch_free(bt);
@@ -1014,7 +1046,11 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
             return LVBGPU_E_NOMEM;
     }
     lvbgpu_batch *b = ctx->step_batch;
-    int rc = build_into(ctx, b, B, edit_offsets, edits, roots);
+    BuildJob job;
+    job.edit_offsets = edit_offsets;
+    job.edits = edits;
+    job.roots = roots;
+    int rc = build_into(ctx, b, B, job);
     if (rc == LVBGPU_OK)
         rc = lvbgpu_batch_launch(ctx, b);
     if (rc == LVBGPU_OK)
@@ -1028,36 +1064,23 @@ extern "C" int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t
     if (!ctx || B < 1 || !left || !right || !lengths_out)
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    Packed pk;
-    Program prog;
-    std::string why;
-    Topology t;
-    ProgramBuilder pb(ctx->nb);
-    for (int32_t b = 0; b < B; b++)
+    if (!ctx->full_batch)
     {
-        if (!t.assign((int32_t)ctx->n, left + (size_t)b * ctx->nb, right + (size_t)b * ctx->nb, roots ? roots[b] : 0,
-                      &why))
-            return ctx->fail(LVBGPU_E_TOPOLOGY, "tree " + std::to_string(b) + ": " + why);
-        const size_t tok0 = prog.toks.size(), dst0 = prog.dsts.size();
-        prog.max_stack = 0;
-        pb.build_full(t, prog);
-        pk.add(prog, tok0, dst0, 0, 0);
-        pk.max_stack = std::max(pk.max_stack, prog.max_stack);
-        pk.dirty += prog.dirty;
+        ctx->full_batch = new (std::nothrow) lvbgpu_batch();
+        if (!ctx->full_batch)
+            return LVBGPU_E_NOMEM;
     }
-    pk.toks.swap(prog.toks);
-    pk.dsts.swap(prog.dsts);
-    lvbgpu_batch *bt = new (std::nothrow) lvbgpu_batch();
-    if (!bt)
-        return LVBGPU_E_NOMEM;
-    bt->ctx = ctx;
-    bt->B = B;
-    int rc = finish_batch(ctx, bt, pk, true);
+    lvbgpu_batch *bt = ctx->full_batch; // recycled like the step batch
+    BuildJob job;
+    job.left = left;
+    job.right = right;
+    job.roots = roots;
+    job.full = true;
+    int rc = build_into(ctx, bt, B, job);
     if (rc == LVBGPU_OK)
         rc = lvbgpu_batch_launch(ctx, bt);
     if (rc == LVBGPU_OK)
         rc = lvbgpu_batch_lengths(ctx, bt, lengths_out);
-    lvbgpu_batch_free(bt);
     return rc;
 }
 
