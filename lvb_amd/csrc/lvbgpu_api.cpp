@@ -8,19 +8,17 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
-#include <functional>
-#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "kernels.hpp"
+#include "pool.hpp"
 #include "program.hpp"
 
 using namespace lvbgpu;
@@ -103,74 +101,6 @@ struct Id128
 {
     char bytes[128]; // ncclUniqueId
 };
-// a few persistent host threads: building B postorder programs is the host-side cost of a step
-class Pool
-{
-  public:
-    explicit Pool(int n)
-    {
-        for (int t = 0; t < n; t++)
-            threads_.emplace_back([this, t] { loop(t); });
-    }
-    ~Pool()
-    {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-            gen_++;
-        }
-        start_.notify_all();
-        for (auto &t : threads_)
-            t.join();
-    }
-    int size() const { return (int)threads_.size(); }
-    // run fn(t) for t in [0, active) on the workers and wait for all of them
-    void run(int active, const std::function<void(int)> &fn)
-    {
-        std::unique_lock<std::mutex> g(m_);
-        job_ = &fn;
-        active_ = active;
-        pending_ = active;
-        gen_++;
-        start_.notify_all();
-        done_.wait(g, [this] { return pending_ == 0; });
-        job_ = nullptr;
-    }
-
-  private:
-    void loop(int t)
-    {
-        uint64_t seen = 0;
-        for (;;)
-        {
-            const std::function<void(int)> *job = nullptr;
-            {
-                std::unique_lock<std::mutex> g(m_);
-                start_.wait(g, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_)
-                    return;
-                if (t < active_)
-                    job = job_;
-            }
-            if (job)
-            {
-                (*job)(t);
-                std::lock_guard<std::mutex> g(m_);
-                if (--pending_ == 0)
-                    done_.notify_one();
-            }
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex m_;
-    std::condition_variable start_, done_;
-    const std::function<void(int)> *job_ = nullptr;
-    int active_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
-};
-
 struct BuildWorker
 {
     Topology topo;
@@ -766,16 +696,6 @@ namespace
 {
 constexpr int32_t PARALLEL_BUILD_MIN = 512; // below this one thread is faster than waking the pool
 
-int build_threads()
-{
-    const char *e = getenv("LVBGPU_THREADS");
-    int n = e ? atoi(e) : 8;
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0 && n > hw)
-        n = hw;
-    return n < 1 ? 1 : n;
-}
-
 // what a batch is made from: edits against the resident tree, or whole topologies
 struct BuildJob
 {
@@ -886,7 +806,7 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     {
         if (!ctx->pool)
         {
-            const int n = build_threads();
+            const int n = host_threads();
             if (n > 1)
                 ctx->pool = new (std::nothrow) Pool(n);
         }

@@ -152,17 +152,22 @@ class HostTree:
         return self._edits(self.lib.lvbhost_propose, kind)
 
     def propose_batch(self, kind: int, B: int):
-        """-> (edit_offsets[B+1], edits) ready for lvbgpu_batch_build."""
-        cap = B * 64 + 1024
+        """-> (edit_offsets[B+1], edits) ready for lvbgpu_batch_build (views into reused buffers:
+        copy them if they must outlive the next call)."""
+        cap = getattr(self, "_cap", 0)
+        if cap < B * 8 + 64:
+            cap = B * 8 + 64
         while True:
-            offs = np.zeros(B + 1, dtype=np.int32)
-            buf = np.zeros(cap, dtype=api.EDIT_DTYPE)
-            state = self.lib.lvbhost_propose_batch(self.h, kind, B, offs, buf.ctypes.data, cap)
+            if getattr(self, "_cap", 0) != cap or len(getattr(self, "_offs", ())) != B + 1:
+                self._cap = cap
+                self._buf = np.empty(cap, dtype=api.EDIT_DTYPE)
+                self._offs = np.empty(B + 1, dtype=np.int32)
+            state = self.lib.lvbhost_propose_batch(self.h, kind, B, self._offs, self._buf.ctypes.data, cap)
             if state >= 0:
-                return offs, buf[:state].copy()
+                return self._offs, self._buf[:state]
             if cap > B * (2 * self.nbranches + 8):
                 raise api.LvbGpuError(state, "propose_batch failed")
-            cap *= 4  # note: the random stream has advanced; callers that need determinism reseed
+            cap *= 4  # note: the tree's stream has advanced; callers that need determinism reseed
 
     def nni_edits(self, u: int, swap_right: bool) -> np.ndarray:
         return self._edits(self.lib.lvbhost_nni_edits, int(u), int(bool(swap_right)))

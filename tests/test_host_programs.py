@@ -174,3 +174,4 @@ def test_topology_hash_identifies_unrooted_topologies(host):
         else:
             tree.apply(tree.propose(step % 3))
     assert len(set(seen.values())) == len(seen) > 100
+
