@@ -52,7 +52,10 @@ def parse_args():
     ap.add_argument("--anneal-seconds", type=float, default=4.0,
                     help="after the timed region, run the batched SA host end to end for this long and report "
                          "best-length-vs-wallclock (0 = skip)")
-    ap.add_argument("--anneal-batch", type=int, default=512)
+    ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
+    ap.add_argument("--e2e-steps", type=int, default=40,
+                    help="after the timed region: steps of lvbgpu_propose_score (neighbours drawn, programmed and "
+                         "scored on the GPU, lengths back on the host) to report the end-to-end rate (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -277,6 +280,19 @@ def main():
                     "the XCD L2 / Infinity Cache, so achieved may exceed the HBM figure",
         },
     }
+    if args.e2e_steps > 0:
+        # nothing resident but the tree: every step draws B fresh neighbours on the device
+        ctx.propose_score(args.batch, kind, 1)
+        ctx.synchronize()
+        te = time.perf_counter()
+        for i in range(args.e2e_steps):
+            ctx.propose_score(args.batch, kind, 1000 + i)
+        te = time.perf_counter() - te
+        out["end_to_end"] = {
+            "value": args.batch * args.e2e_steps / te, "unit": "trees/s", "steps": args.e2e_steps,
+            "what": "lvbgpu_propose_score per step: draw B neighbours + build their programs + score on the GPU, "
+                    "lengths and move descriptors copied back to the host (not part of `value`)",
+        }
     if args.anneal_seconds > 0:
         # second half of the metric: best length vs wall clock, whole host loop included
         # (proposal generation, program build, H2D, kernels, D2H, accept/commit) - not part of `value`

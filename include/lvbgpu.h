@@ -133,6 +133,24 @@ int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *batch, int64_t *lengths_
 int lvbgpu_batch_get_stats(const lvbgpu_batch *batch, lvbgpu_batch_stats *out);
 void lvbgpu_batch_free(lvbgpu_batch *batch);
 
+/* ---- neighbourhoods generated on the device ----------------------------------------------
+ * B random neighbours of the resident tree are DRAWN, turned into programs and scored on the
+ * GPU (no per-candidate host work, no program upload).  kind: 0 NNI, 1 SPR, 2 TBR (the rules of
+ * mutate_nni/spr/tbr, TreeOperations.c:160-541), -1 = candidate b gets kind b % 3.  The draw is a
+ * function of (seed, b) only.  lengths_out[b] is INT64_MAX for the rare candidate whose move
+ * does not fit the library's fixed per-candidate buffers (never accept those).
+ * lvbgpu_proposal_edits() returns candidate b of the LAST lvbgpu_propose_score() call as edits
+ * (for lvbgpu_commit and for the host's own topology mirror); info4, if not NULL, receives
+ * {kind, a, b, c}: NNI {0, u, swapped-right?, -}, SPR {1, src, dest, -}, TBR {2, src, dest, leaf x}. */
+int lvbgpu_propose_score(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint64_t seed, int64_t *lengths_out);
+/* the reference's two move schedules: parity >= 0: candidate b is an SPR if (parity + b) is odd, else
+ * an NNI (-a 0, Solve.c:288-297); parity < 0: each candidate draws NNI with probability p_nni, SPR
+ * with p_spr, TBR otherwise (-a 1, Solve.c:262-283) */
+int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_nni, double p_spr, int64_t parity,
+                               uint64_t seed, int64_t *lengths_out);
+int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits,
+                          int32_t *info4);
+
 /* B whole topologies scored from the leaf rows alone (every internal node recomputed, nothing
  * resident read or written): left/right are [B][2n-3]. */
 int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *left, const int32_t *right,

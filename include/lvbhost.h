@@ -123,6 +123,10 @@ typedef struct
                                  Lockstep mode: every rank must then run exactly max_device_steps (> 0)
                                  batches, so the other stop criteria are ignored */
     int32_t log_cap;          /* capacity of log_seconds/log_best */
+    int32_t device_proposals; /* 0: neighbours are drawn and programmed by this library on the host;
+                                 1: on the GPU (lvbgpu_propose_score*); 2: on the GPU for steps of
+                                 >= 1024 candidates, on the host for smaller ones (default) */
+    int32_t reserved;
 } lvbhost_anneal_params;
 
 typedef struct

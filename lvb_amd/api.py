@@ -63,6 +63,10 @@ SIGNATURES = {
     "lvbgpu_batch_lengths": (C.c_int, [C.c_void_p, C.c_void_p, _i64p]),
     "lvbgpu_batch_get_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_batch_free": (None, [C.c_void_p]),
+    "lvbgpu_propose_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, _i64p]),
+    "lvbgpu_propose_score_mixed": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_uint64,
+                                            _i64p]),
+    "lvbgpu_proposal_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _i32p]),
     "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
     "lvbgpu_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "lvbgpu_getplen_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_int64)]),
@@ -258,6 +262,26 @@ class FitchContext:
         self._chk(self.lib.lvbgpu_batch_build(self.h, len(cands), offs, edits.ctypes.data,
                                                None if rts is None else rts.ctypes.data, C.byref(bh)))
         return Batch(self, bh, len(cands))
+
+    # ---- neighbourhoods drawn and scored on the device
+    def propose_score(self, B: int, kind: int, seed: int) -> np.ndarray:
+        out = np.zeros(B, dtype=np.int64)
+        self._chk(self.lib.lvbgpu_propose_score(self.h, B, kind, seed, out))
+        return out
+
+    def propose_score_mixed(self, B: int, p_nni: float, p_spr: float, parity: int, seed: int) -> np.ndarray:
+        out = np.zeros(B, dtype=np.int64)
+        self._chk(self.lib.lvbgpu_propose_score_mixed(self.h, B, p_nni, p_spr, parity, seed, out))
+        return out
+
+    def proposal_edits(self, b: int):
+        """Candidate b of the last propose_score batch -> (edits, [kind, a, b, c])."""
+        cap = 2 * self.nbranches + 8
+        buf = np.zeros(cap, dtype=EDIT_DTYPE)
+        k = C.c_int32()
+        info = np.zeros(4, dtype=np.int32)
+        self._chk(self.lib.lvbgpu_proposal_edits(self.h, int(b), buf.ctypes.data, cap, C.byref(k), info))
+        return buf[: k.value].copy(), info
 
     def score_full_batch(self, lefts, rights, roots=None) -> np.ndarray:
         l = np.ascontiguousarray(lefts, dtype=np.int32)

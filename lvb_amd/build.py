@@ -20,7 +20,7 @@ CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 ARCH = "gfx950"
 
-GPU_SOURCES = ["fitch_kernels.hip", "lvbgpu_api.cpp", "program.cpp"]
+GPU_SOURCES = ["fitch_kernels.hip", "propose_kernels.hip", "lvbgpu_api.cpp", "program.cpp"]
 GPU_HEADERS = ["kernels.hpp", "program.hpp", "pool.hpp"]
 COMPAT_SOURCES = ["getplen_adapter.cpp"]
 HOST_SOURCES = ["host_api.cpp", "proposals.cpp", "anneal.cpp", "program.cpp"]

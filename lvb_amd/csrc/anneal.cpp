@@ -9,7 +9,8 @@
 //     consume them; at the first accepted one the tree is committed and the rest of the batch
 //     (neighbours of a tree that no longer exists) is discarded.  The chain is distributed as the
 //     serial chain; only wasted scoring work differs.  A batch never crosses a temperature
-//     change or a re-root tick.
+//     change or a re-root tick, and its size follows the running acceptance rate (params.batch is
+//     the ceiling).
 //   * the re-root is an edit along the old-root..new-root path (the reference re-evaluates the
 //     whole tree, TreeOperations.c:631-635); lengths and node sets come out the same.
 //   * the treestack is a set of topology hashes (bipartition keys, host_tree.hpp) instead of stored
@@ -21,7 +22,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <vector>
 
 #include "host_tree.hpp"
@@ -48,6 +51,8 @@ struct Chain
     std::vector<int> kinds;
     double dev_seconds = 0.0;
     int64_t scored = 0, dirty = 0;
+    bool on_device = false;          // neighbours drawn on the GPU (lvbgpu_propose_score*)
+    std::vector<lvbgpu_edit> fetched; // edits of an accepted device candidate
 
     // score B fresh proposals of the given kinds; returns lvbgpu status
     int score(int B)
@@ -67,8 +72,37 @@ struct Chain
         scored += B;
         return rc;
     }
+    // B neighbours drawn, programmed and scored on the device.  schedule: >= 0 fixed kind,
+    // -2 alternate NNI/SPR from `parity`, -3 draw by (p_nni, p_spr)
+    int score_device(int B, int schedule, int64_t parity, double p_nni, double p_spr)
+    {
+        lens.resize(B);
+        const uint64_t seed = tree->rng.next();
+        const auto t0 = Clock::now();
+        int rc;
+        if (schedule >= 0)
+            rc = lvbgpu_propose_score(ctx, B, schedule, seed, lens.data());
+        else
+            rc = lvbgpu_propose_score_mixed(ctx, B, p_nni, p_spr, schedule == -2 ? parity : -1, seed, lens.data());
+        dev_seconds += since(t0);
+        scored += B;
+        return rc;
+    }
     int commit(int b, int64_t *len)
     {
+        if (on_device)
+        {
+            fetched.resize((size_t)2 * tree->topo.nb + 8);
+            int32_t ne = 0;
+            const auto t0 = Clock::now();
+            int rc = lvbgpu_proposal_edits(ctx, b, fetched.data(), (int32_t)fetched.size(), &ne, nullptr);
+            if (rc == LVBGPU_OK)
+                rc = lvbgpu_commit(ctx, ne, fetched.data(), -1, len);
+            dev_seconds += since(t0);
+            if (rc == LVBGPU_OK)
+                rc = lvbhost_tree_apply(tree, fetched.data(), ne, -1);
+            return rc;
+        }
         const Edit *e = edits.data() + offs[b];
         const int32_t ne = offs[b + 1] - offs[b];
         const auto t0 = Clock::now();
@@ -124,7 +158,7 @@ extern "C" void lvbhost_anneal_defaults(lvbhost_anneal_params *p)
     p->seed = 0x9E3779B97F4A7C15ull;
     p->algorithm = 1;        // SearchParameters.c:81
     p->cooling_schedule = 0; // geometric
-    p->batch = 256;
+    p->batch = 4096; // ceiling: the step size follows the acceptance rate
     p->reroot_interval = 1000;
     p->t0 = 0.0;
     p->maxaccept = 5;
@@ -136,6 +170,8 @@ extern "C" void lvbhost_anneal_defaults(lvbhost_anneal_params *p)
     p->max_device_steps = 0;
     p->sync_every = 0;
     p->log_cap = 0;
+    p->device_proposals = 2;
+    p->reserved = 0;
 }
 
 extern "C" int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost_anneal_params *p,
@@ -144,6 +180,7 @@ extern "C" int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree,
     if (!ctx || !tree || !p || !t0_out)
         return LVBGPU_E_ARG;
     Chain ch{ctx, tree};
+    ch.on_device = p->device_proposals == 1;
     int64_t cur = 0;
     int rc = lvbgpu_current_length(ctx, &cur);
     if (rc != LVBGPU_OK)
@@ -165,16 +202,23 @@ extern "C" int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree,
                     return rc;
             }
             const int nb = std::min(B, sample + 1 - iter);
-            ch.kinds.resize(nb);
-            for (int b = 0; b < nb; b++)
-                ch.kinds[b] = ((iter + b) & 1) ? MOVE_SPR : MOVE_NNI; // 123-126
-            rc = ch.score(nb);
+            if (ch.on_device)
+                rc = ch.score_device(nb, -2, iter, 0, 0);
+            else
+            {
+                ch.kinds.resize(nb);
+                for (int b = 0; b < nb; b++)
+                    ch.kinds[b] = ((iter + b) & 1) ? MOVE_SPR : MOVE_NNI; // 123-126
+                rc = ch.score(nb);
+            }
             if (rc != LVBGPU_OK)
                 return rc;
             for (int b = 0; b < nb; b++)
             {
                 iter++;
                 const int64_t len = ch.lens[b];
+                if (len == INT64_MAX)
+                    continue; // a device candidate that did not fit its buffers: not a proposal
                 bool take = len <= cur;
                 if (!take)
                 {
@@ -237,6 +281,7 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
     }
 
     Chain ch{ctx, tree};
+    ch.on_device = p.device_proposals == 1;
     const double minlen = (double)p.min_len_tree;
     const double grad_geom = 0.99, grad_linear = 10 * LVB_EPS; // Solve.c:170-171
     const double log_eps = std::log(LVB_EPS), log_geom = std::log(grad_geom), log_t0 = std::log(t0);
@@ -258,10 +303,14 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
     tree->best.clear();
     tree->best.insert(tree->topo); // the initial tree is initially the best (Solve.c:208)
     bool done = false;
+    double accept_rate = 0.5;
     while (!done)
     {
+        // Speculation depth follows the acceptance rate: when most proposals are accepted, all but
+        // the first few of a batch would be thrown away; when acceptances are rare the whole
+        // batch is consumed.  `accept_rate` is a running estimate per consumed proposal.
+        int64_t room = std::min<int64_t>(p.batch, std::max<int64_t>(8, (int64_t)std::ceil(2.0 / accept_rate)));
         // how many proposals may be consumed before something the batch must not straddle
-        int64_t room = p.batch;
         if (p.reroot_interval > 0)
         {
             const int64_t to_tick = p.reroot_interval - (current_iter % p.reroot_interval);
@@ -282,8 +331,24 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
             room = std::min(room, std::max<int64_t>(1, p.max_proposals - iter));
         const int B = (int)std::max<int64_t>(1, room);
 
+        // drawing on the device pays once the batch is large (its fixed cost per step is higher,
+        // its cost per candidate ~10x lower): mode 2 switches per step
+        ch.on_device = p.device_proposals == 1 || (p.device_proposals == 2 && B >= 1024);
+        if (ch.on_device)
+        {
+            switch (p.algorithm)
+            {
+            case 0: rc = ch.score_device(B, -2, iter, 0, 0); break;
+            case 10: rc = ch.score_device(B, MOVE_NNI, 0, 0, 0); break;
+            case 11: rc = ch.score_device(B, MOVE_SPR, 0, 0, 0); break;
+            case 12: rc = ch.score_device(B, MOVE_TBR, 0, 0, 0); break;
+            default: rc = ch.score_device(B, -3, 0, probs[0], probs[1]); break;
+            }
+            if (rc != LVBGPU_OK)
+                return rc;
+        }
         ch.kinds.resize(B);
-        for (int b = 0; b < B; b++)
+        for (int b = 0; b < B && !ch.on_device; b++)
         {
             int kind;
             switch (p.algorithm)
@@ -300,15 +365,22 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
             }
             ch.kinds[b] = kind;
         }
-        rc = ch.score(B);
-        if (rc != LVBGPU_OK)
-            return rc;
+        if (!ch.on_device)
+        {
+            rc = ch.score(B);
+            if (rc != LVBGPU_OK)
+                return rc;
+        }
         res->device_steps++;
 
+        int consumed_now = 0, accepted_now = 0;
         for (int b = 0; b < B && !done; b++)
         {
-            current_iter++;
             const int64_t len = ch.lens[b];
+            if (len == INT64_MAX)
+                continue; // a device candidate that did not fit its buffers: not a proposal
+            current_iter++;
+            consumed_now++;
             // accept / reject (Solve.c:303-378)
             bool take;
             if (len <= cur)
@@ -317,6 +389,7 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
                 take = accept_worse(energy_delta(minlen, cur, len), t, tree->rng);
             if (take)
             {
+                accepted_now++;
                 const bool stack_it = len <= cur && len <= best; // ties or beats the best (Solve.c:309)
                 rc = ch.commit(b, &cur);
                 if (rc != LVBGPU_OK)
@@ -384,6 +457,8 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
             if (take || dect)
                 break; // stale neighbours / new temperature: start a fresh batch
         }
+        if (consumed_now > 0)
+            accept_rate = std::max(1e-4, 0.8 * accept_rate + 0.2 * (double)accepted_now / consumed_now);
         if (p.max_seconds > 0 && since(wall0) >= p.max_seconds)
             done = true;
         if (p.max_device_steps > 0 && res->device_steps >= p.max_device_steps)

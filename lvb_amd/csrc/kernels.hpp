@@ -59,6 +59,26 @@ inline uint32_t choose_groups(uint32_t B, uint32_t ntiles, uint32_t target_waves
     return (ntiles + per_wave - 1) / per_wave;
 }
 
+// ---- device-side proposals (propose_kernels.hip)
+struct lvbgpu_edit_dev
+{
+    int32_t node, left, right;
+};
+struct ProposalInfo
+{
+    int32_t kind;     // 0 NNI, 1 SPR, 2 TBR
+    int32_t a, b, c;  // NNI: u,-,- ; SPR: src,dest,- ; TBR: src,dest,x (-1: subtree too small, plain SPR)
+    int32_t flag;     // NNI: which child of u was swapped out
+    int32_t n_edits;  // edits written (may exceed the stride when overflow is set)
+    int32_t overflow; // the move did not fit the fixed strides: its length is meaningless, never accept it
+    int32_t ncomb;    // combines of its program (D + 2)
+};
+// topo4 = [parent | left | right | leaves-below] each 2n-3 int32
+hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
+                          uint64_t seed, uint32_t B,
+                          uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
+                          CandDesc *cands, ProposalInfo *info, hipStream_t stream);
+
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
 hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -151,6 +153,13 @@ struct lvbgpu_ctx
     DevBuf d_export;      // one row in nibble layout (lvbgpu_get_sets)
     lvbgpu_batch *step_batch = nullptr; // recycled by lvbgpu_score_batch
     lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
+    // device-side proposals (lvbgpu_propose_score)
+    lvbgpu_batch *prop_batch = nullptr;
+    DevBuf d_topo4, d_pedits, d_pinfo;
+    PinBuf h_pinfo;
+    uint64_t d_topo_version = ~0ull;
+    uint32_t p_stride_t = 0, p_stride_e = 0;
+    int32_t p_B = 0; // candidates of the last device batch (0: none)
     PinBuf h_pin;
     DevBuf d_cin, d_cout; // strict-compat arenas
     PinBuf h_cin, h_cout;
@@ -475,7 +484,11 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipFree(ctx->d_scalars);
     delete ctx->pool;
     ctx->pool = nullptr;
-    for (lvbgpu_batch *rb : {ctx->step_batch, ctx->full_batch})
+    ctx->d_topo4.release();
+    ctx->d_pedits.release();
+    ctx->d_pinfo.release();
+    ctx->h_pinfo.release();
+    for (lvbgpu_batch *rb : {ctx->step_batch, ctx->full_batch, ctx->prop_batch})
         if (rb)
         {
             rb->ctx = nullptr;
@@ -976,6 +989,181 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
     if (rc == LVBGPU_OK)
         rc = lvbgpu_batch_lengths(ctx, b, lengths_out);
     return rc;
+}
+
+// ---- device-side neighbourhoods
+
+namespace
+{
+// parent | left | right | number of leaves below, for propose_kernel
+int sync_device_topology(lvbgpu_ctx *ctx)
+{
+    if (ctx->d_topo_version == ctx->topo_version)
+        return LVBGPU_OK;
+    const int32_t nb = ctx->nb;
+    const Topology &t = ctx->topo;
+    std::vector<int32_t> host((size_t)4 * nb);
+    memcpy(host.data(), t.parent.data(), (size_t)nb * 4);
+    memcpy(host.data() + nb, t.left.data(), (size_t)nb * 4);
+    memcpy(host.data() + 2 * (size_t)nb, t.right.data(), (size_t)nb * 4);
+    int32_t *leaves = host.data() + 3 * (size_t)nb;
+    // leaves below each node: children before parents via an explicit preorder
+    std::vector<int32_t> order;
+    order.reserve(nb);
+    std::vector<int32_t> st{t.root};
+    while (!st.empty())
+    {
+        const int32_t v = st.back();
+        st.pop_back();
+        order.push_back(v);
+        if (t.left[v] >= 0)
+        {
+            st.push_back(t.left[v]);
+            st.push_back(t.right[v]);
+        }
+    }
+    for (auto it = order.rbegin(); it != order.rend(); ++it)
+    {
+        const int32_t v = *it;
+        leaves[v] = (t.left[v] < 0 || v == t.root) ? 1 : leaves[t.left[v]] + leaves[t.right[v]];
+    }
+    HIPCHK(ctx, ctx->d_topo4.reserve(host.size() * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_topo4.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // `host` goes out of scope
+    ctx->d_topo_version = ctx->topo_version;
+    return LVBGPU_OK;
+}
+} // namespace
+
+namespace
+{
+int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a, uint32_t mix_b, uint64_t seed,
+                       int64_t *lengths_out)
+{
+    if (!ctx || B < 1 || kind < -3 || kind > 2 || !lengths_out)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    if (ctx->n < 5)
+        return ctx->fail(LVBGPU_E_ARG, "rearrangements need at least 5 taxa");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = sync_device_topology(ctx);
+    if (rc != LVBGPU_OK)
+        return rc;
+    // fixed strides: a program has at most (n-3)+3 tokens; edits are capped (longer TBR paths overflow)
+    const uint32_t stride_t = (uint32_t)ctx->n + 8u;
+    const uint32_t stride_e = (uint32_t)std::min<int64_t>(ctx->nb, 512);
+    if ((uint64_t)B * stride_t >= (1ull << 32) || (uint64_t)B * ctx->ntiles >= (1ull << 31))
+        return ctx->fail(LVBGPU_E_ARG, "batch too large");
+    if (!ctx->prop_batch)
+    {
+        ctx->prop_batch = new (std::nothrow) lvbgpu_batch();
+        if (!ctx->prop_batch)
+            return LVBGPU_E_NOMEM;
+    }
+    lvbgpu_batch *bt = ctx->prop_batch;
+    const size_t o_t = align16((size_t)B * sizeof(CandDesc));
+    const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
+    const size_t total = o_d + align16((size_t)B * stride_t * 4);
+    HIPCHK(ctx, bt->d_prog.reserve(total));
+    HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
+    HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
+    HIPCHK(ctx, ctx->d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
+    HIPCHK(ctx, ctx->d_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
+    HIPCHK(ctx, ctx->h_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
+    bt->ctx = ctx;
+    bt->B = B;
+    bt->off_toks = o_t;
+    bt->off_dsts = o_d;
+    bt->full_mode = false;
+    bt->stats = lvbgpu_batch_stats{};
+    bt->stats.candidates = B;
+    bt->stats.max_stack = 1; // at most one sibling set waits while the other path is walked
+    ctx->p_stride_t = stride_t;
+    ctx->p_stride_e = stride_e;
+    ctx->p_B = 0;
+    HIPCHK(ctx, launch_propose((const int32_t *)ctx->d_topo4.p, (int32_t)ctx->n, ctx->topo.root, kind, mix_a, mix_b, seed,
+                               (uint32_t)B,
+                               stride_t, stride_e, (uint32_t *)((char *)bt->d_prog.p + o_t),
+                               (int32_t *)((char *)bt->d_prog.p + o_d), (lvbgpu_edit_dev *)ctx->d_pedits.p,
+                               (CandDesc *)bt->d_prog.p, (ProposalInfo *)ctx->d_pinfo.p, ctx->stream));
+    rc = lvbgpu_batch_launch(ctx, bt);
+    if (rc != LVBGPU_OK)
+        return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinfo.p, ctx->d_pinfo.p, (size_t)B * sizeof(ProposalInfo), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const ProposalInfo *pi = (const ProposalInfo *)ctx->h_pinfo.p;
+    const int64_t *len = (const int64_t *)bt->h_len.p;
+    int64_t combines = 0;
+    for (int32_t b = 0; b < B; b++)
+    {
+        if (pi[b].overflow)
+        {
+            lengths_out[b] = INT64_MAX;
+            continue;
+        }
+        lengths_out[b] = len[b];
+        combines += pi[b].ncomb;
+        if (len[b] <= 0)
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    }
+    bt->stats.combines = combines;
+    bt->stats.rows_read = combines + B;
+    bt->stats.dirty_nodes = combines - 2 * (int64_t)B;
+    bt->stats.algorithmic_bytes = bt->stats.rows_read * ctx->nwords * 8;
+    ctx->p_B = B;
+    return LVBGPU_OK;
+}
+} // namespace
+
+extern "C" int lvbgpu_propose_score(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint64_t seed, int64_t *lengths_out)
+{
+    if (kind < -1)
+        return LVBGPU_E_ARG;
+    return propose_score_impl(ctx, B, kind, 0, 0, seed, lengths_out);
+}
+
+extern "C" int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_nni, double p_spr, int64_t parity,
+                                          uint64_t seed, int64_t *lengths_out)
+{
+    if (parity >= 0)
+        return propose_score_impl(ctx, B, -2, (uint32_t)(parity & 1), 0, seed, lengths_out);
+    if (!(p_nni >= 0) || !(p_spr >= 0) || p_nni + p_spr > 1.0 + 1e-12)
+        return LVBGPU_E_ARG;
+    auto scaled = [](double p) { return (uint32_t)std::min(4294967295.0, p * 4294967296.0); };
+    return propose_score_impl(ctx, B, -3, scaled(p_nni), scaled(p_nni + p_spr), seed, lengths_out);
+}
+
+extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits,
+                                     int32_t *info4)
+{
+    if (!ctx || !edits || !n_edits)
+        return LVBGPU_E_ARG;
+    if (ctx->p_B <= 0 || b < 0 || b >= ctx->p_B)
+        return ctx->fail(LVBGPU_E_STATE, "no device batch holds that candidate: call lvbgpu_propose_score first");
+    if (ctx->d_topo_version != ctx->topo_version)
+        return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since that batch was drawn");
+    const ProposalInfo &pi = ((const ProposalInfo *)ctx->h_pinfo.p)[b];
+    if (pi.overflow)
+        return ctx->fail(LVBGPU_E_ARG, "that candidate overflowed the per-candidate buffers");
+    if (pi.n_edits > cap)
+        return ctx->fail(LVBGPU_E_ARG, "edit buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    static_assert(sizeof(lvbgpu_edit) == sizeof(lvbgpu_edit_dev), "edit layout");
+    HIPCHK(ctx, hipMemcpyAsync(edits, (const lvbgpu_edit_dev *)ctx->d_pedits.p + (size_t)b * ctx->p_stride_e,
+                               (size_t)pi.n_edits * sizeof(lvbgpu_edit), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_edits = pi.n_edits;
+    if (info4)
+    {
+        info4[0] = pi.kind;
+        info4[1] = pi.a;
+        info4[2] = pi.kind == 0 ? pi.flag : pi.b;
+        info4[3] = pi.c;
+    }
+    return LVBGPU_OK;
 }
 
 extern "C" int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *left, const int32_t *right,

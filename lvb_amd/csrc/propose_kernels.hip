@@ -1,0 +1,509 @@
+// propose_kernels.hip - NNI / SPR / TBR proposals AND their postorder programs generated on the
+// device (SURVEY.md 8f "next" row 1: once scoring is fast, building candidates on the host and
+// shipping them over PCIe is the limiter).
+//
+// One thread = one candidate.  It draws a move with the reference's rules
+//   mutate_nni TreeOperations.c:160-209, mutate_spr :236-335, mutate_tbr :337-541
+// (same eligibility/rejection loops, same re-use of the pruned parent as graft node; the random
+// stream is a counter-based splitmix64, not the reference's generator), and writes
+//   - the move as child-pair rewrites (edits) - what the host applies if the candidate is accepted,
+//   - the token program fitch_walk will run (program.hpp's format), and its CandDesc.
+//
+// The dirty set of any of these moves is a union of at most two root-ward paths in the NEW
+// topology (the reference's make_dirty_below calls), so the program is one or two chains, one
+// merge, and the common path to the root; no general postorder is needed here (the general builder
+// stays on the host: program.cpp).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace lvbgpu
+{
+
+namespace
+{
+
+struct DevRng
+{
+    uint64_t s;
+    __device__ uint64_t next()
+    {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    __device__ uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+};
+
+// the emitting side of one candidate
+struct Emit
+{
+    uint32_t *toks;
+    int32_t *dsts;
+    lvbgpu_edit_dev *edits;
+    uint32_t ntok = 0, ndst = 0, nedit = 0, nfresh = 0, cap_t, cap_e;
+    bool overflow = false;
+
+    __device__ void tok(int32_t row, uint32_t flags)
+    {
+        if (ntok < cap_t)
+            toks[ntok] = (uint32_t)row | flags;
+        else
+            overflow = true;
+        ntok++;
+        if (flags & TOK_FRESH)
+            nfresh++;
+    }
+    __device__ void dst(int32_t d)
+    {
+        if (ndst < cap_t)
+            dsts[ndst] = d;
+        else
+            overflow = true;
+        ndst++;
+    }
+    __device__ void merge(int32_t d)
+    {
+        if (ntok > 0 && ntok <= cap_t)
+            toks[ntok - 1] += 1u << TOK_MERGE_SHIFT;
+        dst(d);
+    }
+    __device__ void edit(int32_t node, int32_t l, int32_t r)
+    {
+        if (nedit < cap_e)
+            edits[nedit] = {node, l, r};
+        else
+            overflow = true;
+        nedit++;
+    }
+};
+
+struct Topo
+{
+    const int32_t *parent, *left, *right, *leaves;
+    int32_t n, nb, root;
+    __device__ int32_t sister(int32_t v) const
+    {
+        const int32_t p = parent[v];
+        return left[p] == v ? right[p] : left[p];
+    }
+};
+
+// children of v in the topology after an SPR-shaped move: pp lost sp for ss, dp lost dest for sp,
+// sp holds (dest, top)
+struct SprView
+{
+    const Topo &t;
+    int32_t sp, ss, pp, dp, dest, top;
+    __device__ void children(int32_t v, int32_t &l, int32_t &r) const
+    {
+        if (v == sp)
+        {
+            l = dest;
+            r = top;
+            return;
+        }
+        l = t.left[v];
+        r = t.right[v];
+        if (v == pp)
+        {
+            if (l == sp)
+                l = ss;
+            else
+                r = ss;
+        }
+        if (v == dp)
+        {
+            if (l == dest)
+                l = sp;
+            else if (r == dest)
+                r = sp;
+        }
+    }
+    __device__ int32_t parent(int32_t v) const
+    {
+        if (v == sp)
+            return dp;
+        if (v == ss)
+            return pp;
+        if (v == dest || v == top)
+            return sp;
+        return t.parent[v];
+    }
+    __device__ int32_t other_child(int32_t v, int32_t d) const
+    {
+        int32_t l, r;
+        children(v, l, r);
+        return l == d ? r : l;
+    }
+};
+
+constexpr int MAX_PATH = 768; // nodes of one root-ward path kept per thread (scratch memory); longer -> overflow flag
+
+} // namespace
+
+// kind_all: 0 NNI, 1 SPR, 2 TBR; -1: candidate b gets kind b % 3; -2: NNI/SPR alternate by the
+// parity of (mix_a + b) (reference -a 0, Solve.c:288-297); -3: drawn per candidate, NNI below
+// threshold mix_a, SPR below mix_b, else TBR, both scaled to 2^32 (reference -a 1, Solve.c:262-283)
+__global__ void propose_kernel(const int32_t *parent, const int32_t *left, const int32_t *right, const int32_t *leaves,
+                               int32_t n, int32_t root, int32_t kind_all, uint32_t mix_a, uint32_t mix_b,
+                               uint64_t seed, uint32_t B, uint32_t stride_t,
+                               uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
+                               CandDesc *cands, ProposalInfo *info)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B)
+        return;
+    const Topo t{parent, left, right, leaves, n, 2 * n - 3, root};
+    DevRng rng{seed ^ ((uint64_t)(b + 1) * 0xD1B54A32D192ED03ull)};
+    Emit e;
+    e.toks = toks + (size_t)b * stride_t;
+    e.dsts = dsts + (size_t)b * stride_t;
+    e.edits = edits + (size_t)b * stride_e;
+    e.cap_t = stride_t;
+    e.cap_e = stride_e;
+    int32_t kind = kind_all;
+    if (kind_all == -1)
+        kind = (int32_t)(b % 3u);
+    else if (kind_all == -2)
+        kind = ((mix_a + b) & 1u) ? 1 : 0;
+    else if (kind_all == -3)
+    {
+        const uint32_t r = (uint32_t)(rng.next() >> 32);
+        kind = r < mix_a ? 0 : (r < mix_b ? 1 : 2);
+    }
+    ProposalInfo pi{kind, -1, -1, -1, 0, 0, 0, 0};
+
+    int32_t last = -1; // top node of the chain that reaches the root
+
+    if (kind == 0)
+    {
+        // ---- NNI: u any internal node, v its parent, swap one child of u with u's sister
+        const int32_t u = n + (int32_t)rng.below((uint32_t)(t.nb - n));
+        const bool swap_right = (rng.next() >> 63) != 0;
+        const int32_t v = t.parent[u], a = t.left[u], bb = t.right[u], c = t.sister(u);
+        const int32_t keep = swap_right ? a : bb, moved = swap_right ? bb : a;
+        pi.a = u;
+        pi.flag = swap_right ? 1 : 0;
+        // edits: v trades c for `moved`, u holds (keep, c)
+        e.edit(v, t.left[v] == c ? moved : t.left[v], t.left[v] == c ? t.right[v] : moved);
+        e.edit(u, keep, c);
+        // chain: u (keep, c), then v with `moved` as its clean child, then the old path above v
+        e.tok(keep, TOK_FRESH);
+        e.tok(c, 0);
+        e.dst(u);
+        last = u;
+        if (v != root)
+        {
+            e.tok(moved, 0);
+            e.dst(v);
+            last = v;
+            for (int32_t w = t.parent[v]; w != root; w = t.parent[w])
+            {
+                e.tok(t.left[w] == last ? t.right[w] : t.left[w], 0);
+                e.dst(w);
+                last = w;
+            }
+            e.tok(t.left[root] == last ? t.right[root] : t.left[root], 0);
+        }
+        else
+            e.tok(moved, 0); // the root's other child is now `moved`
+        e.dst(-1);
+        e.tok(root, 0);
+        e.dst(-1);
+    }
+    else
+    {
+        // ---- SPR / TBR: prune src (with its parent sp), graft on the edge above dest
+        // every draw loop is bounded: a tree with no admissible move must not hang the GPU
+        int32_t src, dest = -1;
+        int tries = 0;
+        do
+            src = (int32_t)rng.below((uint32_t)t.nb);
+        while ((src == root || src == t.left[root] || src == t.right[root]) && ++tries < 4096);
+        if (tries >= 4096)
+        {
+            e.overflow = true;
+            src = t.left[t.left[root] >= n ? t.left[root] : t.right[root]];
+        }
+        const int32_t sp = t.parent[src], ss = t.sister(src), pp = t.parent[sp];
+        for (tries = 0; tries < 65536; tries++)
+        {
+            dest = (int32_t)rng.below((uint32_t)t.nb);
+            if (dest == src || dest == sp || dest == ss || dest == root)
+                continue;
+            bool below = false; // dest inside src's subtree?
+            for (int32_t p = t.parent[dest]; p != UNSET; p = t.parent[p])
+                if (p == src)
+                {
+                    below = true;
+                    break;
+                }
+            if (!below)
+                break;
+        }
+        if (tries >= 65536)
+        {
+            // no admissible destination found: emit nothing usable
+            CandDesc none{};
+            none.tok_off = b * stride_t;
+            none.dst_off = b * stride_t;
+            cands[b] = none;
+            pi.overflow = 1;
+            info[b] = pi;
+            return;
+        }
+        const int32_t dp = t.parent[dest];
+        pi.a = src;
+        pi.b = dest;
+
+        int32_t buf1[MAX_PATH], buf2[MAX_PATH]; // root-ward paths (thread-private scratch)
+        int32_t top = src;   // what hangs under sp next to dest
+        bool have_acc = false; // a chain inside the moved subtree already feeds sp
+        if (kind == 2 && t.leaves[src] > 2)
+        {
+            // TBR: re-root the moved subtree on the edge above a random leaf x (not a child of src)
+            int32_t x;
+            int xt = 0;
+            do
+            {
+                x = src;
+                while (t.left[x] >= 0)
+                {
+                    const int32_t l = t.left[x];
+                    x = rng.below((uint32_t)t.leaves[x]) < (uint32_t)t.leaves[l] ? l : t.right[x];
+                }
+            } while ((x == t.left[src] || x == t.right[src]) && ++xt < 4096);
+            if (xt >= 4096)
+                e.overflow = true;
+            pi.c = x;
+            // path P0 = parent(x) .. Pk = src; walk it from the bottom to emit edits, then emit the
+            // chain from Pk upwards: Pk (other child, displaced(k-1)), Pi (displaced(i-1)), P0 (x)
+            int32_t *path = buf1;
+            int k = 0;
+            for (int32_t p = t.parent[x]; p != src && k < MAX_PATH - 1; p = t.parent[p])
+                path[k++] = p;
+            if (k >= MAX_PATH - 1)
+                e.overflow = true;
+            path[k] = src;
+            // displaced[i] = the child of Pi that is not P(i-1) (for i = 0: the sister of x)
+            // edits
+            int32_t displaced = t.sister(x);
+            e.edit(path[0], path[1], x);
+            for (int i = 1; i < k; i++)
+            {
+                const int32_t pi_ = path[i];
+                const int32_t other = (t.left[pi_] == path[i - 1]) ? t.right[pi_] : t.left[pi_];
+                e.edit(pi_, path[i + 1], displaced);
+                displaced = other;
+            }
+            {
+                const int32_t l = t.left[src], r = t.right[src];
+                e.edit(src, l == path[k - 1] ? displaced : l, l == path[k - 1] ? r : displaced);
+                // chain bottom: src's two (clean) children in the new topology
+                e.tok(l == path[k - 1] ? r : l, TOK_FRESH);
+                e.tok(displaced, 0);
+                e.dst(src);
+            }
+            // upwards: P(k-1) .. P1 each take the sister displaced from the node below them
+            for (int i = k - 1; i >= 1; i--)
+            {
+                // clean child of Pi in the new topology = displaced(i-1) = child of P(i-1) not on the path
+                const int32_t below_node = path[i - 1];
+                const int32_t dis = (i - 1 == 0) ? t.sister(x)
+                                                 : ((t.left[below_node] == path[i - 2]) ? t.right[below_node]
+                                                                                        : t.left[below_node]);
+                e.tok(dis, 0);
+                e.dst(path[i]);
+            }
+            e.tok(x, 0);
+            e.dst(path[0]);
+            top = path[0];
+            have_acc = true;
+        }
+        const SprView nv{t, sp, ss, pp, dp, dest, top};
+        // edits of the prune-and-graft (pp and dp may be the same node)
+        {
+            int32_t l, r;
+            if (pp == dp)
+            {
+                nv.children(pp, l, r);
+                e.edit(pp, l, r);
+            }
+            else
+            {
+                nv.children(pp, l, r);
+                e.edit(pp, l, r);
+                nv.children(dp, l, r);
+                e.edit(dp, l, r);
+            }
+            e.edit(sp, dest, top);
+        }
+        // path A: sp upwards in the new topology (excluding the root)
+        int32_t *pa = buf1; // the TBR path above is no longer needed (top is saved)
+        int na = 0;
+        for (int32_t v = sp; v != root && na < MAX_PATH; v = nv.parent(v))
+            pa[na++] = v;
+        if (na >= MAX_PATH)
+            e.overflow = true;
+        // path B: pp upwards until it meets A or the root
+        int32_t *pb = buf2;
+        int nbp = 0, meet_a = -1;
+        if (pp != root)
+        {
+            for (int32_t v = pp; v != root && nbp < MAX_PATH; v = nv.parent(v))
+            {
+                int hit = -1;
+                for (int i = 0; i < na; i++)
+                    if (pa[i] == v)
+                    {
+                        hit = i;
+                        break;
+                    }
+                if (hit >= 0)
+                {
+                    meet_a = hit;
+                    break;
+                }
+                pb[nbp++] = v;
+            }
+            if (nbp >= MAX_PATH)
+                e.overflow = true;
+        }
+        // chain below sp -> sp: sp's clean child is dest (its other child is `top`: clean for SPR,
+        // the accumulated chain for TBR)
+        auto chain_from_sp = [&](int upto) { // emits pa[0 .. upto)
+            if (upto <= 0)
+                return;
+            if (have_acc)
+                e.tok(dest, 0);
+            else
+            {
+                e.tok(dest, TOK_FRESH);
+                e.tok(top, 0);
+            }
+            e.dst(sp);
+            for (int i = 1; i < upto; i++)
+            {
+                e.tok(nv.other_child(pa[i], pa[i - 1]), 0);
+                e.dst(pa[i]);
+            }
+        };
+        if (nbp == 0)
+        {
+            // pp is the root, or pp already lies on A: one chain
+            chain_from_sp(na);
+            last = pa[na - 1];
+        }
+        else
+        {
+            // does B pass through sp (dest is pp or above it)?  then B continues as A: one chain from pp
+            bool b_has_sp = (meet_a == 0);
+            if (b_has_sp)
+            {
+                // B: pp (ss, other) ... up to the node below sp, then all of A with the chain as dirty child
+                int32_t l, r;
+                nv.children(pb[0], l, r);
+                uint32_t push = have_acc ? TOK_PUSH : 0u;
+                e.tok(l, TOK_FRESH | push);
+                e.tok(r, 0);
+                e.dst(pb[0]);
+                for (int i = 1; i < nbp; i++)
+                {
+                    e.tok(nv.other_child(pb[i], pb[i - 1]), 0);
+                    e.dst(pb[i]);
+                }
+                // sp: children (dest = top of B chain [dirty], top)
+                if (have_acc)
+                    e.merge(sp); // both children of sp are dirty: the subtree chain waits on the stack
+                else
+                {
+                    e.tok(top, 0);
+                    e.dst(sp);
+                }
+                for (int i = 1; i < na; i++)
+                {
+                    e.tok(nv.other_child(pa[i], pa[i - 1]), 0);
+                    e.dst(pa[i]);
+                }
+                last = pa[na - 1];
+            }
+            else
+            {
+                // two chains: A below the meeting node (or all of A if they only meet at the root), then B
+                const int a_len = meet_a >= 0 ? meet_a : na;
+                chain_from_sp(a_len);
+                int32_t l, r;
+                nv.children(pb[0], l, r);
+                e.tok(l, TOK_FRESH | TOK_PUSH);
+                e.tok(r, 0);
+                e.dst(pb[0]);
+                for (int i = 1; i < nbp; i++)
+                {
+                    e.tok(nv.other_child(pb[i], pb[i - 1]), 0);
+                    e.dst(pb[i]);
+                }
+                if (meet_a >= 0)
+                {
+                    e.merge(pa[meet_a]); // both children of the meeting node are dirty
+                    for (int i = meet_a + 1; i < na; i++)
+                    {
+                        e.tok(nv.other_child(pa[i], pa[i - 1]), 0);
+                        e.dst(pa[i]);
+                    }
+                    last = pa[na - 1];
+                }
+                else
+                {
+                    // the chains meet only at the root: its two children are both dirty
+                    e.merge(-1);
+                    last = -2; // root combine already emitted
+                }
+            }
+        }
+        if (last != -2)
+        {
+            e.tok(nv.other_child(root, last), 0);
+            e.dst(-1);
+        }
+        e.tok(root, 0);
+        e.dst(-1);
+    }
+
+    CandDesc cd{};
+    cd.tok_off = b * stride_t;
+    cd.ntok = e.ntok;
+    cd.dst_off = b * stride_t;
+    cd.ncomb = e.ndst;
+    cd.base = 0;
+    cd.flags = CAND_RESIDENT_BASE;
+    cd.nfresh = e.nfresh;
+    if (e.overflow)
+    {
+        // cannot be represented in the fixed strides: score it as the unchanged tree's root
+        // combine only and flag it, so the host never accepts it
+        cd.ntok = 0;
+        cd.ncomb = 0;
+        cd.nfresh = 0;
+    }
+    cands[b] = cd;
+    pi.n_edits = (int32_t)e.nedit;
+    pi.overflow = e.overflow ? 1 : 0;
+    pi.ncomb = (int32_t)e.ndst;
+    info[b] = pi;
+}
+
+hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
+                          uint64_t seed, uint32_t B,
+                          uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
+                          CandDesc *cands, ProposalInfo *info, hipStream_t stream)
+{
+    const int32_t nb = 2 * n - 3;
+    hipLaunchKernelGGL(propose_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, topo4, topo4 + nb, topo4 + 2 * nb,
+                       topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts, edits, cands, info);
+    return hipGetLastError();
+}
+
+} // namespace lvbgpu

@@ -23,7 +23,8 @@ class AnnealParams(C.Structure):
                 ("batch", C.c_int32), ("reroot_interval", C.c_int32), ("t0", C.c_double),
                 ("maxaccept", C.c_int64), ("maxpropose", C.c_int64), ("maxfail", C.c_int64),
                 ("min_len_tree", C.c_int64), ("max_proposals", C.c_int64), ("max_seconds", C.c_double),
-                ("max_device_steps", C.c_int64), ("sync_every", C.c_int32), ("log_cap", C.c_int32)]
+                ("max_device_steps", C.c_int64), ("sync_every", C.c_int32), ("log_cap", C.c_int32),
+                ("device_proposals", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AnnealResult(C.Structure):

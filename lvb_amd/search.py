@@ -13,8 +13,8 @@ import time
 from . import api, host
 
 
-def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 256, device: int = 0, out: str | None = "outtree",
-        max_seconds: float = 0.0, cooling: int = 0, verbose: bool = True) -> dict:
+def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 4096, device: int = 0, out: str | None = "outtree",
+        max_seconds: float = 0.0, cooling: int = 0, verbose: bool = True, device_proposals: int = 2) -> dict:
     t0 = time.perf_counter()
     names, rows = host.read_phylip(path)
     n, m_read = len(rows), len(rows[0])
@@ -32,6 +32,7 @@ def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 256, device: 
     p.min_len_tree = min_len
     p.max_seconds = max_seconds
     p.t0 = 0.0  # StartingTemperature()
+    p.device_proposals = int(device_proposals)
     p.log_cap = 4096
     res, log = host.anneal(ctx, tree, p)
     best = tree.best_trees()
@@ -65,12 +66,14 @@ def main(argv=None) -> int:
     ap.add_argument("-s", dest="seed", type=int, default=int(time.time()) % 900000000)
     ap.add_argument("-a", dest="algorithm", type=int, default=1)
     ap.add_argument("-c", dest="cooling", choices=["g", "l"], default="g")
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max-seconds", type=float, default=0.0)
+    ap.add_argument("--host-proposals", action="store_true", help="draw neighbours on the host instead of the GPU")
     a = ap.parse_args(argv)
     try:
-        run(a.infile, a.seed, a.algorithm, a.batch, a.device, a.out, a.max_seconds, 0 if a.cooling == "g" else 1)
+        run(a.infile, a.seed, a.algorithm, a.batch, a.device, a.out, a.max_seconds, 0 if a.cooling == "g" else 1,
+            device_proposals=0 if a.host_proposals else 2)
     except (api.LvbGpuError, ValueError, OSError) as exc:
         print(f"\nFATAL ERROR: {exc}")
         return 1

@@ -37,6 +37,7 @@ def test_lvbhost_exports_every_declared_symbol():
     assert declared == set(host.SIGNATURES), declared ^ set(host.SIGNATURES)
     p = host.anneal_defaults()
     assert (p.maxaccept, p.maxpropose, p.maxfail, p.reroot_interval) == (5, 2000, 40, 1000)
+    assert (p.batch, p.device_proposals) == (4096, 2)
 
 
 def test_adapter_exports_the_reference_mangled_getplen():

@@ -1,0 +1,105 @@
+"""Neighbourhoods drawn on the device (lvbgpu_propose_score): every candidate must be a move our
+host generators - themselves checked against the reference's mutate_* - can reproduce from the
+reported parameters, with identical edits, and its device-built program must give the length the
+host-built program gives."""
+import numpy as np
+import pytest
+
+from tests import helpers, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from lvb_amd import api, host
+    assert api.device_count() >= 1
+    return api, host
+
+
+def _replay(tree, info, api):
+    kind, a, b, c = (int(x) for x in info)
+    if kind == 0:
+        return tree.nni_edits(a, bool(b))
+    if kind == 1 or c < 0:
+        return tree.spr_edits(a, b)
+    return tree.tbr_edits(a, b, c)
+
+
+@pytest.mark.parametrize("n,m,B", [(7, 40, 256), (60, 3000, 768), (500, 50000, 1536)])
+def test_device_moves_replay_on_host_and_score_the_same(mods, n, m, B):
+    api, host = mods
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 41))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=43)
+    tree.upload(ctx)
+    for round_ in range(3):
+        for kind in (0, 1, 2, -1):
+            seed = 1000 * round_ + 17 * (kind + 2)
+            lens = ctx.propose_score(B, kind, seed)
+            assert np.array_equal(lens, ctx.propose_score(B, kind, seed))      # a function of (seed, b)
+            assert not np.array_equal(lens, ctx.propose_score(B, kind, seed + 1))
+            ctx.propose_score(B, kind, seed)                                    # make it the current batch again
+            assert (lens < np.iinfo(np.int64).max).all()                        # nothing overflowed at these sizes
+            step = 1 if B <= 256 else 7
+            cands, picked, kinds_seen = [], [], set()
+            for b in range(0, B, step):
+                edits, info = ctx.proposal_edits(b)
+                assert info[0] == (kind if kind >= 0 else b % 3)
+                assert helpers.edit_key(edits) == helpers.edit_key(_replay(tree, info, api)), (kind, b, info)
+                cands.append(edits)
+                picked.append(b)
+                kinds_seen.add((int(info[0]), int(info[3]) >= 0))
+            assert np.array_equal(ctx.score_batch(cands), lens[picked])        # host-built programs agree
+            if kind == 2 and n >= 60:
+                assert (2, True) in kinds_seen                                  # real TBR re-rootings occurred
+        # accept something and go on from the new tree
+        b = int(np.argmin(lens))
+        edits, _ = ctx.proposal_edits(b)
+        assert ctx.commit(edits) == lens[b]
+        with pytest.raises(api.LvbGpuError):                                    # the batch is stale now
+            ctx.proposal_edits(b)
+        tree.apply(edits)
+    ctx.close()
+
+
+def test_device_draws_cover_the_neighbourhood(mods):
+    """With enough draws every NNI of a small tree shows up, and SPR sources/destinations spread."""
+    api, host = mods
+    n = 9
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, 64, 5))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=6)
+    tree.upload(ctx)
+    B = 2048
+    ctx.propose_score(B, 0, 99)
+    seen = {tuple(int(x) for x in ctx.proposal_edits(b)[1][:3]) for b in range(B)}
+    assert len(seen) == 2 * (n - 3)                                             # every (u, side)
+    ctx.propose_score(B, 1, 99)
+    pairs = {tuple(int(x) for x in ctx.proposal_edits(b)[1][1:3]) for b in range(0, B, 2)}
+    assert len(pairs) > 40
+    ctx.close()
+
+
+def test_move_schedules_of_the_reference(mods):
+    """-a 0: NNI/SPR alternate by parity; -a 1: kinds drawn with the given probabilities."""
+    api, host = mods
+    n = 40
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, 500, 8))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=9)
+    tree.upload(ctx)
+    B = 1200
+    for parity in (0, 1):
+        ctx.propose_score_mixed(B, 0.0, 0.0, parity, 5)
+        kinds = [int(ctx.proposal_edits(b)[1][0]) for b in range(0, B, 3)]
+        assert kinds == [1 if (parity + b) & 1 else 0 for b in range(0, B, 3)]
+    ctx.propose_score_mixed(B, 0.2, 0.3, -1, 6)
+    kinds = np.array([int(ctx.proposal_edits(b)[1][0]) for b in range(B)])
+    frac = [(kinds == k).mean() for k in (0, 1, 2)]
+    assert abs(frac[0] - 0.2) < 0.05 and abs(frac[1] - 0.3) < 0.05 and abs(frac[2] - 0.5) < 0.05
+    ctx.propose_score_mixed(B, 0.0, 0.0, -1, 7)                                  # all TBR (t = t0)
+    assert all(int(ctx.proposal_edits(b)[1][0]) == 2 for b in range(0, B, 5))
+    with pytest.raises(api.LvbGpuError):
+        ctx.propose_score_mixed(B, 0.8, 0.5, -1, 7)
+    ctx.close()

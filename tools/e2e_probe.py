@@ -35,3 +35,13 @@ for B in (256, 1024, 4096, 16384):
     print(f"B={B}: propose {1e6*t_prop:.0f} us, batch_build(alloc+build+H2D) {1e6*t_build:.0f} us, "
           f"score_batch(build+H2D+kernel+D2H) {1e6*t_score:.0f} us -> {B/t_score/1e6:.2f} M/s e2e, "
           f"{B/(t_score+t_prop)/1e6:.2f} M/s incl. proposals")
+
+print("neighbourhoods drawn on the device (lvbgpu_propose_score: draw + program + score + D2H of lengths/info):")
+for B in (256, 1024, 4096, 16384, 65536):
+    reps = 20
+    ctx.propose_score(B, 1, 1)
+    t0 = time.perf_counter()
+    for r in range(reps):
+        ctx.propose_score(B, 1, 100 + r)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"B={B}: {1e6*dt:.0f} us/step -> {B/dt/1e6:.2f} M candidates/s end to end")

@@ -11,12 +11,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--taxa", type=int, default=500); ap.add_argument("--sites", type=int, default=50000)
 ap.add_argument("--batch", type=int, default=256); ap.add_argument("--seconds", type=float, default=5.0)
 ap.add_argument("--alg", type=int, default=0); ap.add_argument("--t0", type=float, default=0.0)
+ap.add_argument("--device-proposals", type=int, default=0)
 a = ap.parse_args()
 rows, minlen = host.prepare_alignment(synth.treelike_rows(a.taxa, a.sites, 3))
 ctx = api.FitchContext(text_rows=rows)
 tree = host.HostTree(a.taxa, seed=11)
 print("start length", tree.upload(ctx))
 p = host.anneal_defaults(); p.min_len_tree = minlen; p.batch = a.batch; p.algorithm = a.alg
+p.device_proposals = a.device_proposals
 t = time.perf_counter()
 if a.t0 <= 0:
     t0 = host.starting_temperature(ctx, tree, p)
