@@ -155,6 +155,24 @@ bool ProgramBuilder::apply(Topology &t, const Edit *edits, int32_t n_edits, int3
         undo_.push_back({U_PARENT, new_root, t.parent[new_root]});
         t.parent[new_root] = UNSET;
     }
+    // Local consistency, O(#edits): the edits must MOVE children, not duplicate or drop them.
+    //  - a child that got a new parent must have been released by its old one;
+    //  - a child released by an edited node must have been adopted by another edit.
+    for (const Undo &u : undo_)
+    {
+        if (u.kind == U_PARENT)
+        {
+            const int32_t c = u.idx, was = u.old, now = t.parent[c];
+            if (was >= 0 && was != now && (t.left[was] == c || t.right[was] == c))
+                return fail("node " + std::to_string(c) + " would have two parents");
+        }
+        else if (u.kind == U_LEFT || u.kind == U_RIGHT)
+        {
+            const int32_t v = u.idx, oc = u.old;
+            if (oc >= 0 && t.left[v] != oc && t.right[v] != oc && t.parent[oc] == v)
+                return fail("node " + std::to_string(oc) + " would be left without a parent");
+        }
+    }
     return true;
 }
 
