@@ -157,7 +157,10 @@ int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *left, con
                             const int32_t *roots, int64_t *lengths_out);
 
 /* Accept a candidate (SwapTrees after getplen, Solve.c:323/370): apply the edits to the
- * resident tree, recompute its dirty nodes' sets and per-node changes in place. */
+ * resident tree, recompute its dirty nodes' sets and per-node changes in place.
+ * length_out == NULL makes the commit asynchronous: it is only enqueued (ordered before any later
+ * call on this context) and nothing is read back - for callers that know the length already
+ * because they scored the candidate. */
 int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit *edits, int32_t root,
                   int64_t *length_out);
 

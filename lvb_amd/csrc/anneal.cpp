@@ -97,7 +97,9 @@ struct Chain
             const auto t0 = Clock::now();
             int rc = lvbgpu_proposal_edits(ctx, b, fetched.data(), (int32_t)fetched.size(), &ne, nullptr);
             if (rc == LVBGPU_OK)
-                rc = lvbgpu_commit(ctx, ne, fetched.data(), -1, len);
+                rc = lvbgpu_commit(ctx, ne, fetched.data(), -1, nullptr); // asynchronous: length known
+            if (rc == LVBGPU_OK)
+                *len = lens[b];
             dev_seconds += since(t0);
             if (rc == LVBGPU_OK)
                 rc = lvbhost_tree_apply(tree, fetched.data(), ne, -1);
@@ -106,7 +108,10 @@ struct Chain
         const Edit *e = edits.data() + offs[b];
         const int32_t ne = offs[b + 1] - offs[b];
         const auto t0 = Clock::now();
-        int rc = lvbgpu_commit(ctx, ne, reinterpret_cast<const lvbgpu_edit *>(e), -1, len);
+        // asynchronous: the candidate's length is already known from scoring it
+        int rc = lvbgpu_commit(ctx, ne, reinterpret_cast<const lvbgpu_edit *>(e), -1, nullptr);
+        if (rc == LVBGPU_OK)
+            *len = lens[b];
         dev_seconds += since(t0);
         if (rc == LVBGPU_OK)
             rc = lvbhost_tree_apply(tree, reinterpret_cast<const lvbgpu_edit *>(e), ne, -1);

@@ -149,7 +149,13 @@ struct lvbgpu_ctx
     Pool *pool = nullptr;
     std::vector<BuildWorker> workers;
 
-    DevBuf d_prog, d_len; // scratch for single-program launches (set_tree, commit)
+    DevBuf d_len; // length slot of single-program launches (set_tree, commit)
+    static constexpr int COMMIT_SLOTS = 4;
+    PinBuf h_commit[COMMIT_SLOTS]; // commit programs in flight (asynchronous commits)
+    DevBuf d_commit[COMMIT_SLOTS];
+    hipEvent_t commit_ev[COMMIT_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int commit_slot = 0;
+    bool cur_length_stale = false; // the device holds a newer length than cur_length
     DevBuf d_export;      // one row in nibble layout (lvbgpu_get_sets)
     lvbgpu_batch *step_batch = nullptr; // recycled by lvbgpu_score_batch
     lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
@@ -245,27 +251,6 @@ struct Packed
 };
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
-
-int upload_program(lvbgpu_ctx *ctx, DevBuf &dev, const std::vector<CandDesc> &cands,
-                   const std::vector<uint32_t> &toks, const std::vector<int32_t> &dsts, size_t *off_toks,
-                   size_t *off_dsts)
-{
-    const size_t o_t = align16(cands.size() * sizeof(CandDesc));
-    const size_t o_d = o_t + align16(toks.size() * 4);
-    const size_t total = o_d + align16(dsts.size() * 4);
-    HIPCHK(ctx, dev.reserve(total));
-    HIPCHK(ctx, ctx->h_pin.reserve(total));
-    char *h = (char *)ctx->h_pin.p;
-    memcpy(h, cands.data(), cands.size() * sizeof(CandDesc));
-    memcpy(h + o_t, toks.data(), toks.size() * 4);
-    memcpy(h + o_d, dsts.data(), dsts.size() * 4);
-    HIPCHK(ctx, hipMemcpyAsync(dev.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-    // h_pin is reused by the next upload: make sure the copy has left it
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *off_toks = o_t;
-    *off_dsts = o_d;
-    return LVBGPU_OK;
-}
 
 WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, size_t off_dsts, void *d_len,
                        uint32_t B, int32_t max_stack)
@@ -494,9 +479,15 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
             rb->ctx = nullptr;
             lvbgpu_batch_free(rb);
         }
-    ctx->d_prog.release();
     ctx->d_len.release();
     ctx->d_export.release();
+    for (int i = 0; i < lvbgpu_ctx::COMMIT_SLOTS; i++)
+    {
+        ctx->h_commit[i].release();
+        ctx->d_commit[i].release();
+        if (ctx->commit_ev[i])
+            (void)hipEventDestroy(ctx->commit_ev[i]);
+    }
     ctx->h_pin.release();
     ctx->d_cin.release();
     ctx->d_cout.release();
@@ -574,35 +565,63 @@ namespace
 {
 // run one stored-result program (full evaluation or commit) against the resident rows and
 // refresh S_all / current length.  `prog` holds node ids.
-int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all)
+// refresh cur_length from the device scalars (after an asynchronous commit)
+int read_current_length(lvbgpu_ctx *ctx)
+{
+    if (!ctx->cur_length_stale)
+        return LVBGPU_OK;
+    long long scal[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(scal, ctx->d_scalars, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cur_length = scal[1];
+    ctx->cur_length_stale = false;
+    return LVBGPU_OK;
+}
+
+// readback = false: everything is only enqueued (own pinned slot for the program, no
+// synchronisation); the caller already knows the length from scoring the candidate
+int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool readback)
 {
     int rc = check_depth(ctx, prog.max_stack);
     if (rc != LVBGPU_OK)
         return rc;
     Packed pk;
     pk.add(prog, 0, 0, 0, 0);
-    size_t o_t = 0, o_d = 0;
-    rc = upload_program(ctx, ctx->d_prog, pk.cands, prog.toks, prog.dsts, &o_t, &o_d);
-    if (rc != LVBGPU_OK)
-        return rc;
+    // the program goes through one of a few pinned slots, each guarded by an event, so the host
+    // never waits for the device here
+    const size_t o_t = align16(sizeof(CandDesc));
+    const size_t o_d = o_t + align16(prog.toks.size() * 4);
+    const size_t total = o_d + align16(prog.dsts.size() * 4);
+    const int slot = ctx->commit_slot;
+    ctx->commit_slot = (slot + 1) % lvbgpu_ctx::COMMIT_SLOTS;
+    if (!ctx->commit_ev[slot])
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->commit_ev[slot], hipEventDisableTiming));
+    else
+        HIPCHK(ctx, hipEventSynchronize(ctx->commit_ev[slot])); // long done unless 4 commits are in flight
+    HIPCHK(ctx, ctx->h_commit[slot].reserve(total));
+    HIPCHK(ctx, ctx->d_commit[slot].reserve(total));
+    char *h = (char *)ctx->h_commit[slot].p;
+    memcpy(h, pk.cands.data(), sizeof(CandDesc));
+    memcpy(h + o_t, prog.toks.data(), prog.toks.size() * 4);
+    memcpy(h + o_d, prog.dsts.data(), prog.dsts.size() * 4);
+    DevBuf &dprog = ctx->d_commit[slot];
+    HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
     HIPCHK(ctx, ctx->d_len.reserve(8));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
     if (zero_all)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
     else
     {
-        HIPCHK(ctx, launch_zero_changes(ctx->d_changes, (const int32_t *)((const char *)ctx->d_prog.p + o_d),
+        HIPCHK(ctx, launch_zero_changes(ctx->d_changes, (const int32_t *)((const char *)dprog.p + o_d),
                                         (uint32_t)prog.dsts.size(), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_changes + ctx->nb, 0, 8, ctx->stream));
     }
-    WalkArgs a = resident_args(ctx, ctx->d_prog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
+    WalkArgs a = resident_args(ctx, dprog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
-    long long scal[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(scal, ctx->d_scalars, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->cur_length = scal[1];
-    return LVBGPU_OK;
+    ctx->cur_length_stale = true;
+    return readback ? read_current_length(ctx) : LVBGPU_OK;
 }
 } // namespace
 
@@ -621,7 +640,7 @@ extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32
     ctx->have_tree = false;
     Program prog;
     ctx->pb.build_full(ctx->topo, prog);
-    int rc = run_commit_program(ctx, prog, true);
+    int rc = run_commit_program(ctx, prog, true, true);
     if (rc != LVBGPU_OK)
         return rc;
     ctx->have_tree = true;
@@ -638,6 +657,10 @@ extern "C" int lvbgpu_current_length(lvbgpu_ctx *ctx, int64_t *length_out)
         return LVBGPU_E_ARG;
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = read_current_length(ctx);
+    if (rc != LVBGPU_OK)
+        return rc;
     *length_out = ctx->cur_length;
     return LVBGPU_OK;
 }
@@ -1207,16 +1230,20 @@ extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit
     if (!ctx->pb.apply_edits(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, &why))
         return ctx->fail(LVBGPU_E_TOPOLOGY, why);
     ctx->topo_version++;
-    int rc = run_commit_program(ctx, prog, false);
+    // length_out == NULL: the caller knows the length (it scored this candidate): nothing is
+    // read back and nothing waits - the commit is ordered before later work on the stream
+    int rc = run_commit_program(ctx, prog, false, length_out != nullptr);
     if (rc != LVBGPU_OK)
     {
         ctx->have_tree = false; // resident state is no longer trustworthy
         return rc;
     }
     if (length_out)
+    {
         *length_out = ctx->cur_length;
-    if (ctx->cur_length <= 0)
-        return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+        if (ctx->cur_length <= 0)
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    }
     return LVBGPU_OK;
 }
 
