@@ -160,6 +160,58 @@ int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbh
 /* make `tree` resident in ctx (full evaluation) */
 int lvbhost_tree_upload(lvbgpu_ctx *ctx, const lvbhost_tree *tree, int64_t *length_out);
 
+/* ---- the reference's own trajectory on the device scorer ----------------
+ * Same seed and options as the reference program => same start trees, starting temperature,
+ * proposals, decisions, cooling, re-roots and treestack, hence the same "Rearrangements
+ * evaluated", "Tree score", "Topologies recovered" and output trees.  Pieces first (so each can be
+ * checked against the compiled reference on its own), then the whole search. */
+typedef struct lvbhost_refrng lvbhost_refrng; /* uni()/randpint(), RandomNumberGenerator.c:87-256 */
+int lvbhost_refrng_new(lvbhost_refrng **out, int32_t seed /* rinit: 0..900000000 */);
+void lvbhost_refrng_free(lvbhost_refrng *r);
+double lvbhost_refrng_uni(lvbhost_refrng *r);
+int64_t lvbhost_refrng_randpint(lvbhost_refrng *r, int64_t upper);
+/* PullRandomTree (TreeOperations.c:799-811): child arrays [2n-3] of a tree rooted at taxon 0 */
+int lvbhost_ref_random_tree(lvbhost_refrng *r, int32_t n, int32_t *left, int32_t *right);
+/* mutate_nni/spr/tbr (kind 0/1/2) of `tree` with the reference's draws, as edits */
+int lvbhost_ref_propose(const lvbhost_tree *tree, lvbhost_refrng *r, int kind, lvbgpu_edit *edits, int32_t cap,
+                        int32_t *n_edits);
+/* arbreroot (TreeOperations.c:639-656) as edits + the new root */
+int lvbhost_ref_arbreroot(const lvbhost_tree *tree, lvbhost_refrng *r, lvbgpu_edit *edits, int32_t cap,
+                          int32_t *n_edits, int32_t *new_root);
+
+typedef struct
+{
+    int32_t seed;             /* -s */
+    int32_t algorithm;        /* -a 0 | 1 | 2 (Solve.c:251-298, 452-466) */
+    int32_t cooling_schedule; /* -c g (0) | l (1) */
+    int32_t max_batch;        /* ceiling on proposals drawn ahead per device step (< 1000) */
+    int64_t min_len_tree;     /* MinimumTreeLength of the alignment */
+    int64_t max_trees;        /* -N: stop when the treestack holds this many (0 = keep all) */
+    int64_t maxaccept, maxpropose, maxfail; /* 5, 2000, 40 */
+    int64_t reserved[4];
+} lvbhost_refsearch_params;
+
+typedef struct
+{
+    double t0;                  /* "SA Starting Temperature" */
+    int64_t rearrangements;     /* "Rearrangements evaluated" (Anneal's iteration count) */
+    int64_t best_length;        /* "Tree score" */
+    int64_t trees;              /* "Topologies recovered" */
+    int64_t start_length, final_length;
+    int64_t accepted_moves, reroots, temperatures;
+    int64_t st_rearrangements;  /* proposals consumed by the starting-temperature search */
+    int64_t scored, device_steps;       /* candidates scored / lvbgpu_score_batch calls, overall */
+    int64_t st_scored, st_device_steps; /* ... of which while finding t0 */
+    double t_final, seconds, seconds_device;
+} lvbhost_refsearch_result;
+
+void lvbhost_refsearch_defaults(lvbhost_refsearch_params *p);
+/* ctx holds the alignment (constant columns already cut).  *tree_out receives a new tree handle
+ * (free with lvbhost_tree_free) holding the final tree and, as its kept best trees in treestack
+ * order (lvbhost_tree_best_get), the trees the reference would print. */
+int lvbhost_reference_search(lvbgpu_ctx *ctx, const lvbhost_refsearch_params *params, lvbhost_refsearch_result *result,
+                             lvbhost_tree **tree_out);
+
 #ifdef __cplusplus
 }
 #endif

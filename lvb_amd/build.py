@@ -23,7 +23,7 @@ ARCH = "gfx950"
 GPU_SOURCES = ["fitch_kernels.hip", "propose_kernels.hip", "lvbgpu_api.cpp", "program.cpp"]
 GPU_HEADERS = ["kernels.hpp", "program.hpp", "pool.hpp"]
 COMPAT_SOURCES = ["getplen_adapter.cpp"]
-HOST_SOURCES = ["host_api.cpp", "proposals.cpp", "anneal.cpp", "program.cpp"]
+HOST_SOURCES = ["host_api.cpp", "proposals.cpp", "anneal.cpp", "refsearch.cpp", "program.cpp"]
 HOST_HEADERS = ["program.hpp", "proposals.hpp", "host_tree.hpp"]
 
 

@@ -72,6 +72,20 @@ bool is_descendant(const Topology &t, int32_t ancestor, int32_t v)
     return false;
 }
 
+// prune src (with its parent sp) and graft it on the edge above dest; `top` is what hangs under
+// the re-used node sp next to dest (src itself for SPR, the new subtree top for TBR)
+void prune_and_graft(const Topology &t, Overlay &ov, int32_t src, int32_t dest, int32_t top)
+{
+    const int32_t sp = t.parent[src];
+    const int32_t ss = sister_of(t, src);
+    const int32_t pp = t.parent[sp];
+    ov.replace_child(pp, sp, ss);               // free the pruned parent (TreeOperations.c:287-299)
+    ov.replace_child(t.parent[dest], dest, sp); // make room above dest   (301-316)
+    ov.set(sp, dest, top);                      // (317-324)
+}
+
+} // namespace
+
 void subtree_leaves(const Topology &t, int32_t top, std::vector<int32_t> &leaves)
 {
     std::vector<int32_t> st{top};
@@ -88,20 +102,6 @@ void subtree_leaves(const Topology &t, int32_t top, std::vector<int32_t> &leaves
         }
     }
 }
-
-// prune src (with its parent sp) and graft it on the edge above dest; `top` is what hangs under
-// the re-used node sp next to dest (src itself for SPR, the new subtree top for TBR)
-void prune_and_graft(const Topology &t, Overlay &ov, int32_t src, int32_t dest, int32_t top)
-{
-    const int32_t sp = t.parent[src];
-    const int32_t ss = sister_of(t, src);
-    const int32_t pp = t.parent[sp];
-    ov.replace_child(pp, sp, ss);               // free the pruned parent (TreeOperations.c:287-299)
-    ov.replace_child(t.parent[dest], dest, sp); // make room above dest   (301-316)
-    ov.set(sp, dest, top);                      // (317-324)
-}
-
-} // namespace
 
 bool spr_move_allowed(const Topology &t, int32_t src, int32_t dest)
 {

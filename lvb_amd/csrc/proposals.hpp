@@ -53,6 +53,8 @@ int nni_edits(const Topology &t, int32_t u, bool swap_right, std::vector<Edit> &
 int spr_edits(const Topology &t, int32_t src, int32_t dest, std::vector<Edit> &out);
 int tbr_edits(const Topology &t, int32_t src, int32_t dest, int32_t newroot_leaf, std::vector<Edit> &out);
 bool spr_move_allowed(const Topology &t, int32_t src, int32_t dest);
+// leaves under `top`, left before right (the order of the reference's addtoarray, TreeOperations.c:560-574)
+void subtree_leaves(const Topology &t, int32_t top, std::vector<int32_t> &leaves);
 
 // edits that re-root the tree at leaf `newroot` (old root leaf ends with children (-1,-1))
 int reroot_edits(const Topology &t, int32_t newroot, std::vector<Edit> &out);

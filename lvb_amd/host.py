@@ -36,6 +36,22 @@ class AnnealResult(C.Structure):
                 ("frozen", C.c_int32)]
 
 
+class RefSearchParams(C.Structure):
+    _fields_ = [("seed", C.c_int32), ("algorithm", C.c_int32), ("cooling_schedule", C.c_int32),
+                ("max_batch", C.c_int32), ("min_len_tree", C.c_int64), ("max_trees", C.c_int64),
+                ("maxaccept", C.c_int64), ("maxpropose", C.c_int64), ("maxfail", C.c_int64),
+                ("reserved", C.c_int64 * 4)]
+
+
+class RefSearchResult(C.Structure):
+    _fields_ = [("t0", C.c_double), ("rearrangements", C.c_int64), ("best_length", C.c_int64), ("trees", C.c_int64),
+                ("start_length", C.c_int64), ("final_length", C.c_int64), ("accepted_moves", C.c_int64),
+                ("reroots", C.c_int64), ("temperatures", C.c_int64), ("st_rearrangements", C.c_int64),
+                ("scored", C.c_int64), ("device_steps", C.c_int64), ("st_scored", C.c_int64),
+                ("st_device_steps", C.c_int64), ("t_final", C.c_double), ("seconds", C.c_double),
+                ("seconds_device", C.c_double)]
+
+
 SIGNATURES = {
     "lvbhost_tree_random": (C.c_void_p, [C.c_int32, C.c_uint64]),
     "lvbhost_tree_from_arrays": (C.c_void_p, [C.c_int32, _i32p, _i32p, C.c_int32, C.c_uint64]),
@@ -73,6 +89,17 @@ SIGNATURES = {
     "lvbhost_starting_temperature": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AnnealParams),
                                                C.POINTER(C.c_double)]),
     "lvbhost_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "lvbhost_refrng_new": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32]),
+    "lvbhost_refrng_free": (None, [C.c_void_p]),
+    "lvbhost_refrng_uni": (C.c_double, [C.c_void_p]),
+    "lvbhost_refrng_randpint": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "lvbhost_ref_random_tree": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
+    "lvbhost_ref_propose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lvbhost_ref_arbreroot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]),
+    "lvbhost_refsearch_defaults": (None, [C.POINTER(RefSearchParams)]),
+    "lvbhost_reference_search": (C.c_int, [C.c_void_p, C.POINTER(RefSearchParams), C.POINTER(RefSearchResult),
+                                           C.POINTER(C.c_void_p)]),
 }
 
 _lib = None
@@ -85,12 +112,16 @@ def load_library() -> C.CDLL:
     api.load_library()  # liblvbhost links liblvbgpu: make the failure message the useful one
     if not LIB_PATH.exists():
         raise api.LvbGpuError(-2, f"{LIB_PATH} is not built (run `python -m lvb_amd.build`)")
-    lib = C.CDLL(str(LIB_PATH))
+    _lib = bind(C.CDLL(str(LIB_PATH)))
+    return _lib
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Declare include/lvbhost.h's signatures on a loaded library."""
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
 
 
@@ -104,9 +135,12 @@ TOK_PUSH = 1 << 31
 class HostTree:
     """Topology + random stream (lvbhost_tree)."""
 
-    def __init__(self, n: int | None = None, *, seed: int = 1, left=None, right=None, root: int = 0):
-        self.lib = load_library()
-        if left is not None:
+    def __init__(self, n: int | None = None, *, seed: int = 1, left=None, right=None, root: int = 0, handle=None,
+                 lib=None):
+        self.lib = lib or load_library()
+        if handle is not None:  # adopt a tree the library made (lvbhost_reference_search)
+            self.h = handle
+        elif left is not None:
             l = np.ascontiguousarray(left, dtype=np.int32)
             r = np.ascontiguousarray(right, dtype=np.int32)
             n = (len(l) + 3) // 2
@@ -212,8 +246,27 @@ class HostTree:
             r = np.zeros(self.nbranches, dtype=np.int32)
             root = C.c_int32()
             self.lib.lvbhost_tree_best_get(self.h, i, l, r, C.byref(root))
-            out.append(HostTree(left=l, right=r, root=root.value))
+            out.append(HostTree(left=l, right=r, root=root.value, lib=self.lib))
         return out
+
+    def ref_propose(self, rng: "RefRng", kind: int) -> np.ndarray:
+        """mutate_nni/spr/tbr with the reference's own draws, as edits."""
+        cap = 2 * self.nbranches + 8
+        buf = np.zeros(cap, dtype=api.EDIT_DTYPE)
+        k = C.c_int32()
+        rc = self.lib.lvbhost_ref_propose(self.h, rng.h, int(kind), buf.ctypes.data, cap, C.byref(k))
+        if rc != 0:
+            raise api.LvbGpuError(rc, "ref_propose")
+        return buf[: k.value].copy()
+
+    def ref_arbreroot(self, rng: "RefRng") -> tuple[np.ndarray, int]:
+        cap = 2 * self.nbranches + 8
+        buf = np.zeros(cap, dtype=api.EDIT_DTYPE)
+        k, nr = C.c_int32(), C.c_int32()
+        rc = self.lib.lvbhost_ref_arbreroot(self.h, rng.h, buf.ctypes.data, cap, C.byref(k), C.byref(nr))
+        if rc != 0:
+            raise api.LvbGpuError(rc, "ref_arbreroot")
+        return buf[: k.value].copy(), nr.value
 
     def topology_hash(self) -> int:
         return int(self.lib.lvbhost_tree_topology_hash(self.h))
@@ -225,6 +278,62 @@ class HostTree:
         out = C.c_int64()
         ctx._chk(self.lib.lvbhost_tree_upload(ctx.h, self.h, C.byref(out)))
         return out.value
+
+
+class RefRng:
+    """The reference's uni()/randpint() stream (RandomNumberGenerator.c), seeded as rinit() does."""
+
+    def __init__(self, seed: int, lib=None):
+        self.lib = lib or load_library()
+        h = C.c_void_p()
+        rc = self.lib.lvbhost_refrng_new(C.byref(h), int(seed))
+        if rc != 0:
+            raise api.LvbGpuError(rc, f"seed {seed} is outside 0..900000000")
+        self.h = h
+
+    def uni(self) -> float:
+        return float(self.lib.lvbhost_refrng_uni(self.h))
+
+    def randpint(self, upper: int) -> int:
+        return int(self.lib.lvbhost_refrng_randpint(self.h, int(upper)))
+
+    def random_tree(self, n: int) -> "HostTree":
+        """PullRandomTree: rooted at taxon 0."""
+        l = np.zeros(2 * n - 3, dtype=np.int32)
+        r = np.zeros(2 * n - 3, dtype=np.int32)
+        rc = self.lib.lvbhost_ref_random_tree(self.h, int(n), l, r)
+        if rc != 0:
+            raise api.LvbGpuError(rc, "ref_random_tree")
+        return HostTree(left=l, right=r, root=0, lib=self.lib)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lvbhost_refrng_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def refsearch_defaults(lib=None) -> RefSearchParams:
+    p = RefSearchParams()
+    (lib or load_library()).lvbhost_refsearch_defaults(C.byref(p))
+    return p
+
+
+def reference_search(ctx_handle, params: RefSearchParams, lib=None) -> tuple[dict, "HostTree"]:
+    """The reference's own trajectory on the device scorer -> (result dict, tree holding the
+    final tree and, as best_trees(), the treestack in the reference's order)."""
+    lib = lib or load_library()
+    res = RefSearchResult()
+    h = C.c_void_p()
+    rc = lib.lvbhost_reference_search(ctx_handle, C.byref(params), C.byref(res), C.byref(h))
+    if rc != 0:
+        raise api.LvbGpuError(rc, "reference_search")
+    return {k: getattr(res, k) for k, _ in RefSearchResult._fields_}, HostTree(handle=h, lib=lib)
 
 
 def anneal_defaults() -> AnnealParams:
@@ -288,7 +397,7 @@ def read_phylip(path) -> tuple[list[bytes], list[bytes]]:
 
 def newick(tree: "HostTree", names: list[bytes]) -> str:
     """One line, the reference's unrooted bracket form (ur_print)."""
-    lib = load_library()
+    lib = tree.lib
     arr = (C.c_char_p * len(names))(*names)
     cap = sum(len(x) + 4 for x in names) * 2 + 64
     buf = C.create_string_buffer(cap)

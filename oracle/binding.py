@@ -231,6 +231,10 @@ def load_ref():
     lib.refh_enc_row.argtypes = [vp, C.c_long, _u64p]
     lib.refh_reseed.argtypes = [vp, C.c_int]
     lib.refh_random_tree.argtypes = [vp]
+    lib.refh_uni.restype = C.c_double
+    lib.refh_uni.argtypes = []
+    lib.refh_randpint.restype = C.c_long
+    lib.refh_randpint.argtypes = [C.c_long]
     lib.refh_root.restype = C.c_long
     lib.refh_root.argtypes = [vp, C.c_int]
     lib.refh_getplen.restype = C.c_long
@@ -330,6 +334,12 @@ class RefRun:
 
     def random_tree(self) -> None:
         self.lib.refh_random_tree(self.h)
+
+    def uni(self) -> float:
+        return float(self.lib.refh_uni())
+
+    def randpint(self, upper: int) -> int:
+        return int(self.lib.refh_randpint(int(upper)))
 
     def root(self, which: int = 0) -> int:
         return int(self.lib.refh_root(self.h, which))

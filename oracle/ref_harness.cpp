@@ -171,6 +171,10 @@ void refh_reseed(void *vh, int seed)
     rinit(seed);
 }
 
+/* the global random stream itself (RandomNumberGenerator.c:87, 235) */
+double refh_uni(void) { return uni(); }
+long refh_randpint(long upper) { return randpint(upper); }
+
 /* new random start tree into slot 0 (Solve.c:543-544) */
 void refh_random_tree(void *vh)
 {
