@@ -3,6 +3,13 @@ the best trees.  Mirrors the reference program's flow (Main.c:60-155) and result
 host (batched SA over the device scorer); it is a convenience around the library, not a port of the CLI.
 
   python -m lvb_amd.search -i alignment.phy [-s seed] [-a 0|1] [-o outtree] [--batch B] [--device D]
+  python -m lvb_amd.search -i alignment.phy -s seed --exact     # the reference's own trajectory (-a 0|1|2)
+
+--exact reproduces the reference program decision for decision (same random stream, start trees,
+proposals, cooling, treestack: lvb_amd/csrc/refsearch.cpp), so "Rearrangements evaluated", "Tree score",
+"Topologies recovered" and the output trees are the reference's for that seed.  Without it the search
+is the batched one (lvb_amd/csrc/anneal.cpp): same algorithm and statistics, its own random stream,
+far more candidates per second.
 """
 from __future__ import annotations
 
@@ -59,6 +66,47 @@ def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 4096, device:
     return res
 
 
+def run_exact(path: str, seed: int, algorithm: int = 1, cooling: int = 0, device: int = 0, out: str | None = "outtree",
+              verbose: bool = True, max_batch: int = 0, max_trees: int = 0) -> dict:
+    """The reference's trajectory for this seed on the device scorer (Main.c:60-155 flow)."""
+    t0 = time.perf_counter()
+    names, rows = host.read_phylip(path)
+    n, m_read = len(rows), len(rows[0])
+    if n < 5:
+        raise ValueError("The data matrix must have at least 5 sequences.")
+    rows, min_len = host.prepare_alignment(rows)
+    ctx = api.FitchContext(text_rows=rows, device=device)
+    p = host.refsearch_defaults()
+    p.seed, p.algorithm, p.cooling_schedule, p.min_len_tree, p.max_trees = seed, algorithm, cooling, min_len, max_trees
+    if max_batch:
+        p.max_batch = max_batch
+    res, tree = host.reference_search(ctx.h, p)
+    best = tree.best_trees()
+    if out:
+        with open(out, "w") as f:
+            for t in best:
+                if t.root != 0:  # PrintTreestack re-roots at the first taxon (Treestack.c:402-403)
+                    t.apply(t.reroot_edits(0), 0)
+                f.write(host.newick(t, names))
+    res.update(taxa=n, sites_read=m_read, sites_used=len(rows[0]), min_len_tree=min_len,
+               wall_seconds=time.perf_counter() - t0, outtree=out)
+    if verbose:
+        ci = min_len / res["best_length"]
+        print(f"  SA Starting Temperature: {res['t0']:.8f}")
+        print("\nSearch Results:")
+        print(f"  Rearrangements evaluated: {res['rearrangements']}")
+        print(f"  Topologies recovered:     {res['trees']}")
+        print(f"  Tree score:               {res['best_length']}")
+        print(f"  Consistency index:        {ci:.2f}")
+        print(f"  Homoplasy index:          {1 - ci:.2f}")
+        print(f"  Total runtime (seconds):  {res['wall_seconds']:.2f}")
+        if out:
+            print(f"\nAll topologies written to '{out}'")
+    tree.close()
+    ctx.close()
+    return res
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="python -m lvb_amd.search")
     ap.add_argument("-i", dest="infile", default="infile")
@@ -70,8 +118,14 @@ def main(argv=None) -> int:
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--host-proposals", action="store_true", help="draw neighbours on the host instead of the GPU")
+    ap.add_argument("--exact", action="store_true", help="reproduce the reference program's run for this seed")
+    ap.add_argument("-N", dest="max_trees", type=int, default=0)
     a = ap.parse_args(argv)
     try:
+        if a.exact:
+            run_exact(a.infile, a.seed, a.algorithm, 0 if a.cooling == "g" else 1, a.device, a.out,
+                      max_trees=max(a.max_trees, 0))
+            return 0
         run(a.infile, a.seed, a.algorithm, a.batch, a.device, a.out, a.max_seconds, 0 if a.cooling == "g" else 1,
             device_proposals=0 if a.host_proposals else 2)
     except (api.LvbGpuError, ValueError, OSError) as exc:
