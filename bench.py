@@ -170,7 +170,7 @@ def main():
     kind = MOVES[args.move]
     t_setup = time.perf_counter()
     rows, min_len = host.prepare_alignment(synth_rows(args.taxa, args.sites, args.seed, args.dist))
-    ctx = api.FitchContext(text_rows=rows, device=local_rank)      # encode on the device
+    ctx = api.FitchContext(text_rows=rows, device=ranks.device)    # encode on the device
     tree = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed))  # each rank: its own restart
     length = tree.upload(ctx)
     for _ in range(args.walk):                                      # short random walk, as BASELINE.md

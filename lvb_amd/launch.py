@@ -17,6 +17,12 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.backend = None
+        self.device = self.local_rank  # the GPU this rank scores on
+        # rehearsal of the N-rank flow on a box with ONE GPU: every rank shares device 0 and the
+        # plumbing runs over gloo (RCCL refuses two ranks on one device).  Never set on a real node.
+        if os.environ.get("LVBGPU_REHEARSE_ON_ONE_GPU"):
+            backend = backend or "gloo"
+            self.device = 0
         if self.world > 1:
             import torch
             import torch.distributed as dist
