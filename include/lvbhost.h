@@ -68,6 +68,10 @@ typedef struct lvbhost_alignment lvbhost_alignment;
 /* PHYLIP, sequential or interleaved: header "n m", 10-character name field, digits and blanks
  * inside sequences ignored, text upper-cased (MSAInput.cpp:829).  NULL + message on error. */
 lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, char *err, int32_t errcap);
+/* any of the reference's four input formats (-f; DataStructure.h:50-53: 0 phylip, 1 fasta, 2 nexus,
+ * 3 clustal; MSAInput.cpp:141-217, 274-432, 546-579, 594-695) followed by the checks read_file applies
+ * to all of them (737-849: at least two sequences, equal lengths, upper case, accepted characters) */
+lvbhost_alignment *lvbhost_alignment_read(const char *path, int format, char *err, int32_t errcap);
 void lvbhost_alignment_free(lvbhost_alignment *a);
 int64_t lvbhost_alignment_n(const lvbhost_alignment *a);
 int64_t lvbhost_alignment_m(const lvbhost_alignment *a);

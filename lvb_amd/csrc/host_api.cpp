@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <new>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -440,6 +441,315 @@ extern "C" lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, ch
         return fail(msg);
     }
     a->m = m;
+    return a;
+}
+
+// ---- the other three input formats (reference MSAInput.cpp: read_fasta 546-579, read_nexus
+// 594-695, read_clustal 141-217) and the checks every format goes through (read_file 737-849)
+
+namespace
+{
+// trim as the reference's reader does: newline, carriage return and blank, in that order, each
+// stripped from both ends once (MSAInput.cpp:49-57, 102-119)
+std::string ref_trim(std::string s)
+{
+    for (char c : {'\n', '\r', '\n', ' '})
+    {
+        const size_t first = s.find_first_not_of(c);
+        if (first == std::string::npos)
+            return "";
+        s = s.substr(first, s.find_last_not_of(c) - first + 1);
+    }
+    return s;
+}
+// blank-separated fields, empty ones kept (consecutive blanks), none after a trailing blank
+std::vector<std::string> fields_of(const std::string &line)
+{
+    std::vector<std::string> out;
+    std::stringstream ss(line);
+    std::string item;
+    while (std::getline(ss, item, ' '))
+        out.push_back(item);
+    return out;
+}
+int nonempty_fields(const std::vector<std::string> &f)
+{
+    int k = 0;
+    for (const auto &x : f)
+        k += !x.empty();
+    return k;
+}
+// last non-empty field = the sequence chunk; the non-empty fields before it, blank-joined = the name
+std::string last_field(const std::vector<std::string> &f)
+{
+    for (size_t i = f.size(); i-- > 0;)
+        if (!f[i].empty())
+            return f[i];
+    return "";
+}
+std::string name_fields(const std::vector<std::string> &f)
+{
+    size_t last = f.size();
+    for (size_t i = f.size(); i-- > 0;)
+        if (!f[i].empty())
+        {
+            last = i;
+            break;
+        }
+    std::string out;
+    for (size_t i = 0; i < last && last != f.size(); i++)
+        if (!f[i].empty())
+        {
+            if (!out.empty())
+                out += " ";
+            out += f[i];
+        }
+    return out;
+}
+
+bool read_fasta(std::ifstream &in, lvbhost_alignment &a, std::string &)
+{
+    std::string line;
+    long current = -1;
+    while (std::getline(in, line))
+    {
+        line = ref_trim(line);
+        if (line.empty())
+            continue;
+        if (line[0] == '>')
+        {
+            a.names.push_back(line.substr(1));
+            current++;
+        }
+        else if (current == (long)a.rows.size())
+            a.rows.push_back(line);
+        else if (current >= 0 && current < (long)a.rows.size())
+            a.rows[(size_t)current] += line;
+        // sequence text before the first '>' has nowhere to go (the reference indexes out of range there)
+    }
+    return true;
+}
+
+bool read_nexus(std::ifstream &in, lvbhost_alignment &a, std::string &why)
+{
+    int nseq = 0, nchar = 0;
+    bool reading = false, names_done = false;
+    int cursor = 0;
+    std::string line;
+    while (std::getline(in, line))
+    {
+        line = ref_trim(line);
+        if (line.empty())
+            continue;
+        if (line.find("dimensions") != std::string::npos)
+        {
+            nseq = nchar = 0;
+            // lower-case keywords, taxa first; the reference's second pattern (characters first)
+            // stores its two numbers the same way round, so such a file fails the count check below
+            if (sscanf(line.c_str(), "dimensions ntax=%d nchar=%d;", &nseq, &nchar) == 0)
+                sscanf(line.c_str(), "dimensions nchar=%d ntax=%d;", &nseq, &nchar);
+            if (nseq == 0 || nchar == 0)
+            {
+                why = "Wans't possible to get the dimensions of the matrix.\nLine: " + line;
+                return false;
+            }
+        }
+        if (line.find("matrix") != std::string::npos)
+        {
+            reading = true;
+            continue;
+        }
+        if (!reading)
+            continue;
+        if (line.find(";") != std::string::npos)
+        {
+            reading = false;
+            continue;
+        }
+        const std::vector<std::string> f = fields_of(line);
+        if (f.empty())
+            continue;
+        if (!names_done)
+        {
+            if (f.size() > 1)
+            {
+                a.names.push_back(name_fields(f));
+                a.rows.push_back(last_field(f));
+            }
+            if ((int)a.names.size() == nseq)
+                names_done = true;
+        }
+        else
+        {
+            if (cursor >= (int)a.rows.size())
+            {
+                why = "Some problem reading the file.";
+                return false;
+            }
+            a.rows[(size_t)cursor++] += last_field(f);
+            if (cursor == nseq)
+                cursor = 0;
+        }
+    }
+    if (nseq == 0)
+    {
+        why = "Some problem reading the file. Please, check the file format.";
+        return false;
+    }
+    if ((int)a.names.size() != nseq)
+    {
+        why = "The file has a different number of sequences.\nRead: " + std::to_string(a.names.size()) +
+              "\nIn the header: " + std::to_string(nseq);
+        return false;
+    }
+    for (size_t i = 0; i < a.rows.size(); i++)
+        if ((int)a.rows[i].size() != nchar)
+        {
+            why = "This sequence " + a.names[i] + " has a different length " + std::to_string(a.rows[i].size()) +
+                  " from the one read in the header: " + std::to_string(nchar);
+            return false;
+        }
+    return true;
+}
+
+bool read_clustal(std::ifstream &in, lvbhost_alignment &a, std::string &why)
+{
+    bool header = false, first_block_done = false;
+    int cursor = 0;
+    std::string line;
+    while (std::getline(in, line))
+    {
+        if (!header)
+        {
+            if (line.size() > 1)
+            {
+                if (line.find("CLUSTAL") != std::string::npos)
+                    header = true;
+                continue;
+            }
+        }
+        else if (!line.empty())
+        {
+            const std::vector<std::string> f = fields_of(line);
+            if (f.empty())
+                continue;
+            if (nonempty_fields(f) == 1 || f[0].empty()) // the conservation line under a block
+            {
+                if (!first_block_done)
+                {
+                    first_block_done = true;
+                    continue;
+                }
+                if (cursor == (int)a.names.size())
+                {
+                    cursor = 0;
+                    continue;
+                }
+            }
+            if (!first_block_done)
+            {
+                if (f.size() > 1)
+                {
+                    a.names.push_back(name_fields(f));
+                    a.rows.push_back(last_field(f));
+                }
+            }
+            else
+            {
+                if (cursor >= (int)a.rows.size())
+                {
+                    why = "Some problem reading the file.";
+                    return false;
+                }
+                a.rows[(size_t)cursor++] += last_field(f);
+            }
+            continue;
+        }
+        // blank line (or a one-character line before the header): a block ended
+        cursor = 0;
+        if (!a.names.empty())
+            first_block_done = true;
+    }
+    return true;
+}
+
+// read_file's checks after any format (MSAInput.cpp:780-849)
+bool check_alignment(lvbhost_alignment &a, const std::string &path, std::string &why)
+{
+    if (a.rows.size() < 2)
+    {
+        why = (a.rows.empty() ? "Zero sequences were read from the file: " : "Only one sequence was read from the file: ") + path;
+        return false;
+    }
+    if (a.rows.size() != a.names.size())
+    {
+        why = "Something wrong with the file.\nThe number of sequences names are different from the number of "
+              "sequences in the file: " + path;
+        return false;
+    }
+    for (size_t i = 1; i < a.rows.size(); i++)
+        if (a.rows[i].size() != a.rows[0].size())
+        {
+            why = "Something wrong with the file.\nThe sequence lengths are different in the file: " + path;
+            return false;
+        }
+    static const std::string accepted = "ACGTUYRWSKMBDHVNX?O-";
+    for (size_t i = 0; i < a.rows.size(); i++)
+    {
+        for (char &c : a.rows[i])
+            c = (char)toupper((unsigned char)c);
+        for (char c : a.rows[i])
+            if (accepted.find(c) == std::string::npos)
+            {
+                why = std::string("This char is not allowed (") + c + ")\nThe char is in this line: " + a.names[i] + ": " +
+                      a.rows[i] + "\n";
+                return false;
+            }
+    }
+    a.m = (int64_t)a.rows[0].size();
+    return true;
+}
+} // namespace
+
+extern "C" lvbhost_alignment *lvbhost_alignment_read(const char *path, int format, char *err, int32_t errcap)
+{
+    auto fail = [&](const std::string &msg) -> lvbhost_alignment * {
+        if (err && errcap > 0)
+            snprintf(err, (size_t)errcap, "%s", msg.c_str());
+        return nullptr;
+    };
+    if (!path)
+        return fail("no file name");
+    if (format < 0 || format > 3)
+        return fail(std::string("Unrecognized file...") + path);
+    lvbhost_alignment *a = nullptr;
+    std::string why;
+    if (format == 0)
+    {
+        a = lvbhost_alignment_read_phylip(path, err, errcap);
+        if (!a)
+            return nullptr;
+    }
+    else
+    {
+        std::ifstream in(path);
+        if (!in)
+            return fail(std::string("Failed to open alignment file: ") + path);
+        a = new (std::nothrow) lvbhost_alignment();
+        if (!a)
+            return fail("out of memory");
+        const bool ok = format == 1 ? read_fasta(in, *a, why) : (format == 2 ? read_nexus(in, *a, why) : read_clustal(in, *a, why));
+        if (!ok)
+        {
+            delete a;
+            return fail(why);
+        }
+    }
+    if (!check_alignment(*a, path, why))
+    {
+        delete a;
+        return fail(why);
+    }
     return a;
 }
 

@@ -75,6 +75,7 @@ SIGNATURES = {
                                   C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lvbhost_alignment_read_phylip": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int32]),
+    "lvbhost_alignment_read": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p, C.c_int32]),
     "lvbhost_alignment_free": (None, [C.c_void_p]),
     "lvbhost_alignment_n": (C.c_int64, [C.c_void_p]),
     "lvbhost_alignment_m": (C.c_int64, [C.c_void_p]),
@@ -380,19 +381,27 @@ def prepare_alignment(rows: list[bytes]) -> tuple[list[bytes], int]:
     return rows, int(lib.lvbhost_min_tree_length(n, int(kept), arr))
 
 
-def read_phylip(path) -> tuple[list[bytes], list[bytes]]:
-    """PHYLIP alignment -> (names, rows): what the reference's reader hands to matchange."""
+FORMATS = {"phylip": 0, "fasta": 1, "nexus": 2, "clustal": 3}  # the reference's -f (DataStructure.h:50-53)
+
+
+def read_alignment(path, fmt: str | int = "phylip") -> tuple[list[bytes], list[bytes]]:
+    """Alignment file -> (names, rows): what the reference's reader hands to matchange."""
     import os
     lib = load_library()
-    err = C.create_string_buffer(512)
-    h = lib.lvbhost_alignment_read_phylip(os.fsencode(path), err, 512)
+    code = FORMATS[fmt] if isinstance(fmt, str) else int(fmt)
+    err = C.create_string_buffer(4096)
+    h = lib.lvbhost_alignment_read(os.fsencode(path), code, err, 4096)
     if not h:
-        raise ValueError(err.value.decode())
+        raise ValueError(err.value.decode(errors="replace"))
     try:
         n = lib.lvbhost_alignment_n(h)
         return ([lib.lvbhost_alignment_name(h, i) for i in range(n)], [lib.lvbhost_alignment_row(h, i) for i in range(n)])
     finally:
         lib.lvbhost_alignment_free(h)
+
+
+def read_phylip(path) -> tuple[list[bytes], list[bytes]]:
+    return read_alignment(path, "phylip")
 
 
 def newick(tree: "HostTree", names: list[bytes]) -> str:

@@ -21,9 +21,10 @@ from . import api, host
 
 
 def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 4096, device: int = 0, out: str | None = "outtree",
-        max_seconds: float = 0.0, cooling: int = 0, verbose: bool = True, device_proposals: int = 2) -> dict:
+        max_seconds: float = 0.0, cooling: int = 0, verbose: bool = True, device_proposals: int = 2,
+        fmt: str = "phylip") -> dict:
     t0 = time.perf_counter()
-    names, rows = host.read_phylip(path)
+    names, rows = host.read_alignment(path, fmt)
     n, m_read = len(rows), len(rows[0])
     if n < 5:
         raise ValueError("The data matrix must have at least 5 sequences.")  # Wrapper.c:54 (MIN_N)
@@ -67,10 +68,10 @@ def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 4096, device:
 
 
 def run_exact(path: str, seed: int, algorithm: int = 1, cooling: int = 0, device: int = 0, out: str | None = "outtree",
-              verbose: bool = True, max_batch: int = 0, max_trees: int = 0) -> dict:
+              verbose: bool = True, max_batch: int = 0, max_trees: int = 0, fmt: str = "phylip") -> dict:
     """The reference's trajectory for this seed on the device scorer (Main.c:60-155 flow)."""
     t0 = time.perf_counter()
-    names, rows = host.read_phylip(path)
+    names, rows = host.read_alignment(path, fmt)
     n, m_read = len(rows), len(rows[0])
     if n < 5:
         raise ValueError("The data matrix must have at least 5 sequences.")
@@ -114,6 +115,7 @@ def main(argv=None) -> int:
     ap.add_argument("-s", dest="seed", type=int, default=int(time.time()) % 900000000)
     ap.add_argument("-a", dest="algorithm", type=int, default=1)
     ap.add_argument("-c", dest="cooling", choices=["g", "l"], default="g")
+    ap.add_argument("-f", dest="fmt", choices=list(host.FORMATS), default="phylip")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max-seconds", type=float, default=0.0)
@@ -124,10 +126,10 @@ def main(argv=None) -> int:
     try:
         if a.exact:
             run_exact(a.infile, a.seed, a.algorithm, 0 if a.cooling == "g" else 1, a.device, a.out,
-                      max_trees=max(a.max_trees, 0))
+                      max_trees=max(a.max_trees, 0), fmt=a.fmt)
             return 0
         run(a.infile, a.seed, a.algorithm, a.batch, a.device, a.out, a.max_seconds, 0 if a.cooling == "g" else 1,
-            device_proposals=0 if a.host_proposals else 2)
+            device_proposals=0 if a.host_proposals else 2, fmt=a.fmt)
     except (api.LvbGpuError, ValueError, OSError) as exc:
         print(f"\nFATAL ERROR: {exc}")
         return 1

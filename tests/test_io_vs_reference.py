@@ -57,3 +57,81 @@ def test_reader_rejects_ragged_file(tmp_path):
     with pytest.raises(ValueError) as ei:
         host.read_phylip(bad)
     assert "different length" in str(ei.value)
+
+
+FMT = {".phy": 0, ".fas": 1, ".nex": 2, ".aln": 3}
+
+
+def _same_as_reference(ob, path, code):
+    from lvb_amd import host
+    names, rows = host.read_alignment(path, code)
+    rr = ob.RefRun(path=str(path), fmt=code, seed=1)
+    try:
+        assert len(rows) == rr.n and len(rows[0]) == rr.original_m
+        assert [n.rstrip() for n in names] == [t.rstrip() for t in rr.titles()]
+        cut, min_len = host.prepare_alignment(rows)
+        assert cut == rr.rows()
+        assert min_len == rr.min_len
+    finally:
+        rr.close()
+    return names, rows
+
+
+@pytest.mark.parametrize("name", ["stock_100x1000.fas", "stock_100x1000.nex", "stock_100x1000.aln"])
+def test_other_formats_of_the_example_matrix_match_reference_reader(ob, name):
+    """The reference ships its 100 x 1000 example in all four formats (-f fasta|nexus|clustal)."""
+    from lvb_amd import host
+    path = GOLD / name
+    names, rows = _same_as_reference(ob, path, FMT[path.suffix])
+    # and all four hold the same matrix (row order differs between the files)
+    pn, pr = host.read_alignment(GOLD / "stock_100x1000.phy", "phylip")
+    assert dict(zip([n.strip() for n in names], rows)) == dict(zip([n.strip() for n in pn], pr))
+
+
+def _write_variants(tmp_path):
+    seqs = {"Alpha": "ACGTACGTAC" * 3, "Beta_2": "ACGTTCGTAC" * 3, "Gamma": "AC-TACGNAC" * 3, "Delta": "ACGTACGTAY" * 3,
+            "Eps": "TCGTACGTAC" * 3}
+    out = []
+    fas = tmp_path / "v.fas"  # wrapped lines, lower case, blank lines
+    fas.write_text("".join(f">{k}\n{v[:17].lower()}\n\n{v[17:]}\n" for k, v in seqs.items()))
+    out.append((fas, 1))
+    nex = tmp_path / "v.nex"  # interleaved blocks
+    body = "#NEXUS\n\nbegin data;\n    dimensions ntax=5 nchar=30;\n    format datatype=dna interleave=yes gap=-;\n    matrix\n"
+    body += "".join(f"{k:<10}{v[:12]}\n" for k, v in seqs.items()) + "\n"
+    body += "".join(f"{k:<10}{v[12:]}\n" for k, v in seqs.items()) + "    ;\nend;\n"
+    nex.write_text(body)
+    out.append((nex, 2))
+    aln = tmp_path / "v.aln"  # three blocks with conservation lines
+    body = "CLUSTAL 2.1 multiple sequence alignment\n\n\n"
+    for lo, hi in ((0, 12), (12, 24), (24, 30)):
+        body += "".join(f"{k:<16}{v[lo:hi]}\n" for k, v in seqs.items())
+        body += " " * 16 + "*" * (hi - lo) + "\n\n"
+    aln.write_text(body)
+    out.append((aln, 3))
+    return seqs, out
+
+
+def test_wrapped_interleaved_and_multi_block_files_match_reference_reader(ob, tmp_path):
+    seqs, files = _write_variants(tmp_path)
+    for path, code in files:
+        names, rows = _same_as_reference(ob, path, code)
+        assert [n.decode().strip() for n in names] == list(seqs)
+        assert [r.decode() for r in rows] == [v.upper() for v in seqs.values()]
+
+
+@pytest.mark.parametrize("text,code,msg", [
+    (">a\nACGT\n>b\nACG\n>c\nACGT\n", 1, "sequence lengths are different"),
+    (">a\nACGT\n", 1, "Only one sequence"),
+    ("", 1, "Zero sequences"),
+    (">a\nACGT\n>b\nACJT\n", 1, "This char is not allowed (J)"),
+    ("#NEXUS\nbegin data;\ndimensions ntax=3 nchar=4;\nmatrix\na ACGT\nb ACGT\n;\nend;\n", 2, "different number of sequences"),
+    ("#NEXUS\nbegin data;\ndimensions ntax=2 nchar=5;\nmatrix\na ACGT\nb ACGT\n;\nend;\n", 2, "different length"),
+    ("#NEXUS\nbegin data;\nmatrix\na ACGT\nb ACGT\n;\nend;\n", 2, "check the file format"),
+])
+def test_reader_error_messages_follow_the_reference(tmp_path, text, code, msg):
+    from lvb_amd import host
+    f = tmp_path / "bad.txt"
+    f.write_text(text)
+    with pytest.raises(ValueError) as ei:
+        host.read_alignment(f, code)
+    assert msg in str(ei.value)
