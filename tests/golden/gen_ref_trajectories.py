@@ -29,6 +29,9 @@ RUNS += [("stock_100x1000.phy", 12345, 0, "g"), ("stock_100x1000.phy", 12345, 1,
          # linear cooling only where t0 is tiny: its gradient is 1e-10 per step (Solve.c:178, 430), so
          # from t0 = 0.15 the reference needs ~1.5e9 temperatures to freeze
          ("test_treelength_4.phy", 5, 1, "l")]
+# -t N: stop as soon as the treestack holds N trees (Solve.c:447-450)
+MAX_TREES = {("test_treelength_4.phy", 4242, 1, "g"): 10, ("stock_100x1000.phy", 12345, 0, "g"): 3}
+RUNS = [r + (0,) for r in RUNS] + [k + (v,) for k, v in MAX_TREES.items()]
 
 FIELDS = {"rearrangements": r"Rearrangements evaluated: +(\d+)", "trees": r"Topologies recovered: +(\d+)",
           "score": r"Tree score: +(\d+)", "t0": r"SA Starting Temperature: +([0-9.]+)"}
@@ -36,10 +39,10 @@ FIELDS = {"rearrangements": r"Rearrangements evaluated: +(\d+)", "trees": r"Topo
 
 def main():
     cases = []
-    for infile, seed, alg, cool in RUNS:
+    for infile, seed, alg, cool, max_trees in RUNS:
         with tempfile.TemporaryDirectory() as d:
             shutil.copy(FILES / infile, Path(d) / "infile")
-            args = ["-s", str(seed), "-a", str(alg), "-c", cool, "-p", "1"]
+            args = ["-s", str(seed), "-a", str(alg), "-c", cool, "-p", "1"] + (["-t", str(max_trees)] if max_trees else [])
             p = subprocess.run([str(REFBIN), *args], cwd=d, capture_output=True, text=True, timeout=300, check=True)
             out = {}
             for k, pat in FIELDS.items():
@@ -48,8 +51,9 @@ def main():
             trees = (Path(d) / "outtree").read_bytes()
             out["outtree_sha256"] = hashlib.sha256(trees).hexdigest()
             out["outtree_head"] = trees.decode().splitlines()[:2]
-            cases.append({"infile": infile, "seed": seed, "algorithm": alg, "cooling": cool, "args": args, "expect": out})
-            print(cases[-1]["infile"], seed, alg, cool, out["rearrangements"], out["score"], out["trees"], out["t0"])
+            cases.append({"infile": infile, "seed": seed, "algorithm": alg, "cooling": cool, "max_trees": max_trees,
+                          "args": args, "expect": out})
+            print(cases[-1]["infile"], seed, alg, cool, max_trees, out["rearrangements"], out["score"], out["trees"], out["t0"])
     doc = {"_comment": "Runs of the compiled reference program (oracle/_ref/lvb_ref) with pinned seeds; see "
                        "gen_ref_trajectories.py. Output of the reference, not of this repository's code.",
            "cases": cases}

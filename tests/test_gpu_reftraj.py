@@ -25,10 +25,10 @@ PICK = {("stock_100x1000.phy", 12345, 0), ("stock_100x1000.phy", 12345, 1), ("st
         ("test_treelength_4.phy", 4242, 0), ("test_treelength_4.phy", 4242, 1), ("test_treelength_4.phy", 4242, 2),
         ("test_treelength_4.phy", 5, 1), ("test_treelength_1.phy", 7, 1), ("test_treelength_6_thread_3.phy", 465380177, 1)}
 if not os.environ.get("LVB_ALL_TRAJ"):
-    CASES = [c for c in CASES if (c["infile"], c["seed"], c["algorithm"]) in PICK]
+    CASES = [c for c in CASES if (c["infile"], c["seed"], c["algorithm"]) in PICK or c["max_trees"]]
 
 
-def search(path, seed, algorithm, cooling="g", max_batch=None):
+def search(path, seed, algorithm, cooling="g", max_batch=None, max_trees=0):
     from lvb_amd import api, host
     names, rows = host.read_phylip(path)
     rows, min_len = host.prepare_alignment(rows)
@@ -36,6 +36,7 @@ def search(path, seed, algorithm, cooling="g", max_batch=None):
     try:
         p = host.refsearch_defaults()
         p.seed, p.algorithm, p.cooling_schedule, p.min_len_tree = seed, algorithm, 0 if cooling == "g" else 1, min_len
+        p.max_trees = max_trees
         if max_batch:
             p.max_batch = max_batch
         res, tree = host.reference_search(ctx.h, p)
@@ -49,9 +50,10 @@ def search(path, seed, algorithm, cooling="g", max_batch=None):
         ctx.close()
 
 
-@pytest.mark.parametrize("case", CASES, ids=[f"{c['infile'][:-4]}-s{c['seed']}-a{c['algorithm']}{c['cooling']}" for c in CASES])
+@pytest.mark.parametrize("case", CASES, ids=[f"{c['infile'][:-4]}-s{c['seed']}-a{c['algorithm']}{c['cooling']}" + (f"-t{c['max_trees']}" if c["max_trees"] else "") for c in CASES])
 def test_golden_run_of_the_reference_program(case):
-    res, trees = search(GOLD / "ref_tests" / case["infile"], case["seed"], case["algorithm"], case["cooling"])
+    res, trees = search(GOLD / "ref_tests" / case["infile"], case["seed"], case["algorithm"], case["cooling"],
+                        max_trees=case["max_trees"])
     e = case["expect"]
     assert f"{res['t0']:.8f}" == e["t0"]
     assert (res["rearrangements"], res["best_length"], res["trees"]) == (e["rearrangements"], e["score"], e["trees"])

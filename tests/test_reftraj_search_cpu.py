@@ -29,6 +29,7 @@ def run_case(case, lib, new_ctx, free_ctx, max_batch=None):
         p.seed, p.algorithm = case["seed"], case["algorithm"]
         p.cooling_schedule = 0 if case["cooling"] == "g" else 1
         p.min_len_tree = min_len
+        p.max_trees = case.get("max_trees", 0)
         if max_batch:
             p.max_batch = max_batch
         res, tree = host.reference_search(ctx, p, lib)
@@ -58,7 +59,7 @@ def check(case, res, trees):
     assert hashlib.sha256(trees).hexdigest() == e["outtree_sha256"]
 
 
-@pytest.mark.parametrize("case", QUICK, ids=[f"{c['infile'][:-4]}-s{c['seed']}-a{c['algorithm']}{c['cooling']}" for c in QUICK])
+@pytest.mark.parametrize("case", QUICK, ids=[f"{c['infile'][:-4]}-s{c['seed']}-a{c['algorithm']}{c['cooling']}" + (f"-t{c['max_trees']}" if c["max_trees"] else "") for c in QUICK])
 def test_whole_run_matches_the_reference_program(double, case):
     lib, new_ctx, free_ctx = double
     res, trees = run_case(case, lib, new_ctx, free_ctx)
@@ -68,6 +69,7 @@ def test_whole_run_matches_the_reference_program(double, case):
 @pytest.mark.parametrize("max_batch", [1, 3, 64, 999])
 def test_trajectory_does_not_depend_on_how_far_ahead_proposals_are_drawn(double, max_batch):
     lib, new_ctx, free_ctx = double
-    case = next(c for c in CASES if c["infile"] == "test_treelength_4.phy" and c["algorithm"] == 1 and c["cooling"] == "g")
+    case = next(c for c in CASES if c["infile"] == "test_treelength_4.phy" and c["algorithm"] == 1 and c["cooling"] == "g"
+                and not c["max_trees"])
     res, trees = run_case(case, lib, new_ctx, free_ctx, max_batch=max_batch)
     check(case, res, trees)
