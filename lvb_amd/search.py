@@ -4,6 +4,7 @@ host (batched SA over the device scorer); it is a convenience around the library
 
   python -m lvb_amd.search -i alignment.phy [-s seed] [-a 0|1] [-o outtree] [--batch B] [--device D]
   python -m lvb_amd.search -i alignment.phy -s seed --exact     # the reference's own trajectory (-a 0|1|2)
+  python -m torch.distributed.run --nproc-per-node 8 -m lvb_amd.search -i alignment.phy   # one restart per GPU
 
 --exact reproduces the reference program decision for decision (same random stream, start trees,
 proposals, cooling, treestack: lvb_amd/csrc/refsearch.cpp), so "Rearrangements evaluated", "Tree score",
@@ -44,12 +45,12 @@ def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 4096, device:
     p.log_cap = 4096
     res, log = host.anneal(ctx, tree, p)
     best = tree.best_trees()
+    newick = [host.newick(t, names) for t in best]
     if out:
         with open(out, "w") as f:
-            for t in best:
-                f.write(host.newick(t, names))
+            f.writelines(newick)
     res.update(taxa=n, sites_read=m_read, sites_used=len(rows[0]), min_len_tree=min_len, start_length=start,
-               wall_seconds=time.perf_counter() - t0, log=log, outtree=out)
+               wall_seconds=time.perf_counter() - t0, log=log, outtree=out, newick=newick)
     if verbose:
         ci = min_len / res["best_length"]
         print("\nSearch Results:")
@@ -108,6 +109,36 @@ def run_exact(path: str, seed: int, algorithm: int = 1, cooling: int = 0, device
     return res
 
 
+def run_restarts(ranks, path: str, seed: int, out: str | None = "outtree", verbose: bool = True, **kw) -> dict:
+    """One independent restart per rank (= per GPU), as SURVEY.md 8e shards the path: every rank anneals from
+    its own start tree and seed on its own device; the only exchange is the best length (a min-reduce) and
+    the rank that holds it writes the trees.  `ranks` is lvb_amd.launch.Ranks()."""
+    res = run(path, seed=ranks.restart_seed(seed), device=ranks.device, out=None, verbose=False, **kw)
+    best = int(-ranks.max_over_ranks(-float(res["best_length"])))
+    # lowest rank among those holding the best length
+    winner = int(-ranks.max_over_ranks(-float(ranks.rank if res["best_length"] == best else ranks.world)))
+    total_scored = ranks.sum_over_ranks(int(res["scored"]))
+    res.update(global_best_length=best, winner_rank=winner, restarts=ranks.world, scored_all_ranks=total_scored)
+    if ranks.rank == winner:
+        if out:
+            with open(out, "w") as f:
+                f.writelines(res["newick"])
+        if verbose:
+            ci = res["min_len_tree"] / best
+            print("\nSearch Results:")
+            print(f"  Restarts (one per GPU):   {ranks.world}")
+            print(f"  Candidates scored (GPU):  {total_scored}")
+            print(f"  Topologies recovered:     {res['topologies']}")
+            print(f"  Tree score:               {best}  (restart {winner})")
+            print(f"  Consistency index:        {ci:.2f}")
+            print(f"  Homoplasy index:          {1 - ci:.2f}")
+            print(f"  Total runtime (seconds):  {res['wall_seconds']:.2f}")
+            if out:
+                print(f"\nAll topologies written to '{out}'")
+    ranks.barrier()
+    return res
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="python -m lvb_amd.search")
     ap.add_argument("-i", dest="infile", default="infile")
@@ -128,8 +159,15 @@ def main(argv=None) -> int:
             run_exact(a.infile, a.seed, a.algorithm, 0 if a.cooling == "g" else 1, a.device, a.out,
                       max_trees=max(a.max_trees, 0), fmt=a.fmt)
             return 0
-        run(a.infile, a.seed, a.algorithm, a.batch, a.device, a.out, a.max_seconds, 0 if a.cooling == "g" else 1,
-            device_proposals=0 if a.host_proposals else 2, fmt=a.fmt)
+        from .launch import Ranks
+        ranks = Ranks()  # WORLD_SIZE > 1 (python -m torch.distributed.run ... -m lvb_amd.search): one restart per GPU
+        kw = dict(algorithm=a.algorithm, batch=a.batch, max_seconds=a.max_seconds, cooling=0 if a.cooling == "g" else 1,
+                  device_proposals=0 if a.host_proposals else 2, fmt=a.fmt)
+        if ranks.world > 1:
+            run_restarts(ranks, a.infile, a.seed, a.out, **kw)
+            ranks.close()
+        else:
+            run(a.infile, a.seed, device=a.device, out=a.out, **kw)
     except (api.LvbGpuError, ValueError, OSError) as exc:
         print(f"\nFATAL ERROR: {exc}")
         return 1

@@ -29,3 +29,36 @@ def test_search_reaches_reference_optimum(tmp_path, phy, score, topologies, on_d
         assert res["topologies"] == topologies
     lines = out.read_text().splitlines()
     assert len(lines) == min(res["topologies"], 1024) and all(l.startswith("(") and l.endswith(");") for l in lines)
+
+
+def test_two_restarts_share_one_gpu_and_the_best_one_writes_the_trees(tmp_path):
+    """The N-rank search flow (one independent restart per rank, min-reduce of the best length, the
+    winner writes the output), rehearsed with two ranks on this box's single GPU over gloo - RCCL
+    refuses two ranks on one device, and on a real node every rank has its own."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "outtree"
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PYTHONPATH=str(root), LVBGPU_REHEARSE_ON_ONE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, "-m", "lvb_amd.search", "-i",
+                                       str(GOLD / "ref_tests" / "test_treelength_6_thread_2.phy"), "-s", "509739986",
+                                       "-o", str(out), "--batch", "64", "--max-seconds", "60"],
+                                      cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    texts = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-2000:]
+        texts.append(o)
+    printed = [t for t in texts if "Search Results" in t]
+    assert len(printed) == 1                                # only the winning restart reports
+    assert "Restarts (one per GPU):   2" in printed[0] and "Tree score:               1628" in printed[0]
+    lines = out.read_text().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("(") and lines[0].endswith(");")
