@@ -203,7 +203,14 @@ struct lvbgpu_batch
     size_t off_toks = 0, off_dsts = 0;
     lvbgpu_batch_stats stats{};
     bool full_mode = false; // whole topologies: reads leaf rows only
+    // step batches owned by the context (lvbgpu_score_batch / _score_full_batch) run build -> launch
+    // -> lengths back to back, which lets them drop one synchronisation and take the zeroing of the
+    // length slots off the critical path
+    bool recycled = false;
+    bool len_zeroed = false; // d_len was cleared after the previous read-back
 };
+
+constexpr int32_t SPIN_WAIT_MAX_B = 512;
 
 #define HIPCHK(ctx, call)                                                                                              \
     do                                                                                                                 \
@@ -907,12 +914,18 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     else
         ctx->pool->run(T, gather);
     HIPCHK(ctx, hipMemcpyAsync(bt->d_prog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // h_pin is reused by the next upload
+    // h_pin is reused by the next upload.  A recycled step batch is read back (and the stream
+    // drained) by lvbgpu_batch_lengths before anything can build again: no need to wait here.
+    if (!bt->recycled)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     bt->ctx = ctx;
     bt->B = B;
     bt->off_toks = o_t;
     bt->off_dsts = o_d;
+    const void *old_len = bt->d_len.p;
     HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
+    if (bt->d_len.p != old_len)
+        bt->len_zeroed = false;
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     bt->full_mode = job.full;
     bt->stats.candidates = B;
@@ -956,7 +969,9 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
     if (!ctx || !b || b->ctx != ctx)
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, (size_t)b->B * 8, ctx->stream));
+    if (!b->len_zeroed)
+        HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, (size_t)b->B * 8, ctx->stream));
+    b->len_zeroed = false;
     WalkArgs a = resident_args(ctx, b->d_prog, b->off_toks, b->off_dsts, b->d_len.p, (uint32_t)b->B,
                                (int32_t)b->stats.max_stack);
     HIPCHK(ctx, launch_walk(a, false, ctx->stream));
@@ -970,7 +985,23 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // through pinned memory: one DMA, no staging
     HIPCHK(ctx, hipMemcpyAsync(b->h_len.p, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->recycled && b->B <= SPIN_WAIT_MAX_B)
+    {
+        // a latency-bound step (serial-exact search, small speculative batches): poll instead of
+        // sleeping in the runtime, the wake-up costs more than the step
+        hipError_t q;
+        while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady)
+            ;
+        HIPCHK(ctx, q);
+    }
+    else
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->recycled)
+    {
+        // clear the slots for the next step now, while the host consumes these lengths
+        HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->d_len.cap, ctx->stream));
+        b->len_zeroed = true;
+    }
     memcpy(lengths_out, b->h_len.p, (size_t)b->B * 8);
     for (int32_t i = 0; i < b->B; i++)
         if (lengths_out[i] <= 0)
@@ -1000,6 +1031,7 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
         ctx->step_batch = new (std::nothrow) lvbgpu_batch();
         if (!ctx->step_batch)
             return LVBGPU_E_NOMEM;
+        ctx->step_batch->recycled = true;
     }
     lvbgpu_batch *b = ctx->step_batch;
     BuildJob job;
@@ -1089,7 +1121,10 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
     const size_t total = o_d + align16((size_t)B * stride_t * 4);
     HIPCHK(ctx, bt->d_prog.reserve(total));
+    const void *old_len = bt->d_len.p;
     HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
+    if (bt->d_len.p != old_len)
+        bt->len_zeroed = false;
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     HIPCHK(ctx, ctx->d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
     HIPCHK(ctx, ctx->d_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
@@ -1117,6 +1152,8 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
                                ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(bt->d_len.p, 0, bt->d_len.cap, ctx->stream)); // for the next step, off its critical path
+    bt->len_zeroed = true;
     const ProposalInfo *pi = (const ProposalInfo *)ctx->h_pinfo.p;
     const int64_t *len = (const int64_t *)bt->h_len.p;
     int64_t combines = 0;
@@ -1200,6 +1237,7 @@ extern "C" int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t
         ctx->full_batch = new (std::nothrow) lvbgpu_batch();
         if (!ctx->full_batch)
             return LVBGPU_E_NOMEM;
+        ctx->full_batch->recycled = true;
     }
     lvbgpu_batch *bt = ctx->full_batch; // recycled like the step batch
     BuildJob job;
