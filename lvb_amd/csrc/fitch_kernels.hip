@@ -154,9 +154,10 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     uint32_t k_comb = 0;   // combines done (index into ds[])
     uint4 *const my_stack = lds_stack + (size_t)wave * a.stack_depth * 64u + lane;
 
-    // row `off16` (in 16-byte units from rows_in) -> this lane's group: scalar base + VGPR offset
-    auto load_row = [&](uint32_t off16) -> uint4 {
-        const char *row = in + ((size_t)off16 << 4);
+    // row at `offt` tiles (1 KiB units; every row stride is a whole number of tiles, so 32 bits reach
+    // 4 TiB) from rows_in -> this lane's group: scalar base + VGPR offset
+    auto load_row = [&](uint32_t offt) -> uint4 {
+        const char *row = in + ((size_t)offt << 10);
         return *reinterpret_cast<const uint4 *>(row + voff);
     };
 
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
         // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
         const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
-        const uint32_t myoff = (mytok & TOK_ROW_MASK) * a.in_stride4;
+        const uint32_t myoff = (mytok & TOK_ROW_MASK) * (a.in_stride4 >> 6);
         auto tok_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)mytok, (int)j); };
         auto off_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)myoff, (int)j); };
 
