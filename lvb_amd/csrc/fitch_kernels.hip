@@ -119,6 +119,14 @@ __device__ __forceinline__ uint32_t wave_sum_bits(uint32_t v, uint32_t nbits)
 // ---------------------------------------------------------------------------------------------
 // The walk.  COMMIT: store every produced node set to rows_out[dst] and add its change count to
 // changes_out[dst] (accepting a candidate / full evaluation / strict-compat write-back).
+typedef const __attribute__((address_space(1))) char *global_cp; // keeps loads global_load, not flat_load
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct OffVec
+{
+    uint32_t lo, hi; // one 64-bit value per lane, split over two VGPRs
+};
+
 template <bool COMMIT>
 __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 {
@@ -136,10 +144,16 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         return;
     // an item = (tile group, candidate): the wave walks the candidate's program once per tile of
     // its group, so descriptor/token fetches and the final reduction are paid once per group
-    const uint32_t group = item / a.B;
-    const uint32_t cand = item - group * a.B;
-    const uint32_t tile_begin = (group * a.ntiles) / a.ngroups;
-    const uint32_t tile_end = ((group + 1u) * a.ntiles) / a.ngroups;
+    // (no division: a wave's fixed cost is scalar work too)
+    uint32_t group = __umulhi(item, a.inv_B); // floor(item / B) or one less
+    uint32_t cand = item - group * a.B;
+    if (cand >= a.B)
+    {
+        group++;
+        cand -= a.B;
+    }
+    const uint32_t tile_begin = group * a.tiles_per + (group < a.tiles_rem ? group : a.tiles_rem);
+    const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
 
     const CandDesc cd = a.cands[cand];
     const uint32_t *__restrict__ tk = a.toks + cd.tok_off;
@@ -148,17 +162,20 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     uint32_t voff = col * 16u;                       // its byte offset (a row is far below 4 GiB)
     const char *__restrict__ in = reinterpret_cast<const char *>(a.rows_in);
 
-    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 acc;
     uint32_t sp = 0;       // stack pointer (levels)
     uint32_t nonempty = 0; // sites with non-empty intersection, this lane, whole program
     uint32_t k_comb = 0;   // combines done (index into ds[])
     uint4 *const my_stack = lds_stack + (size_t)wave * a.stack_depth * 64u + lane;
 
-    // row at `offt` tiles (1 KiB units; every row stride is a whole number of tiles, so 32 bits reach
-    // 4 TiB) from rows_in -> this lane's group: scalar base + VGPR offset
-    auto load_row = [&](uint32_t offt) -> uint4 {
-        const char *row = in + ((size_t)offt << 10);
-        return *reinterpret_cast<const uint4 *>(row + voff);
+    // row at byte offset `off` (wave-uniform) from rows_in -> this lane's group.  lane_ptr (rows_in +
+    // this lane's column offset) is kept opaque so the add stays ONE vector instruction taking the
+    // scalar pair as an operand, instead of being regrouped into scalar adds
+    global_cp lane_ptr = (global_cp)(in + voff);
+    auto load_row = [&](uint64_t off) -> uint4 {
+        asm volatile("" : "+v"(lane_ptr));
+        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(lane_ptr + off);
+        return make_uint4(v.x, v.y, v.z, v.w);
     };
 
     // COMMIT: the combine just done produced node ds[k_comb] with `ch` changes in this lane
@@ -172,99 +189,159 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         k_comb++;
     };
 
-    // one token: tok is wave-uniform (SGPR), cur is the row it names.  The common case (no flag
-    // bits) is a single combine; chain starts and merges are rare (2-3 per NNI/SPR/TBR program).
-    // A chain start sets acc = cur and still runs the common combine: fitch(cur, cur) = cur and
-    // counts 32 non-empty sites (every valid set is non-empty), which cd.nfresh accounts for.
+    // One token = one combine, acc = fitch(acc, row), and ONE scalar test.  The scalar unit is shared by
+    // the CU's four SIMDs and is what bounds this loop (tools/l2_probe3.hip: beyond ~4 scalar
+    // instructions per 1 KiB load the read rate falls, VALU work up to 16 per load is free), so
+    // everything rare is folded behind a single precomputed bit per token:
+    //   * a chain start (FRESH) needs acc = row.  Instead of testing for it, the token BEFORE it
+    //     leaves acc = all-ones (after pushing the old acc if the chain start says PUSH): then the
+    //     ordinary combine gives fitch(all, row) = row and counts 32 non-empty sites, which cd.nfresh
+    //     accounts for.  acc starts all-ones for the program's first token.
+    //   * merges after a token's own step are rare as well.
+    //   post bit j = token j has merges, or token j+1 is a chain start.
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
     uint32_t nonempty_rare = 0; // kept apart so the hot path's counter has a single definition
-    auto step = [&](uint32_t tok, const uint4 cur) {
-        const bool special = (tok >> TOK_MERGE_SHIFT) != 0u;
-        const bool fresh = special && (tok & TOK_FRESH);
-        if (__builtin_expect(fresh, 0))
-        {
-            if (tok & TOK_PUSH)
-            {
-                my_stack[(size_t)sp * 64u] = acc;
-                sp++;
-            }
-            acc = cur;
-        }
-        const uint32_t before = nonempty;
-        acc = fitch_planes(acc, cur, nonempty);
-        if constexpr (COMMIT)
-        {
-            if (!fresh)
-                produce(32u - (nonempty - before));
-        }
-        if (__builtin_expect(special, 0))
-        {
-            for (uint32_t m = (tok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK; m != 0; m--)
-            {
-                sp--;
-                const uint4 other = my_stack[(size_t)sp * 64u];
-                const uint32_t b2 = nonempty_rare;
-                acc = fitch_planes(other, acc, nonempty_rare);
-                if constexpr (COMMIT)
-                    produce(32u - (nonempty_rare - b2));
-            }
-        }
-    };
 
-    for (uint32_t tile = tile_begin; tile < tile_end; tile++, col += 64u, voff += 1024u)
-    for (uint32_t c0 = 0; c0 < cd.ntok; c0 += 64u)
+    for (uint32_t tile = tile_begin; tile < tile_end; tile++, col += 64u, lane_ptr += 1024)
     {
-        const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
-        // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
-        const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
-        const uint32_t myoff = (mytok & TOK_ROW_MASK) * (a.in_stride4 >> 6);
-        auto tok_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)mytok, (int)j); };
-        auto off_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)myoff, (int)j); };
+        acc = ones;
+        if constexpr (COMMIT)
+            k_comb = 0;
+        for (uint32_t c0 = 0; c0 < cd.ntok; c0 += 64u)
+        {
+            const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
+            // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
+            const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
+            // byte offset of that row, 64 bits in two vectors (the vector unit is not what bounds this loop)
+            const uint64_t myoff64 = (uint64_t)(mytok & TOK_ROW_MASK) * ((uint64_t)a.in_stride4 << 4);
+            OffVec o0{(uint32_t)myoff64, (uint32_t)(myoff64 >> 32)};
+            // the same offsets seen from 1, 2, 3 lanes further down, so that the four refills of a
+            // group read lane j of four vectors with ONE scalar index
+            auto down = [&](const OffVec &v, uint32_t k) {
+                const int sel = (int)(((lane + k) & 63u) << 2);
+                return OffVec{(uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v.lo),
+                              (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v.hi)};
+            };
+            const OffVec o1 = down(o0, 1u), o2 = down(o0, 2u), o3 = down(o0, 3u);
+            auto row_at = [&](const OffVec &v, uint32_t j) -> uint4 {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.lo, (int)j);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)v.hi, (int)j);
+                return load_row(((uint64_t)hi << 32) | lo);
+            };
+            const uint64_t freshm = __builtin_amdgcn_ballot_w64((mytok & TOK_FRESH) != 0u);
+            const uint64_t mergem = __builtin_amdgcn_ballot_w64(((mytok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK) != 0u);
+            const uint64_t postm = mergem | (freshm >> 1);
+            auto tok_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)mytok, (int)j); };
 
-        if (cnt < 4u)
-        {
-            for (uint32_t j = 0; j < cnt; j++)
-                step(tok_at(j), load_row(off_at(j)));
-            continue;
+            // rare: what follows token j's own combine
+            auto post = [&](uint32_t j) {
+                const uint32_t tok = tok_at(j);
+                for (uint32_t m = (tok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK; m != 0; m--)
+                {
+                    sp--;
+                    const uint4 other = my_stack[(size_t)sp * 64u];
+                    const uint32_t b2 = nonempty_rare;
+                    acc = fitch_planes(other, acc, nonempty_rare);
+                    if constexpr (COMMIT)
+                        produce(32u - (nonempty_rare - b2));
+                }
+                if (j < 63u && ((freshm >> (j + 1u)) & 1u)) // the next token (of this chunk) starts a chain
+                {
+                    if (tok_at(j + 1u) & TOK_PUSH)
+                    {
+                        my_stack[(size_t)sp * 64u] = acc;
+                        sp++;
+                    }
+                    acc = ones;
+                }
+            };
+            auto step = [&](uint32_t j, uint32_t flagged, const uint4 cur) {
+                const uint32_t before = nonempty;
+                acc = fitch_planes(acc, cur, nonempty);
+                if constexpr (COMMIT)
+                {
+                    if (!((freshm >> j) & 1u))
+                        produce(32u - (nonempty - before));
+                }
+                if (__builtin_expect(flagged != 0u, 0))
+                    post(j);
+            };
+            if (c0 != 0u && (freshm & 1u)) // a chunk of a long program that opens with a chain start
+            {
+                if (tok_at(0) & TOK_PUSH)
+                {
+                    my_stack[(size_t)sp * 64u] = acc;
+                    sp++;
+                }
+                acc = ones;
+            }
+
+            if (cnt < 4u)
+            {
+                for (uint32_t j = 0; j < cnt; j++)
+                    step(j, (uint32_t)(postm >> j) & 1u, row_at(o0, j));
+                continue;
+            }
+            // 4-slot ring: slot q holds the row of token j+q
+            uint4 ra = row_at(o0, 0), rb = row_at(o0, 1), rc = row_at(o0, 2), rd = row_at(o0, 3);
+            uint32_t jl = 4;     // first token not yet in the ring
+            uint64_t fm = postm; // post bits of the tokens from the head of the ring on, bit 0 first
+#define LVB_GROUP(F, J0, JL)                                                                                  \
+    step((J0), (F) & 1u, ra);                                                                                 \
+    ra = row_at(o0, (JL));                                                                                    \
+    step((J0) + 1u, (F) & 2u, rb);                                                                            \
+    rb = row_at(o1, (JL));                                                                                    \
+    step((J0) + 2u, (F) & 4u, rc);                                                                            \
+    rc = row_at(o2, (JL));                                                                                    \
+    step((J0) + 3u, (F) & 8u, rd);                                                                            \
+    rd = row_at(o3, (JL));
+            // every refill below is in range: no branches, counted vmcnt.  Two groups per trip to
+            // halve the loop's own scalar instructions.
+            for (; jl + 8u <= cnt; jl += 8u, fm >>= 8)
+            {
+                const uint32_t f = (uint32_t)fm;
+                LVB_GROUP(f, jl - 4u, jl)
+                LVB_GROUP(f >> 4, jl, jl + 4u)
+            }
+            if (jl + 4u <= cnt)
+            {
+                const uint32_t f = (uint32_t)fm;
+                LVB_GROUP(f, jl - 4u, jl)
+                jl += 4u;
+                fm >>= 4;
+            }
+#undef LVB_GROUP
+            // 4..7 tokens left, the first four already in the ring
+            const uint32_t left = cnt - (jl - 4u);
+            const uint32_t f = (uint32_t)fm;
+            step(jl - 4u, f & 1u, ra);
+            if (left > 4u)
+                ra = row_at(o0, jl);
+            step(jl - 3u, f & 2u, rb);
+            if (left > 5u)
+                rb = row_at(o1, jl);
+            step(jl - 2u, f & 4u, rc);
+            if (left > 6u)
+                rc = row_at(o2, jl);
+            step(jl - 1u, f & 8u, rd);
+            if (left > 4u)
+                step(jl, f & 16u, ra);
+            if (left > 5u)
+                step(jl + 1u, f & 32u, rb);
+            if (left > 6u)
+                step(jl + 2u, f & 64u, rc);
         }
-        // 4-slot ring: slot q holds the row of token j+q
-        uint4 ra = load_row(off_at(0)), rb = load_row(off_at(1)), rc = load_row(off_at(2)), rd = load_row(off_at(3));
-        uint32_t j = 0;
-        for (; j + 8u <= cnt; j += 4u) // every refill below is in range: no branches, counted vmcnt
-        {
-            step(tok_at(j), ra);
-            ra = load_row(off_at(j + 4u));
-            step(tok_at(j + 1u), rb);
-            rb = load_row(off_at(j + 5u));
-            step(tok_at(j + 2u), rc);
-            rc = load_row(off_at(j + 6u));
-            step(tok_at(j + 3u), rd);
-            rd = load_row(off_at(j + 7u));
-        }
-        // 4..7 tokens left, the first four already in the ring
-        const uint32_t left = cnt - j;
-        step(tok_at(j), ra);
-        if (left > 4u)
-            ra = load_row(off_at(j + 4u));
-        step(tok_at(j + 1u), rb);
-        if (left > 5u)
-            rb = load_row(off_at(j + 5u));
-        step(tok_at(j + 2u), rc);
-        if (left > 6u)
-            rc = load_row(off_at(j + 6u));
-        step(tok_at(j + 3u), rd);
-        if (left > 4u)
-            step(tok_at(j + 4u), ra);
-        if (left > 5u)
-            step(tok_at(j + 5u), rb);
-        if (left > 6u)
-            step(tok_at(j + 6u), rc);
     }
 
     // changes of this lane = 32 sites per combine (and per chain start, see step) minus the non-empty ones
     const uint32_t per_lane = 32u * (cd.ncomb + cd.nfresh) * (tile_end - tile_begin);
     const uint32_t lane_changes = per_lane - nonempty - nonempty_rare;
-    const uint32_t nbits = 32u - __builtin_clz(per_lane | 1u);
-    unsigned long long total = wave_sum_bits(lane_changes, nbits);
+    // butterfly over the LDS crossbar: no scalar instructions (the bit-sliced ballot sum that
+    // produce() uses for its 6-bit counts would cost ~4 per bit here)
+    uint32_t wsum = lane_changes;
+    for (int off = 32; off > 0; off >>= 1)
+        wsum += (uint32_t)__shfl_xor((int)wsum, off);
+    unsigned long long total = wsum;
 
     if (group == 0)
     {
@@ -427,12 +504,19 @@ hipError_t upload_iupac_table()
     return hipMemcpyToSymbol(HIP_SYMBOL(k_iupac), tab, sizeof(tab));
 }
 
-hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream)
+hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
 {
-    if (a.nitems == 0)
+    if (args.nitems == 0)
         return hipSuccess;
-    if (a.ngroups == 0 || a.ngroups > a.ntiles || a.nitems != a.B * a.ngroups)
+    if (args.ngroups == 0 || args.ngroups > args.ntiles || args.nitems != args.B * args.ngroups ||
+        args.nitems >= (1u << 31))
         return hipErrorInvalidValue;
+    WalkArgs a = args;
+    a.tiles_per = a.ntiles / a.ngroups;
+    a.tiles_rem = a.ntiles % a.ngroups;
+    // floor(2^32 / B): mulhi(item, inv_B) is floor(item / B) or one less for item < 2^31 (the kernel
+    // fixes up once).  B == 1 would need 2^32: 2^32 - 1 gives item - 1 (0 for item 0), same fix-up.
+    a.inv_B = a.B == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / a.B);
     uint32_t nblk = (a.nitems + WALK_WAVES - 1) / WALK_WAVES;
     nblk = (nblk + 7u) & ~7u; // the XCD remap needs a multiple of 8
     const size_t lds = (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4);

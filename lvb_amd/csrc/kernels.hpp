@@ -44,6 +44,9 @@ struct WalkArgs
     uint32_t B, ntiles;
     uint32_t ngroups;                   // tiles are dealt to this many groups; one wave walks one (group, candidate)
     uint32_t nitems;                    // B * ngroups
+    // filled by launch_walk so that no wave divides: group g walks tiles_per (+1 if g < tiles_rem)
+    // tiles; item / B = mulhi(item, inv_B) or that + 1
+    uint32_t tiles_per, tiles_rem, inv_B;
     uint32_t stack_depth;               // operand-stack levels per wave in LDS (>= 1)
     uint32_t root_slot;                 // COMMIT: changes_out slot that collects the two root combines
 };
