@@ -151,8 +151,23 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
                                int32_t n, int32_t root, int32_t kind_all, uint32_t mix_a, uint32_t mix_b,
                                uint64_t seed, uint32_t B, uint32_t stride_t,
                                uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                               CandDesc *cands, ProposalInfo *info)
+                               CandDesc *cands, ProposalInfo *info, int32_t use_lds)
 {
+    // The walk below is pointer chasing (two root-ward paths, a random descent for TBR): from global
+    // memory every step is an L2 round trip.  When the four arrays fit, the block first copies them
+    // into LDS (coalesced) and chases there.
+    extern __shared__ int32_t lds_topo[];
+    const int32_t nb_all = 2 * n - 3;
+    if (use_lds)
+    {
+        for (int32_t i = (int32_t)threadIdx.x; i < 4 * nb_all; i += (int32_t)blockDim.x)
+            lds_topo[i] = parent[i]; // parent | left | right | leaves are contiguous (launch_propose)
+        __syncthreads();
+        parent = lds_topo;
+        left = lds_topo + nb_all;
+        right = lds_topo + 2 * nb_all;
+        leaves = lds_topo + 3 * nb_all;
+    }
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B)
         return;
@@ -501,8 +516,22 @@ hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t
                           CandDesc *cands, ProposalInfo *info, hipStream_t stream)
 {
     const int32_t nb = 2 * n - 3;
-    hipLaunchKernelGGL(propose_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, topo4, topo4 + nb, topo4 + 2 * nb,
-                       topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts, edits, cands, info);
+    // the topology in LDS when it fits (16 bytes per node; 160 KB of LDS per CU): up to ~5000 taxa
+    size_t lds = (size_t)nb * 16u;
+    int32_t use_lds = 1;
+    if (lds > 64u * 1024u)
+    {
+        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (raised != hipSuccess || lds > 160u * 1024u)
+        {
+            lds = 0;
+            use_lds = 0;
+        }
+    }
+    hipLaunchKernelGGL(propose_kernel, dim3((B + 63) / 64), dim3(64), lds, stream, topo4, topo4 + nb, topo4 + 2 * nb,
+                       topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts, edits, cands,
+                       info, use_lds);
     return hipGetLastError();
 }
 
