@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of profiles/collect.sh (gpurun_out/prof_<tag>/) into the two
+summaries kept under profiles/: <tag>_kernel_stats.csv (the --stats table as is) and
+<tag>_pmc_summary.json (per-launch means of every collected counter for the scoring kernel, with the
+HBM figures corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes), and refresh
+profiles/traffic.json, which bench.py quotes as roofline.traffic.
+
+    python profiles/summarize.py r01e
+"""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+KERNEL = "fitch_walk<false>"
+
+
+def main(tag: str) -> None:
+    src = ROOT / "gpurun_out" / f"prof_{tag}"
+    stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], ROOT / "profiles" / f"{tag}_kernel_stats.csv")
+    counters = defaultdict(list)
+    for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if KERNEL in row["Kernel_Name"]:
+                    counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    summary = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(counters.items())}
+    mean = lambda k: summary[k]["mean_per_launch"] if k in summary else None
+    derived = {}
+    if mean("FETCH_SIZE") is not None:
+        # FETCH_SIZE counts KiB and sees exactly half of a 16-B/lane coalesced stream on gfx950: doubled
+        derived["hbm_read_bytes_per_launch_corrected"] = mean("FETCH_SIZE") * 1024 * 2
+    if mean("WRITE_SIZE") is not None:
+        derived["hbm_write_bytes_per_launch"] = mean("WRITE_SIZE") * 1024
+    if mean("TCC_HIT_sum") is not None and mean("TCC_MISS_sum") is not None:
+        derived["l2_hit_rate"] = mean("TCC_HIT_sum") / (mean("TCC_HIT_sum") + mean("TCC_MISS_sum"))
+    if mean("SQ_WAVES"):
+        derived["waves_per_launch"] = mean("SQ_WAVES")
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"):
+            if mean(k) is not None:
+                derived[k.lower().replace("sq_insts_", "") + "_insts_per_wave"] = mean(k) / mean("SQ_WAVES")
+    if mean("SQ_WAVE_CYCLES"):
+        derived["wave_cycle_shares"] = {n: mean(c) / mean("SQ_WAVE_CYCLES") for n, c in
+                                        (("wait_memory(SQ_WAIT_ANY)", "SQ_WAIT_ANY"),
+                                         ("wait_issue(SQ_WAIT_INST_ANY)", "SQ_WAIT_INST_ANY"),
+                                         ("active(SQ_ACTIVE_INST_ANY)", "SQ_ACTIVE_INST_ANY")) if mean(c) is not None}
+    doc = {"command": f"rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 40 --warmup 5 "
+                      f"--no-cpu-baseline --anneal-seconds 0   (one pass per counter set, profiles/collect.sh {tag})",
+           "kernel": f"lvbgpu::{KERNEL}", "counters": summary, "derived": derived}
+    (ROOT / "profiles" / f"{tag}_pmc_summary.json").write_text(json.dumps(doc, indent=1) + "\n")
+    if "hbm_read_bytes_per_launch_corrected" in derived:
+        traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        traffic["hbm_bytes_per_launch"] = derived["hbm_read_bytes_per_launch_corrected"] + derived.get(
+            "hbm_write_bytes_per_launch", 0.0)
+        traffic["source"] = f"profiles/{tag}_pmc_summary.json"
+        (ROOT / "profiles" / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+    print(json.dumps(derived, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01e")
