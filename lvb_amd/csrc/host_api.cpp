@@ -378,7 +378,8 @@ extern "C" lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, ch
         return fail("out of memory");
     long n = 0, m = 0;
     std::string line;
-    std::vector<std::string> lines; // non-empty lines after the header
+    bool started = false;
+    std::vector<std::string> lines; // non-empty lines after the header, from the first sequence line on
     while (std::getline(in, line))
     {
         if (!line.empty() && line.back() == '\r')
@@ -393,6 +394,16 @@ extern "C" lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, ch
                 return fail("Some problem reading the file. Please, check the file format.");
             }
             continue;
+        }
+        if (!started)
+        {
+            // the reference skips everything up to the first line that ends in a sequence character
+            // (MSAInput.cpp:334-340; its PHYLIP character set has no J, O, U and no digits)
+            static const std::string seq_chars = "ABCDEFGHIKLMNPQRSTVWXYZabcdefghiklmnpqrstvwxyz*?-";
+            const std::string tl = trimmed(line);
+            if (seq_chars.find(tl.back()) == std::string::npos)
+                continue;
+            started = true;
         }
         lines.push_back(line);
     }

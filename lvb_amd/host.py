@@ -377,7 +377,9 @@ def prepare_alignment(rows: list[bytes]) -> tuple[list[bytes], int]:
         rows = [np.frombuffer(r, dtype=np.uint8)[idx].tobytes() for r in rows]
         arr = (C.c_char_p * n)(*rows)
     if kept < 1:
-        raise ValueError("after constant columns are ignored, the data matrix has no columns left")
+        # the reference's wording (DataOperations.c:346-350, MIN_M = 1)
+        raise ValueError(f"after constant columns are ignored, data MSA has\n{int(kept)} columns, which is less than "
+                         "LVB's lower limit of\n1 columns.\n")
     return rows, int(lib.lvbhost_min_tree_length(n, int(kept), arr))
 
 

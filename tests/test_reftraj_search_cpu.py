@@ -12,16 +12,20 @@ import pytest
 
 GOLD = Path(__file__).resolve().parent / "golden"
 CASES = json.loads((GOLD / "ref_trajectories.json").read_text())["cases"]
+# the reference's own test_matrix_*_length inputs in the other three formats (-f fasta|nexus|clustal)
+BLACKBOX = [dict(infile="blackbox/" + c["infile"], seed=4242, algorithm=1, cooling="g", max_trees=0, format=c["format"],
+                 expect=dict(c["expect"], outtree_sha256=None, outtree_head=None))
+            for c in json.loads((GOLD / "ref_blackbox.json").read_text())["cases"] if "expect" in c]
 import os  # noqa: E402
 
 # every case passes (LVB_ALL_TRAJ=1, ~3 min on the CPU double); by default the tier runs the runs
 # shorter than 400 k rearrangements, which include the 100-taxon example under all three -a schedules
-QUICK = CASES if os.environ.get("LVB_ALL_TRAJ") else [c for c in CASES if c["expect"]["rearrangements"] < 400000]
+QUICK = CASES + BLACKBOX if os.environ.get("LVB_ALL_TRAJ") else [c for c in CASES if c["expect"]["rearrangements"] < 400000]
 
 
 def run_case(case, lib, new_ctx, free_ctx, max_batch=None):
     from lvb_amd import host
-    names, rows = host.read_phylip(GOLD / "ref_tests" / case["infile"])
+    names, rows = host.read_alignment(GOLD / "ref_tests" / case["infile"], case.get("format", "phylip"))
     rows, min_len = host.prepare_alignment(rows)
     ctx = new_ctx(rows)
     try:
@@ -55,11 +59,12 @@ def check(case, res, trees):
     e = case["expect"]
     assert f"{res['t0']:.8f}" == e["t0"]
     assert (res["rearrangements"], res["best_length"], res["trees"]) == (e["rearrangements"], e["score"], e["trees"])
-    assert trees.decode().splitlines()[:2] == e["outtree_head"]
-    assert hashlib.sha256(trees).hexdigest() == e["outtree_sha256"]
+    if e["outtree_sha256"] is not None:
+        assert trees.decode().splitlines()[:2] == e["outtree_head"]
+        assert hashlib.sha256(trees).hexdigest() == e["outtree_sha256"]
 
 
-@pytest.mark.parametrize("case", QUICK, ids=[f"{c['infile'][:-4]}-s{c['seed']}-a{c['algorithm']}{c['cooling']}" + (f"-t{c['max_trees']}" if c["max_trees"] else "") for c in QUICK])
+@pytest.mark.parametrize("case", QUICK, ids=[f"{Path(c['infile']).stem}-s{c['seed']}-a{c['algorithm']}{c['cooling']}" + (f"-t{c['max_trees']}" if c["max_trees"] else "") for c in QUICK])
 def test_whole_run_matches_the_reference_program(double, case):
     lib, new_ctx, free_ctx = double
     res, trees = run_case(case, lib, new_ctx, free_ctx)
