@@ -135,3 +135,29 @@ def test_reader_error_messages_follow_the_reference(tmp_path, text, code, msg):
     with pytest.raises(ValueError) as ei:
         host.read_alignment(f, code)
     assert msg in str(ei.value)
+
+
+# expected values of the reference's library tests test_lib_phylip_dna_matrin_{interleaved,sequential,simple}
+# and test_lib_phylip_mat_dims_in (their Main.c: name_expected / sequence_expected / EXPECTED_N, EXPECTED_M)
+PHYLIP_DOC = {
+    "names": ["Turkey", "Salmo gair", "H. Sapiens", "Chimp", "Gorilla"],
+    "rows": ["AAGCTNGGGCATTTCAGGGTGAGCCCGGGCAATACAGGGTAT", "AAGCCTTGGCAGTGCAGGGTGAGCCGTGGCCGGGCACGGTAT",
+             "ACCGGTTGGCCGTTCAGGGTACAGGTTGGCCGTTCAGGGTAA", "AAACCCTTGCCGTTACGCTTAAACCGAGGCCGGGACACTCAT",
+             "AAACCCTTGCCGGTACGCTTAAACCATTGCCGGTACGCTTAA"]}
+SIMPLE = {"names": ["Archaeopt", "Hesperorni", "Baluchithe", "B. virgini", "Brontosaur", "B.subtilis"],
+          "rows": ["CGATGCTTACCGC", "CGTTACTCGTTGT", "TAATGTTAATTGT", "TAATGTTCGTTGT", "CAAAACCCATCAT", "GGCAGCCAATCAC"]}
+
+
+@pytest.mark.parametrize("phy,want", [("lib_phylip_interleaved.phy", PHYLIP_DOC), ("lib_phylip_sequential.phy", PHYLIP_DOC),
+                                      ("lib_phylip_simple.phy", SIMPLE)])
+def test_phylip_layouts_known_answers_of_the_reference_library_tests(phy, want):
+    from lvb_amd import host
+    names, rows = host.read_phylip(GOLD / phy)
+    assert [n.decode().strip() for n in names] == want["names"]
+    assert [r.decode() for r in rows] == want["rows"]
+
+
+def test_phylip_dimensions_known_answer():
+    from lvb_amd import host
+    names, rows = host.read_phylip(GOLD / "lib_phylip_mat_dims_in.phy")
+    assert (len(rows), len(rows[0])) == (10, 63)  # EXPECTED_N, EXPECTED_M
