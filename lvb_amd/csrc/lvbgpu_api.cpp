@@ -312,8 +312,7 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     ctx->stride4 = ctx->stride_words / 2;
     if (const char *tw = getenv("LVBGPU_TARGET_WAVES"))
         ctx->target_waves = (uint32_t)std::max(1, atoi(tw));
-    if ((uint64_t)ctx->nb * (ctx->stride4 >> 6) >= (1ull << 32)) // row offsets are 32-bit counts of 1 KiB tiles
-        return ctx->fail(LVBGPU_E_ARG, "tree block exceeds 4 TiB");
+    // (row offsets are 64-bit in the kernels: the tree block is limited by HBM, not by index width)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
