@@ -17,6 +17,9 @@ constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
 constexpr uint32_t TARGET_WAVES = 65536;          // aim for at least this many (group, candidate) waves per launch
 constexpr uint32_t MAX_TILES_PER_WAVE = 8;
 
+// "length" the device generator gives a candidate it could not represent (per-candidate buffers
+// too short, no admissible move): the host turns anything this large into INT64_MAX
+constexpr long long PROPOSAL_OVERFLOW_LENGTH = 1ll << 61;
 constexpr uint32_t CAND_RESIDENT_BASE = 1u;       // base += *s_all - sum(node_changes[dst])
 
 struct CandDesc

@@ -1127,7 +1127,6 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     HIPCHK(ctx, ctx->d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
     HIPCHK(ctx, ctx->d_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
-    HIPCHK(ctx, ctx->h_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
     bt->ctx = ctx;
     bt->B = B;
     bt->off_toks = o_t;
@@ -1147,31 +1146,24 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
         return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinfo.p, ctx->d_pinfo.p, (size_t)B * sizeof(ProposalInfo), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
+    // when) the caller wants that candidate (lvbgpu_proposal_edits)
     HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(bt->d_len.p, 0, bt->d_len.cap, ctx->stream)); // for the next step, off its critical path
     bt->len_zeroed = true;
-    const ProposalInfo *pi = (const ProposalInfo *)ctx->h_pinfo.p;
     const int64_t *len = (const int64_t *)bt->h_len.p;
-    int64_t combines = 0;
     for (int32_t b = 0; b < B; b++)
     {
-        if (pi[b].overflow)
+        if (len[b] >= PROPOSAL_OVERFLOW_LENGTH)
         {
             lengths_out[b] = INT64_MAX;
             continue;
         }
         lengths_out[b] = len[b];
-        combines += pi[b].ncomb;
         if (len[b] <= 0)
             return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
     }
-    bt->stats.combines = combines;
-    bt->stats.rows_read = combines + B;
-    bt->stats.dirty_nodes = combines - 2 * (int64_t)B;
-    bt->stats.algorithmic_bytes = bt->stats.rows_read * ctx->nwords * 8;
     ctx->p_B = B;
     return LVBGPU_OK;
 }
@@ -1204,12 +1196,17 @@ extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *ed
         return ctx->fail(LVBGPU_E_STATE, "no device batch holds that candidate: call lvbgpu_propose_score first");
     if (ctx->d_topo_version != ctx->topo_version)
         return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since that batch was drawn");
-    const ProposalInfo &pi = ((const ProposalInfo *)ctx->h_pinfo.p)[b];
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // this candidate's descriptor, then its edits
+    HIPCHK(ctx, ctx->h_pinfo.reserve(sizeof(ProposalInfo)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinfo.p, (const ProposalInfo *)ctx->d_pinfo.p + b, sizeof(ProposalInfo),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const ProposalInfo pi = *(const ProposalInfo *)ctx->h_pinfo.p;
     if (pi.overflow)
         return ctx->fail(LVBGPU_E_ARG, "that candidate overflowed the per-candidate buffers");
     if (pi.n_edits > cap)
         return ctx->fail(LVBGPU_E_ARG, "edit buffer too small");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
     static_assert(sizeof(lvbgpu_edit) == sizeof(lvbgpu_edit_dev), "edit layout");
     HIPCHK(ctx, hipMemcpyAsync(edits, (const lvbgpu_edit_dev *)ctx->d_pedits.p + (size_t)b * ctx->p_stride_e,
                                (size_t)pi.n_edits * sizeof(lvbgpu_edit), hipMemcpyDeviceToHost, ctx->stream));

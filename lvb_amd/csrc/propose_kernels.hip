@@ -265,6 +265,7 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             CandDesc none{};
             none.tok_off = b * stride_t;
             none.dst_off = b * stride_t;
+            none.base = PROPOSAL_OVERFLOW_LENGTH;
             cands[b] = none;
             pi.overflow = 1;
             info[b] = pi;
@@ -363,29 +364,25 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             pa[na++] = v;
         if (na >= MAX_PATH)
             e.overflow = true;
-        // path B: pp upwards until it meets A or the root
+        // path B: pp upwards until it meets A or the root.  Both paths end just below the root, so
+        // what they share is a common suffix: walk B to the top, then strip the suffix (linear,
+        // instead of searching A for every node of B)
         int32_t *pb = buf2;
         int nbp = 0, meet_a = -1;
         if (pp != root)
         {
             for (int32_t v = pp; v != root && nbp < MAX_PATH; v = nv.parent(v))
-            {
-                int hit = -1;
-                for (int i = 0; i < na; i++)
-                    if (pa[i] == v)
-                    {
-                        hit = i;
-                        break;
-                    }
-                if (hit >= 0)
-                {
-                    meet_a = hit;
-                    break;
-                }
                 pb[nbp++] = v;
-            }
             if (nbp >= MAX_PATH)
                 e.overflow = true;
+            int common = 0;
+            while (common < na && common < nbp && pa[na - 1 - common] == pb[nbp - 1 - common])
+                common++;
+            if (common > 0)
+            {
+                meet_a = na - common; // first node of A that B runs into
+                nbp -= common;
+            }
         }
         // chain below sp -> sp: sp's clean child is dest (its other child is `top`: clean for SPR,
         // the accumulated chain for TBR)
@@ -502,6 +499,8 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
         cd.ntok = 0;
         cd.ncomb = 0;
         cd.nfresh = 0;
+        cd.flags = 0;
+        cd.base = PROPOSAL_OVERFLOW_LENGTH; // its "length": the host reads that as unusable
     }
     cands[b] = cd;
     pi.n_edits = (int32_t)e.nedit;
