@@ -210,7 +210,9 @@ struct lvbgpu_batch
     bool len_zeroed = false; // d_len was cleared after the previous read-back
 };
 
-constexpr int32_t SPIN_WAIT_MAX_B = 512;
+// steps up to this many candidates finish within a few hundred microseconds: poll for them instead of
+// sleeping in the runtime (its wake-up costs ~10 us per step)
+constexpr int32_t SPIN_WAIT_MAX_B = 16384;
 
 #define HIPCHK(ctx, call)                                                                                              \
     do                                                                                                                 \
@@ -258,6 +260,17 @@ struct Packed
 };
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// end of a search step on the context's stream
+hipError_t wait_for_step(lvbgpu_ctx *ctx, int32_t B)
+{
+    if (B > SPIN_WAIT_MAX_B)
+        return hipStreamSynchronize(ctx->stream);
+    hipError_t q;
+    while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady)
+        ;
+    return q;
+}
 
 WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, size_t off_dsts, void *d_len,
                        uint32_t B, int32_t max_stack)
@@ -984,15 +997,8 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // through pinned memory: one DMA, no staging
     HIPCHK(ctx, hipMemcpyAsync(b->h_len.p, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (b->recycled && b->B <= SPIN_WAIT_MAX_B)
-    {
-        // a latency-bound step (serial-exact search, small speculative batches): poll instead of
-        // sleeping in the runtime, the wake-up costs more than the step
-        hipError_t q;
-        while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady)
-            ;
-        HIPCHK(ctx, q);
-    }
+    if (b->recycled)
+        HIPCHK(ctx, wait_for_step(ctx, b->B));
     else
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (b->recycled)
@@ -1149,7 +1155,7 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
     // when) the caller wants that candidate (lvbgpu_proposal_edits)
     HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_for_step(ctx, B));
     HIPCHK(ctx, hipMemsetAsync(bt->d_len.p, 0, bt->d_len.cap, ctx->stream)); // for the next step, off its critical path
     bt->len_zeroed = true;
     const int64_t *len = (const int64_t *)bt->h_len.p;
