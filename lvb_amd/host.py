@@ -362,10 +362,10 @@ def starting_temperature(ctx: api.FitchContext, tree: HostTree, params: AnnealPa
     return t0.value
 
 
-def prepare_alignment(rows: list[bytes]) -> tuple[list[bytes], int]:
+def prepare_alignment(rows: list[bytes], lib=None) -> tuple[list[bytes], int]:
     """matchange (reference DataOperations.c:309-360): drop constant columns, then
     MinimumTreeLength of what is left.  -> (rows after the cut, min_len_tree)."""
-    lib = load_library()
+    lib = lib or load_library()
     n, m = len(rows), len(rows[0])
     arr = (C.c_char_p * n)(*rows)
     keep = np.zeros(m, dtype=np.uint8)
@@ -386,10 +386,10 @@ def prepare_alignment(rows: list[bytes]) -> tuple[list[bytes], int]:
 FORMATS = {"phylip": 0, "fasta": 1, "nexus": 2, "clustal": 3}  # the reference's -f (DataStructure.h:50-53)
 
 
-def read_alignment(path, fmt: str | int = "phylip") -> tuple[list[bytes], list[bytes]]:
+def read_alignment(path, fmt: str | int = "phylip", lib=None) -> tuple[list[bytes], list[bytes]]:
     """Alignment file -> (names, rows): what the reference's reader hands to matchange."""
     import os
-    lib = load_library()
+    lib = lib or load_library()
     code = FORMATS[fmt] if isinstance(fmt, str) else int(fmt)
     err = C.create_string_buffer(4096)
     h = lib.lvbhost_alignment_read(os.fsencode(path), code, err, 4096)

@@ -1,0 +1,43 @@
+"""Host logic under AddressSanitizer + UBSan (CPU only: the pool has no GPU sanitizers).  Driven by
+tools/sanitize_host.sh, which builds the host sources against the scorer's test double
+(tests/cpu_double) with -fsanitize=address,undefined and preloads the runtimes: whole
+reference-trajectory runs, the program builder under random moves, the alignment readers."""
+import sys, json, ctypes as C, numpy as np
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+from lvb_amd import host
+from oracle import binding
+from pathlib import Path
+lib = host.bind(C.CDLL(sys.argv[1]))
+lib.lvbgpu_double_new.restype = C.c_void_p
+lib.lvbgpu_double_new.argtypes = [C.c_long, C.c_long, np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")]
+lib.lvbgpu_double_free.argtypes = [C.c_void_p]
+GOLD = Path(__file__).resolve().parent.parent / 'tests' / 'golden'
+cases = json.loads((GOLD / 'ref_trajectories.json').read_text())['cases']
+for case in cases:
+    if case['expect']['rearrangements'] > 100000: continue
+    names, rows = host.read_alignment(GOLD / 'ref_tests' / case['infile'], lib=lib)
+    rows, ml = host.prepare_alignment(rows, lib)
+    enc = binding.encode_rows(rows)
+    ctx = C.c_void_p(lib.lvbgpu_double_new(enc.shape[0], enc.shape[1], np.ascontiguousarray(enc)))
+    p = host.refsearch_defaults(lib); p.seed, p.algorithm, p.min_len_tree = case['seed'], case['algorithm'], ml
+    p.cooling_schedule = 0 if case['cooling'] == 'g' else 1; p.max_trees = case['max_trees']
+    res, tree = host.reference_search(ctx, p, lib)
+    assert res['rearrangements'] == case['expect']['rearrangements'], (case, res)
+    n = len(tree.best_trees())
+    tree.close(); lib.lvbgpu_double_free(ctx)
+    print(case['infile'], case['seed'], case['algorithm'], 'ok', n)
+# program builder fuzz through the sanitized library
+t = host.HostTree(40, seed=3, lib=lib)
+for k in range(3000):
+    e = t.propose(k % 3)
+    t.program(mode=0, edits=e)
+    if k % 7 == 0: t.apply(e)
+print('fuzz ok')
+for f, fmt in (("stock_100x1000.fas", "fasta"), ("stock_100x1000.nex", "nexus"), ("stock_100x1000.aln", "clustal"),
+               ("lib_phylip_interleaved.phy", "phylip"), ("blackbox/test_min_m_2.infile", "phylip")):
+    try:
+        names, rows = host.read_alignment(GOLD / 'ref_tests' / f, fmt, lib)
+        print(f, len(rows), len(rows[0]))
+    except ValueError as exc:
+        print(f, 'rejected:', str(exc).splitlines()[0])
+print('readers ok')
