@@ -1,0 +1,21 @@
+"""Race detection for the host side (the reference has none): the thread pool and the
+parallel program-build pattern of lvbgpu_api.cpp under ThreadSanitizer, on the CPU."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_parallel_program_build_is_race_free_and_equals_serial(tmp_path):
+    exe = tmp_path / "pool_tsan"
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread",
+                            str(ROOT / "tests" / "native" / "pool_tsan.cpp"), str(ROOT / "lvb_amd" / "csrc" / "program.cpp"),
+                            str(ROOT / "lvb_amd" / "csrc" / "proposals.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in build.stderr.lower():
+        pytest.skip("ThreadSanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
+                         env={"TSAN_OPTIONS": "halt_on_error=1 exitcode=66"})
+    assert run.returncode == 0 and run.stdout.strip() == "ok", (run.returncode, run.stdout[-500:], run.stderr[-3000:])
