@@ -150,6 +150,19 @@ int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_nni, double 
                                uint64_t seed, int64_t *lengths_out);
 int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits,
                           int32_t *info4);
+/* the same with the moves NAMED by the host (a search that draws its own neighbours, e.g. with the
+ * reference's random stream, but wants no host work per candidate beyond 16 bytes): the device turns
+ * each move into its child-pair rewrites and its program, as mutate_nni/spr/tbr + the dirty marking
+ * would, and scores it.  kind 0 NNI: a = internal node u, b = 1 to give away u's right child (0: left;
+ * TreeOperations.c:184-205); kind 1 SPR: a = src, b = dest (256-327); kind 2 TBR: a = src, b = dest,
+ * c = leaf of src's subtree it is re-rooted at, not a child of src (-1, or a subtree of <= 2 leaves: as SPR;
+ * 436-513).  A move the reference's generators could not have made is LVBGPU_E_TOPOLOGY.  Afterwards
+ * lvbgpu_proposal_edits(ctx, b, ...) gives candidate b's rewrites for lvbgpu_commit. */
+typedef struct
+{
+    int32_t kind, a, b, c;
+} lvbgpu_move;
+int lvbgpu_score_moves(lvbgpu_ctx *ctx, int32_t B, const lvbgpu_move *moves, int64_t *lengths_out);
 
 /* B whole topologies scored from the leaf rows alone (every internal node recomputed, nothing
  * resident read or written): left/right are [B][2n-3]. */

@@ -179,6 +179,11 @@ int lvbhost_ref_random_tree(lvbhost_refrng *r, int32_t n, int32_t *left, int32_t
 /* mutate_nni/spr/tbr (kind 0/1/2) of `tree` with the reference's draws, as edits */
 int lvbhost_ref_propose(const lvbhost_tree *tree, lvbhost_refrng *r, int kind, lvbgpu_edit *edits, int32_t cap,
                         int32_t *n_edits);
+/* the same in two halves: draw only the move's parameters (all of the stream consumption), and turn
+ * parameters into edits (no draws).  The parameters are what lvbgpu_score_moves takes. */
+int lvbhost_ref_draw_move(const lvbhost_tree *tree, lvbhost_refrng *r, int kind, lvbgpu_move *out);
+int lvbhost_move_edits(const lvbhost_tree *tree, const lvbgpu_move *move, lvbgpu_edit *edits, int32_t cap,
+                       int32_t *n_edits);
 /* arbreroot (TreeOperations.c:639-656) as edits + the new root */
 int lvbhost_ref_arbreroot(const lvbhost_tree *tree, lvbhost_refrng *r, lvbgpu_edit *edits, int32_t cap,
                           int32_t *n_edits, int32_t *new_root);
@@ -192,7 +197,10 @@ typedef struct
     int64_t min_len_tree;     /* MinimumTreeLength of the alignment */
     int64_t max_trees;        /* -N: stop when the treestack holds this many (0 = keep all) */
     int64_t maxaccept, maxpropose, maxfail; /* 5, 2000, 40 */
-    int64_t reserved[4];
+    int64_t device_moves_min; /* batches at least this long are scored from their 16-byte move parameters
+                                 (lvbgpu_score_moves: the device builds the programs); shorter ones from
+                                 host-built programs (lvbgpu_score_batch).  0: default (128); < 0: never */
+    int64_t reserved[3];
 } lvbhost_refsearch_params;
 
 typedef struct
@@ -206,6 +214,7 @@ typedef struct
     int64_t st_rearrangements;  /* proposals consumed by the starting-temperature search */
     int64_t scored, device_steps;       /* candidates scored / lvbgpu_score_batch calls, overall */
     int64_t st_scored, st_device_steps; /* ... of which while finding t0 */
+    int64_t device_move_steps;          /* steps scored through lvbgpu_score_moves */
     double t_final, seconds, seconds_device;
 } lvbhost_refsearch_result;
 

@@ -34,6 +34,7 @@ class BatchStats(C.Structure):
 
 
 EDIT_DTYPE = np.dtype([("node", np.int32), ("left", np.int32), ("right", np.int32)])
+MOVE_DTYPE = np.dtype([("kind", np.int32), ("a", np.int32), ("b", np.int32), ("c", np.int32)])  # lvbgpu_move
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
@@ -64,6 +65,7 @@ SIGNATURES = {
     "lvbgpu_batch_get_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_batch_free": (None, [C.c_void_p]),
     "lvbgpu_propose_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, _i64p]),
+    "lvbgpu_score_moves": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, _i64p]),
     "lvbgpu_propose_score_mixed": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_uint64,
                                             _i64p]),
     "lvbgpu_proposal_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _i32p]),
@@ -272,6 +274,14 @@ class FitchContext:
     def propose_score_mixed(self, B: int, p_nni: float, p_spr: float, parity: int, seed: int) -> np.ndarray:
         out = np.zeros(B, dtype=np.int64)
         self._chk(self.lib.lvbgpu_propose_score_mixed(self.h, B, p_nni, p_spr, parity, seed, out))
+        return out
+
+    def score_moves(self, moves) -> np.ndarray:
+        """Moves named by the caller (array of MOVE_DTYPE or rows of (kind, a, b, c)) -> lengths."""
+        m = np.ascontiguousarray(moves if getattr(moves, "dtype", None) == MOVE_DTYPE
+                                 else np.array([tuple(int(v) for v in row) for row in moves], dtype=MOVE_DTYPE))
+        out = np.zeros(len(m), dtype=np.int64)
+        self._chk(self.lib.lvbgpu_score_moves(self.h, len(m), m.ctypes.data, out))
         return out
 
     def proposal_edits(self, b: int):

@@ -70,6 +70,14 @@ struct lvbgpu_edit_dev
 {
     int32_t node, left, right;
 };
+// a move named by the host (lvbgpu_score_moves): NNI a = internal node u, b = 1 to swap out u's right
+// child; SPR a = src, b = dest; TBR a = src, b = dest, c = leaf the moved subtree is re-rooted at
+// (-1: as SPR).  Same layout as lvbgpu_move in include/lvbgpu.h.
+struct lvbgpu_move_dev
+{
+    int32_t kind, a, b, c;
+};
+
 struct ProposalInfo
 {
     int32_t kind;     // 0 NNI, 1 SPR, 2 TBR
@@ -83,7 +91,8 @@ struct ProposalInfo
 hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
                           uint64_t seed, uint32_t B,
                           uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                          CandDesc *cands, ProposalInfo *info, hipStream_t stream);
+                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves,
+                          hipStream_t stream);
 
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();

@@ -163,6 +163,8 @@ struct lvbgpu_ctx
     lvbgpu_batch *prop_batch = nullptr;
     DevBuf d_topo4, d_pedits, d_pinfo;
     PinBuf h_pinfo;
+    DevBuf d_moves; // moves named by the host (lvbgpu_score_moves)
+    PinBuf h_moves;
     uint64_t d_topo_version = ~0ull;
     uint32_t p_stride_t = 0, p_stride_e = 0;
     int32_t p_B = 0; // candidates of the last device batch (0: none)
@@ -492,6 +494,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->d_pedits.release();
     ctx->d_pinfo.release();
     ctx->h_pinfo.release();
+    ctx->d_moves.release();
+    ctx->h_moves.release();
     for (lvbgpu_batch *rb : {ctx->step_batch, ctx->full_batch, ctx->prop_batch})
         if (rb)
         {
@@ -1097,8 +1101,47 @@ int sync_device_topology(lvbgpu_ctx *ctx)
 
 namespace
 {
+// why a move named by the host cannot be made on this topology (nullptr: it can).  Same conditions
+// as the generators (mutate_nni / mutate_spr / mutate_tbr, TreeOperations.c:174, 256-271, 450-461).
+const char *move_defect(const Topology &t, const lvbgpu_move &m)
+{
+    const int32_t n = t.n, nb = t.nb, root = t.root;
+    if (m.kind == 0)
+        return (m.a >= n && m.a < nb) ? nullptr : "NNI needs an internal node";
+    if (m.kind != 1 && m.kind != 2)
+        return "kind must be 0 (NNI), 1 (SPR) or 2 (TBR)";
+    const int32_t src = m.a, dest = m.b;
+    if (src < 0 || src >= nb || dest < 0 || dest >= nb)
+        return "node out of range";
+    if (src == root || src == t.left[root] || src == t.right[root])
+        return "the root and its children cannot be pruned";
+    const int32_t sp = t.parent[src];
+    const int32_t ss = t.left[sp] == src ? t.right[sp] : t.left[sp];
+    if (dest == src || dest == sp || dest == ss || dest == root)
+        return "destination is the source, its parent, its sister or the root";
+    for (int32_t p = t.parent[dest]; p != UNSET; p = t.parent[p])
+        if (p == src)
+            return "destination lies inside the pruned subtree";
+    if (m.kind == 2 && m.c >= 0)
+    {
+        const int32_t x = m.c;
+        if (x >= n || x == t.left[src] || x == t.right[src])
+            return "TBR re-roots at a leaf that is not a child of the subtree's top";
+        bool inside = false;
+        for (int32_t p = t.parent[x]; p != UNSET; p = t.parent[p])
+            if (p == src)
+            {
+                inside = true;
+                break;
+            }
+        if (!inside)
+            return "TBR leaf lies outside the pruned subtree";
+    }
+    return nullptr;
+}
+
 int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a, uint32_t mix_b, uint64_t seed,
-                       int64_t *lengths_out)
+                       int64_t *lengths_out, const lvbgpu_move *moves = nullptr)
 {
     if (!ctx || B < 1 || kind < -3 || kind > 2 || !lengths_out)
         return LVBGPU_E_ARG;
@@ -1144,11 +1187,25 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     ctx->p_stride_t = stride_t;
     ctx->p_stride_e = stride_e;
     ctx->p_B = 0;
+    const lvbgpu_move_dev *d_moves = nullptr;
+    if (moves)
+    {
+        static_assert(sizeof(lvbgpu_move) == sizeof(lvbgpu_move_dev), "move layout");
+        for (int32_t b = 0; b < B; b++)
+            if (const char *why = move_defect(ctx->topo, moves[b]))
+                return ctx->fail(LVBGPU_E_TOPOLOGY, "move " + std::to_string(b) + ": " + why);
+        HIPCHK(ctx, ctx->d_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
+        HIPCHK(ctx, ctx->h_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
+        memcpy(ctx->h_moves.p, moves, (size_t)B * sizeof(lvbgpu_move)); // pinned staging: the caller's array may go away
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_moves.p, ctx->h_moves.p, (size_t)B * sizeof(lvbgpu_move), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        d_moves = (const lvbgpu_move_dev *)ctx->d_moves.p;
+    }
     HIPCHK(ctx, launch_propose((const int32_t *)ctx->d_topo4.p, (int32_t)ctx->n, ctx->topo.root, kind, mix_a, mix_b, seed,
                                (uint32_t)B,
                                stride_t, stride_e, (uint32_t *)((char *)bt->d_prog.p + o_t),
                                (int32_t *)((char *)bt->d_prog.p + o_d), (lvbgpu_edit_dev *)ctx->d_pedits.p,
-                               (CandDesc *)bt->d_prog.p, (ProposalInfo *)ctx->d_pinfo.p, ctx->stream));
+                               (CandDesc *)bt->d_prog.p, (ProposalInfo *)ctx->d_pinfo.p, d_moves, ctx->stream));
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
         return rc;
@@ -1180,6 +1237,13 @@ extern "C" int lvbgpu_propose_score(lvbgpu_ctx *ctx, int32_t B, int32_t kind, ui
     if (kind < -1)
         return LVBGPU_E_ARG;
     return propose_score_impl(ctx, B, kind, 0, 0, seed, lengths_out);
+}
+
+extern "C" int lvbgpu_score_moves(lvbgpu_ctx *ctx, int32_t B, const lvbgpu_move *moves, int64_t *lengths_out)
+{
+    if (!moves)
+        return LVBGPU_E_ARG;
+    return propose_score_impl(ctx, B, 0, 0, 0, 0, lengths_out, moves);
 }
 
 extern "C" int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_nni, double p_spr, int64_t parity,

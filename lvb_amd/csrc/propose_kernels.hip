@@ -151,7 +151,7 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
                                int32_t n, int32_t root, int32_t kind_all, uint32_t mix_a, uint32_t mix_b,
                                uint64_t seed, uint32_t B, uint32_t stride_t,
                                uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                               CandDesc *cands, ProposalInfo *info, int32_t use_lds)
+                               CandDesc *cands, ProposalInfo *info, int32_t use_lds, const lvbgpu_move_dev *moves)
 {
     // The walk below is pointer chasing (two root-ward paths, a random descent for TBR): from global
     // memory every step is an L2 round trip.  When the four arrays fit, the block first copies them
@@ -189,6 +189,14 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
         const uint32_t r = (uint32_t)(rng.next() >> 32);
         kind = r < mix_a ? 0 : (r < mix_b ? 1 : 2);
     }
+    // moves != nullptr: nothing is drawn, candidate b IS moves[b] (validated by the host side of
+    // lvbgpu_score_moves); everything after the draws is shared
+    lvbgpu_move_dev given{0, -1, -1, -1};
+    if (moves)
+    {
+        given = moves[b];
+        kind = given.kind;
+    }
     ProposalInfo pi{kind, -1, -1, -1, 0, 0, 0, 0};
 
     int32_t last = -1; // top node of the chain that reaches the root
@@ -196,8 +204,8 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
     if (kind == 0)
     {
         // ---- NNI: u any internal node, v its parent, swap one child of u with u's sister
-        const int32_t u = n + (int32_t)rng.below((uint32_t)(t.nb - n));
-        const bool swap_right = (rng.next() >> 63) != 0;
+        const int32_t u = moves ? given.a : n + (int32_t)rng.below((uint32_t)(t.nb - n));
+        const bool swap_right = moves ? given.b != 0 : (rng.next() >> 63) != 0;
         const int32_t v = t.parent[u], a = t.left[u], bb = t.right[u], c = t.sister(u);
         const int32_t keep = swap_right ? a : bb, moved = swap_right ? bb : a;
         pi.a = u;
@@ -233,18 +241,21 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
     {
         // ---- SPR / TBR: prune src (with its parent sp), graft on the edge above dest
         // every draw loop is bounded: a tree with no admissible move must not hang the GPU
-        int32_t src, dest = -1;
+        int32_t src = given.a, dest = given.b;
         int tries = 0;
-        do
-            src = (int32_t)rng.below((uint32_t)t.nb);
-        while ((src == root || src == t.left[root] || src == t.right[root]) && ++tries < 4096);
-        if (tries >= 4096)
+        if (!moves)
         {
-            e.overflow = true;
-            src = t.left[t.left[root] >= n ? t.left[root] : t.right[root]];
+            do
+                src = (int32_t)rng.below((uint32_t)t.nb);
+            while ((src == root || src == t.left[root] || src == t.right[root]) && ++tries < 4096);
+            if (tries >= 4096)
+            {
+                e.overflow = true;
+                src = t.left[t.left[root] >= n ? t.left[root] : t.right[root]];
+            }
         }
         const int32_t sp = t.parent[src], ss = t.sister(src), pp = t.parent[sp];
-        for (tries = 0; tries < 65536; tries++)
+        for (tries = moves ? 65536 : 0; tries < 65536; tries++)
         {
             dest = (int32_t)rng.below((uint32_t)t.nb);
             if (dest == src || dest == sp || dest == ss || dest == root)
@@ -259,7 +270,7 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             if (!below)
                 break;
         }
-        if (tries >= 65536)
+        if (!moves && tries >= 65536)
         {
             // no admissible destination found: emit nothing usable
             CandDesc none{};
@@ -278,20 +289,23 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
         int32_t buf1[MAX_PATH], buf2[MAX_PATH]; // root-ward paths (thread-private scratch)
         int32_t top = src;   // what hangs under sp next to dest
         bool have_acc = false; // a chain inside the moved subtree already feeds sp
-        if (kind == 2 && t.leaves[src] > 2)
+        if (kind == 2 && t.leaves[src] > 2 && !(moves && given.c < 0))
         {
             // TBR: re-root the moved subtree on the edge above a random leaf x (not a child of src)
-            int32_t x;
+            int32_t x = given.c;
             int xt = 0;
-            do
+            if (!moves)
             {
-                x = src;
-                while (t.left[x] >= 0)
+                do
                 {
-                    const int32_t l = t.left[x];
-                    x = rng.below((uint32_t)t.leaves[x]) < (uint32_t)t.leaves[l] ? l : t.right[x];
-                }
-            } while ((x == t.left[src] || x == t.right[src]) && ++xt < 4096);
+                    x = src;
+                    while (t.left[x] >= 0)
+                    {
+                        const int32_t l = t.left[x];
+                        x = rng.below((uint32_t)t.leaves[x]) < (uint32_t)t.leaves[l] ? l : t.right[x];
+                    }
+                } while ((x == t.left[src] || x == t.right[src]) && ++xt < 4096);
+            }
             if (xt >= 4096)
                 e.overflow = true;
             pi.c = x;
@@ -512,7 +526,7 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
 hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
                           uint64_t seed, uint32_t B,
                           uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                          CandDesc *cands, ProposalInfo *info, hipStream_t stream)
+                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves, hipStream_t stream)
 {
     const int32_t nb = 2 * n - 3;
     // the topology in LDS when it fits (16 bytes per node; 160 KB of LDS per CU): up to ~5000 taxa
@@ -530,7 +544,7 @@ hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t
     }
     hipLaunchKernelGGL(propose_kernel, dim3((B + 63) / 64), dim3(64), lds, stream, topo4, topo4 + nb, topo4 + 2 * nb,
                        topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts, edits, cands,
-                       info, use_lds);
+                       info, use_lds, moves);
     return hipGetLastError();
 }
 

@@ -51,11 +51,17 @@ inline double since(Clock::time_point t0) { return std::chrono::duration<double>
 
 // ---- proposals drawn the reference's way ----------------------------------------------------
 
+// A move as its parameters (lvbgpu_move): NNI a = u, b = 1 if u's right child is given away; SPR
+// a = src, b = dest; TBR a = src, b = dest, c = the leaf the subtree is re-rooted at (-1: as SPR).
+// Drawing consumes the stream exactly as the reference's generators do; turning a move into edits
+// (or handing it to the device, lvbgpu_score_moves) draws nothing.
+using Move = lvbgpu_move;
+
 // mutate_nni (TreeOperations.c:174, 184): one randpint for the internal branch, one uni for the side
-int draw_nni(const Topology &t, Uni &g, std::vector<Edit> &out)
+Move draw_nni(const Topology &t, Uni &g)
 {
     const int32_t u = (int32_t)g.randpint(t.nb - t.n - 1) + t.n;
-    return nni_edits(t, u, g.uni() < 0.5, out);
+    return Move{MOVE_NNI, u, g.uni() < 0.5 ? 1 : 0, -1};
 }
 
 // the two rejection loops shared by mutate_spr and mutate_tbr (256-271 / 367-382)
@@ -69,16 +75,16 @@ void draw_src_dest(const Topology &t, Uni &g, int32_t &src, int32_t &dest)
     while (!spr_move_allowed(t, src, dest));
 }
 
-int draw_spr(const Topology &t, Uni &g, std::vector<Edit> &out)
+Move draw_spr(const Topology &t, Uni &g)
 {
     int32_t src, dest;
     draw_src_dest(t, g, src, dest);
-    return spr_edits(t, src, dest, out);
+    return Move{MOVE_SPR, src, dest, -1};
 }
 
 // mutate_tbr: as SPR, then (subtrees of more than two leaves only) re-root the moved subtree at a
 // random leaf that is not a child of its top (439-461)
-int draw_tbr(const Topology &t, Uni &g, std::vector<Edit> &out, std::vector<int32_t> &leaves)
+Move draw_tbr(const Topology &t, Uni &g, std::vector<int32_t> &leaves)
 {
     int32_t src, dest;
     draw_src_dest(t, g, src, dest);
@@ -86,22 +92,36 @@ int draw_tbr(const Topology &t, Uni &g, std::vector<Edit> &out, std::vector<int3
     subtree_leaves(t, src, leaves);
     const int64_t size = (int64_t)leaves.size();
     if (size <= 2)
-        return spr_edits(t, src, dest, out);
+        return Move{MOVE_TBR, src, dest, -1};
     int32_t x;
     do
         x = leaves[(size_t)g.randpint(size - 1)];
     while (x == t.left[src] || x == t.right[src]);
-    return tbr_edits(t, src, dest, x, out);
+    return Move{MOVE_TBR, src, dest, x};
+}
+
+Move draw_move_params(const Topology &t, int kind, Uni &g, std::vector<int32_t> &scratch)
+{
+    switch (kind)
+    {
+    case MOVE_NNI: return draw_nni(t, g);
+    case MOVE_SPR: return draw_spr(t, g);
+    default: return draw_tbr(t, g, scratch);
+    }
+}
+
+int move_edits(const Topology &t, const Move &m, std::vector<Edit> &out)
+{
+    if (m.kind == MOVE_NNI)
+        return nni_edits(t, m.a, m.b != 0, out);
+    if (m.kind == MOVE_SPR || m.c < 0)
+        return spr_edits(t, m.a, m.b, out);
+    return tbr_edits(t, m.a, m.b, m.c, out);
 }
 
 int draw_move(const Topology &t, int kind, Uni &g, std::vector<Edit> &out, std::vector<int32_t> &scratch)
 {
-    switch (kind)
-    {
-    case MOVE_NNI: return draw_nni(t, g, out);
-    case MOVE_SPR: return draw_spr(t, g, out);
-    default: return draw_tbr(t, g, out, scratch);
-    }
+    return move_edits(t, draw_move_params(t, kind, g, scratch), out);
 }
 
 // arbreroot (TreeOperations.c:639-656)
@@ -349,9 +369,12 @@ struct Driver
         Uni after;   // stream state after this proposal's own draws
     };
     std::vector<Cand> cands;
-    std::vector<Edit> edits;
+    std::vector<Move> moves;  // every proposal of the batch as parameters
+    std::vector<Edit> edits;  // ... and, for batches scored from host-built programs, as edits
     std::vector<int32_t> offs, scratch;
     std::vector<int64_t> lens;
+    int32_t device_moves_min = 128; // batches at least this long go to lvbgpu_score_moves (< 0: never)
+    int64_t device_move_steps = 0;
     // accounting
     int64_t scored = 0, steps = 0, commits = 0, reroots = 0;
     double dev_seconds = 0.0;
@@ -386,14 +409,12 @@ struct Driver
     void begin_batch()
     {
         cands.clear();
-        edits.clear();
-        offs.assign(1, 0);
+        moves.clear();
     }
     // draw one more proposal of `kind` against the current tree and assume it will be rejected
     void speculate(int kind, double rv)
     {
-        draw_move(topo, kind, rng, edits, scratch);
-        offs.push_back((int32_t)edits.size());
+        moves.push_back(draw_move_params(topo, kind, rng, scratch));
         cands.push_back({kind, rv, rng});
         (void)rng.uni(); // the rejected proposal's acceptance draw
     }
@@ -401,10 +422,29 @@ struct Driver
     {
         const int32_t B = (int32_t)cands.size();
         lens.resize((size_t)B);
-        const auto t0 = Clock::now();
-        const int rc = lvbgpu_score_batch(ctx, B, offs.data(), reinterpret_cast<const lvbgpu_edit *>(edits.data()),
-                                          nullptr, lens.data());
-        dev_seconds += since(t0);
+        int rc;
+        if (device_moves_min >= 0 && B >= device_moves_min)
+        {
+            // long batch: 16 bytes per proposal go to the device, which builds the programs itself
+            const auto t0 = Clock::now();
+            rc = lvbgpu_score_moves(ctx, B, moves.data(), lens.data());
+            dev_seconds += since(t0);
+            device_move_steps++;
+        }
+        else
+        {
+            edits.clear();
+            offs.assign(1, 0);
+            for (const Move &m : moves)
+            {
+                move_edits(topo, m, edits);
+                offs.push_back((int32_t)edits.size());
+            }
+            const auto t0 = Clock::now();
+            rc = lvbgpu_score_batch(ctx, B, offs.data(), reinterpret_cast<const lvbgpu_edit *>(edits.data()), nullptr,
+                                    lens.data());
+            dev_seconds += since(t0);
+        }
         scored += B;
         steps++;
         return rc;
@@ -430,7 +470,9 @@ struct Driver
     }
     int accept(int32_t b)
     {
-        const int rc = commit(edits.data() + offs[(size_t)b], offs[(size_t)b + 1] - offs[(size_t)b], -1);
+        std::vector<Edit> e;
+        move_edits(topo, moves[(size_t)b], e); // the accepted move's rewrites, on the host either way
+        const int rc = commit(e.data(), (int32_t)e.size(), -1);
         cur_len = lens[(size_t)b];
         return rc;
     }
@@ -558,6 +600,40 @@ extern "C" int lvbhost_ref_propose(const lvbhost_tree *t, lvbhost_refrng *r, int
     return LVBGPU_OK;
 }
 
+extern "C" int lvbhost_ref_draw_move(const lvbhost_tree *t, lvbhost_refrng *r, int kind, lvbgpu_move *out)
+{
+    if (!t || !r || !out || kind < 0 || kind > 2)
+        return LVBGPU_E_ARG;
+    std::vector<int32_t> scratch;
+    *out = draw_move_params(t->topo, kind, r->g, scratch);
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbhost_move_edits(const lvbhost_tree *t, const lvbgpu_move *m, lvbgpu_edit *edits, int32_t cap,
+                                  int32_t *n_edits)
+{
+    if (!t || !m || !edits || !n_edits || m->kind < 0 || m->kind > 2)
+        return LVBGPU_E_ARG;
+    const Topology &tp = t->topo;
+    // the deterministic forms index the arrays with what they are given: check it first
+    if (m->kind == MOVE_NNI ? (m->a < tp.n || m->a >= tp.nb) : !spr_move_allowed(tp, m->a, m->b))
+        return LVBGPU_E_TOPOLOGY;
+    if (m->kind == MOVE_TBR && m->c >= 0)
+    {
+        std::vector<int32_t> leaves;
+        subtree_leaves(tp, m->a, leaves);
+        if (std::find(leaves.begin(), leaves.end(), m->c) == leaves.end() || m->c == tp.left[m->a] || m->c == tp.right[m->a])
+            return LVBGPU_E_TOPOLOGY;
+    }
+    std::vector<Edit> out;
+    move_edits(tp, *m, out);
+    if ((int32_t)out.size() > cap)
+        return LVBGPU_E_ARG;
+    memcpy(edits, out.data(), out.size() * sizeof(Edit));
+    *n_edits = (int32_t)out.size();
+    return LVBGPU_OK;
+}
+
 extern "C" int lvbhost_ref_arbreroot(const lvbhost_tree *t, lvbhost_refrng *r, lvbgpu_edit *edits, int32_t cap,
                                      int32_t *n_edits, int32_t *new_root)
 {
@@ -606,6 +682,7 @@ extern "C" int lvbhost_reference_search(lvbgpu_ctx *ctx, const lvbhost_refsearch
     d.ctx = ctx;
     d.max_batch = std::min<int32_t>(p->max_batch, (int32_t)REROOT_INTERVAL - 1);
     d.min_len = (double)p->min_len_tree;
+    d.device_moves_min = p->device_moves_min == 0 ? 128 : (int32_t)std::min<int64_t>(p->device_moves_min, 1 << 30);
     d.pb.resize(2 * n - 3);
     if (!d.rng.seed(p->seed))
         return LVBGPU_E_ARG;
@@ -764,6 +841,7 @@ extern "C" int lvbhost_reference_search(lvbgpu_ctx *ctx, const lvbhost_refsearch
     res->device_steps = d.steps;
     res->accepted_moves = accepted_moves;
     res->reroots = d.reroots;
+    res->device_move_steps = d.device_move_steps;
     res->temperatures = st.t_n;
     res->t_final = st.t;
     res->seconds = since(wall0);

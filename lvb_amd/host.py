@@ -40,7 +40,7 @@ class RefSearchParams(C.Structure):
     _fields_ = [("seed", C.c_int32), ("algorithm", C.c_int32), ("cooling_schedule", C.c_int32),
                 ("max_batch", C.c_int32), ("min_len_tree", C.c_int64), ("max_trees", C.c_int64),
                 ("maxaccept", C.c_int64), ("maxpropose", C.c_int64), ("maxfail", C.c_int64),
-                ("reserved", C.c_int64 * 4)]
+                ("device_moves_min", C.c_int64), ("reserved", C.c_int64 * 3)]
 
 
 class RefSearchResult(C.Structure):
@@ -48,7 +48,8 @@ class RefSearchResult(C.Structure):
                 ("start_length", C.c_int64), ("final_length", C.c_int64), ("accepted_moves", C.c_int64),
                 ("reroots", C.c_int64), ("temperatures", C.c_int64), ("st_rearrangements", C.c_int64),
                 ("scored", C.c_int64), ("device_steps", C.c_int64), ("st_scored", C.c_int64),
-                ("st_device_steps", C.c_int64), ("t_final", C.c_double), ("seconds", C.c_double),
+                ("st_device_steps", C.c_int64), ("device_move_steps", C.c_int64), ("t_final", C.c_double),
+                ("seconds", C.c_double),
                 ("seconds_device", C.c_double)]
 
 
@@ -96,6 +97,8 @@ SIGNATURES = {
     "lvbhost_refrng_randpint": (C.c_int64, [C.c_void_p, C.c_int64]),
     "lvbhost_ref_random_tree": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p]),
     "lvbhost_ref_propose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lvbhost_ref_draw_move": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "lvbhost_move_edits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbhost_ref_arbreroot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),
     "lvbhost_refsearch_defaults": (None, [C.POINTER(RefSearchParams)]),
@@ -258,6 +261,24 @@ class HostTree:
         rc = self.lib.lvbhost_ref_propose(self.h, rng.h, int(kind), buf.ctypes.data, cap, C.byref(k))
         if rc != 0:
             raise api.LvbGpuError(rc, "ref_propose")
+        return buf[: k.value].copy()
+
+    def ref_draw_move(self, rng: "RefRng", kind: int) -> tuple[int, int, int, int]:
+        """Parameters (kind, a, b, c) of one mutate_nni/spr/tbr draw: all of its stream consumption."""
+        mv = np.zeros(1, dtype=api.MOVE_DTYPE)
+        rc = self.lib.lvbhost_ref_draw_move(self.h, rng.h, int(kind), mv.ctypes.data)
+        if rc != 0:
+            raise api.LvbGpuError(rc, "ref_draw_move")
+        return tuple(int(mv[0][k]) for k in ("kind", "a", "b", "c"))
+
+    def move_edits(self, move) -> np.ndarray:
+        mv = np.array([tuple(int(v) for v in move)], dtype=api.MOVE_DTYPE)
+        cap = 2 * self.nbranches + 8
+        buf = np.zeros(cap, dtype=api.EDIT_DTYPE)
+        k = C.c_int32()
+        rc = self.lib.lvbhost_move_edits(self.h, mv.ctypes.data, buf.ctypes.data, cap, C.byref(k))
+        if rc != 0:
+            raise api.LvbGpuError(rc, "move cannot be made on this tree")
         return buf[: k.value].copy()
 
     def ref_arbreroot(self, rng: "RefRng") -> tuple[np.ndarray, int]:

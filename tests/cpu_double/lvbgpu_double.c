@@ -147,6 +147,11 @@ int lvbgpu_propose_score_mixed(lvbgpu_ctx *c, int32_t B, double a, double b, int
     (void)c, (void)B, (void)a, (void)b, (void)p, (void)seed, (void)l;
     return LVBGPU_E_NODEVICE;
 }
+int lvbgpu_score_moves(lvbgpu_ctx *c, int32_t B, const lvbgpu_move *m, int64_t *l)
+{
+    (void)c, (void)B, (void)m, (void)l;
+    return LVBGPU_E_NODEVICE;
+}
 int lvbgpu_allreduce_min(lvbgpu_ctx *c, int64_t *v, int32_t *r)
 {
     (void)c, (void)v, (void)r;

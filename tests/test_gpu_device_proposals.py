@@ -103,3 +103,66 @@ def test_move_schedules_of_the_reference(mods):
     with pytest.raises(api.LvbGpuError):
         ctx.propose_score_mixed(B, 0.8, 0.5, -1, 7)
     ctx.close()
+
+
+def _as_map(edits):
+    return {int(e["node"]): (int(e["left"]), int(e["right"])) for e in edits}
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_moves_named_by_the_host_score_and_rewrite_exactly_like_host_generators(kind):
+    """lvbgpu_score_moves: the device turns (kind, a, b, c) into rewrites + program.  Lengths must equal
+    lvbgpu_score_batch on the host generators' edits for the same moves, and the rewrites the device
+    reports must be those edits child for child, side for side (a search that reproduces the reference's
+    trajectory indexes nodes and sides by number)."""
+    from lvb_amd import api, host
+    n, m, B = 60, 700, 512
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 21))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=5)
+    tree.upload(ctx)
+    rng = host.RefRng(1234)
+    try:
+        for round_ in range(3):
+            # draw moves with the reference's generators on the host: parameters, and their edits
+            moves = [tree.ref_draw_move(rng, kind) for _ in range(B)]
+            cands = [tree.move_edits(mv) for mv in moves]
+            got = ctx.score_moves(moves)
+            want = ctx.score_batch(cands)
+            assert np.array_equal(got, want)
+            for b in (0, 1, B // 2, B - 1):
+                dev_edits, info = ctx.proposal_edits(b)
+                assert _as_map(dev_edits) == _as_map(cands[b]), (moves[b], info)
+            # accept one through the device's own rewrites and go on from the new tree
+            dev_edits, _ = ctx.proposal_edits(7)
+            assert ctx.commit(dev_edits) == got[7]
+            tree.apply(dev_edits)
+    finally:
+        ctx.close()
+
+
+def test_moves_the_generators_could_not_make_are_refused():
+    from lvb_amd import api, host
+    n = 12
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, 64, 2))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=2)
+    tree.upload(ctx)
+    p, l, r = tree.arrays()
+    root = tree.root
+    internal = next(v for v in range(n, 2 * n - 3) if p[v] != root and l[v] >= n)
+    try:
+        bad = [(0, 3, 0, -1),                      # NNI at a leaf
+               (1, root, internal, -1),            # prune the root
+               (1, int(l[root]), internal, -1),    # prune a child of the root
+               (1, internal, internal, -1),        # graft on itself
+               (1, internal, int(l[internal]), -1),  # graft inside the pruned subtree
+               (2, internal, root, -1),            # graft on the root
+               (2, internal, int(p[internal]), 0),  # graft on its own parent
+               (7, 0, 0, 0)]
+        for mv in bad:
+            with pytest.raises(api.LvbGpuError) as ei:
+                ctx.score_moves([mv])
+            assert ei.value.status == -6, mv
+    finally:
+        ctx.close()

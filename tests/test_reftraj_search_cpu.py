@@ -34,6 +34,7 @@ def run_case(case, lib, new_ctx, free_ctx, max_batch=None):
         p.cooling_schedule = 0 if case["cooling"] == "g" else 1
         p.min_len_tree = min_len
         p.max_trees = case.get("max_trees", 0)
+        p.device_moves_min = -1  # the test double has no device to build programs on
         if max_batch:
             p.max_batch = max_batch
         res, tree = host.reference_search(ctx, p, lib)

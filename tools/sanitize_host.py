@@ -20,7 +20,7 @@ for case in cases:
     enc = binding.encode_rows(rows)
     ctx = C.c_void_p(lib.lvbgpu_double_new(enc.shape[0], enc.shape[1], np.ascontiguousarray(enc)))
     p = host.refsearch_defaults(lib); p.seed, p.algorithm, p.min_len_tree = case['seed'], case['algorithm'], ml
-    p.cooling_schedule = 0 if case['cooling'] == 'g' else 1; p.max_trees = case['max_trees']
+    p.cooling_schedule = 0 if case['cooling'] == 'g' else 1; p.max_trees = case['max_trees']; p.device_moves_min = -1
     res, tree = host.reference_search(ctx, p, lib)
     assert res['rearrangements'] == case['expect']['rearrangements'], (case, res)
     n = len(tree.best_trees())
