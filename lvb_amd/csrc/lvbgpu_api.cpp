@@ -1191,9 +1191,34 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     if (moves)
     {
         static_assert(sizeof(lvbgpu_move) == sizeof(lvbgpu_move_dev), "move layout");
-        for (int32_t b = 0; b < B; b++)
-            if (const char *why = move_defect(ctx->topo, moves[b]))
-                return ctx->fail(LVBGPU_E_TOPOLOGY, "move " + std::to_string(b) + ": " + why);
+        // admissibility is an O(depth) walk per move: spread it over the host threads for long batches
+        int T = 1;
+        if (B >= 8192) // measured: waking the pool costs more than it saves below that
+        {
+            if (!ctx->pool && host_threads() > 1)
+                ctx->pool = new (std::nothrow) Pool(host_threads());
+            if (ctx->pool)
+                T = std::max(1, std::min(ctx->pool->size(), B / 1024));
+        }
+        std::vector<int32_t> first_bad((size_t)T, -1);
+        auto check = [&](int t) {
+            for (int32_t b = (int32_t)((int64_t)B * t / T); b < (int32_t)((int64_t)B * (t + 1) / T); b++)
+                if (move_defect(ctx->topo, moves[b]))
+                {
+                    first_bad[(size_t)t] = b;
+                    return;
+                }
+        };
+        if (T == 1)
+            check(0);
+        else
+            ctx->pool->run(T, check);
+        for (int t = 0; t < T; t++)
+            if (first_bad[(size_t)t] >= 0)
+            {
+                const int32_t b = first_bad[(size_t)t];
+                return ctx->fail(LVBGPU_E_TOPOLOGY, "move " + std::to_string(b) + ": " + move_defect(ctx->topo, moves[b]));
+            }
         HIPCHK(ctx, ctx->d_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
         HIPCHK(ctx, ctx->h_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
         memcpy(ctx->h_moves.p, moves, (size_t)B * sizeof(lvbgpu_move)); // pinned staging: the caller's array may go away

@@ -45,3 +45,18 @@ for B in (256, 1024, 4096, 16384, 65536):
         ctx.propose_score(B, 1, 100 + r)
     dt = (time.perf_counter() - t0) / reps
     print(f"B={B}: {1e6*dt:.0f} us/step -> {B/dt/1e6:.2f} M candidates/s end to end")
+
+print("moves named by the host (lvbgpu_score_moves: 16 B per candidate up, the device builds rewrites + programs):")
+rng = host.RefRng(5)
+for B in (256, 1024, 4096, 16384):
+    t0 = time.perf_counter()
+    moves = np.array([tree.ref_draw_move(rng, 1) for _ in range(B)], dtype=api.MOVE_DTYPE)
+    t_draw = time.perf_counter() - t0
+    out = np.zeros(B, dtype=np.int64)
+    for _ in range(3):
+        ctx._chk(ctx.lib.lvbgpu_score_moves(ctx.h, B, moves.ctypes.data, out))
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ctx._chk(ctx.lib.lvbgpu_score_moves(ctx.h, B, moves.ctypes.data, out))
+    dt = (time.perf_counter() - t0) / 20
+    print(f"B={B}: {1e6*dt:.0f} us/step -> {B/dt/1e6:.2f} M candidates/s (drawing them in Python took {1e3*t_draw:.1f} ms)")
