@@ -4,7 +4,7 @@ sites: 2397 rows x 2 MiB = 5.0 GB resident), checked against the C oracle (test 
 GPU box: full evaluation, a batch of SPR/TBR candidates scored incrementally, one commit, node sets of
 the highest rows.  One JSON line.  Not a pytest: it needs ~12 GB of host memory and a few minutes.
 
-    gpurun -- python tools/big_parity.py
+    gpurun -- python tests/manual/big_parity.py
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 
 

@@ -3,7 +3,7 @@
 JSON line: both wall times, the numbers both programs report, and whether the output trees are
 byte-identical.  Needs oracle/_ref (built here by oracle/Makefile; it travels to the GPU box).
 
-    python tools/exact_vs_reference.py --taxa 200 --sites 20000 --seed 77 -a 1
+    python tests/manual/exact_vs_reference.py --taxa 200 --sites 20000 --seed 77 -a 1
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ import tempfile
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 
 

@@ -1,9 +1,9 @@
 """Host logic under AddressSanitizer + UBSan (CPU only: the pool has no GPU sanitizers).  Driven by
-tools/sanitize_host.sh, which builds the host sources against the scorer's test double
+tests/manual/sanitize_host.sh, which builds the host sources against the scorer's test double
 (tests/cpu_double) with -fsanitize=address,undefined and preloads the runtimes: whole
 reference-trajectory runs, the program builder under random moves, the alignment readers."""
 import sys, json, ctypes as C, numpy as np
-sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent.parent))
 from lvb_amd import host
 from oracle import binding
 from pathlib import Path
@@ -11,7 +11,7 @@ lib = host.bind(C.CDLL(sys.argv[1]))
 lib.lvbgpu_double_new.restype = C.c_void_p
 lib.lvbgpu_double_new.argtypes = [C.c_long, C.c_long, np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")]
 lib.lvbgpu_double_free.argtypes = [C.c_void_p]
-GOLD = Path(__file__).resolve().parent.parent / 'tests' / 'golden'
+GOLD = Path(__file__).resolve().parent.parent / 'golden'
 cases = json.loads((GOLD / 'ref_trajectories.json').read_text())['cases']
 for case in cases:
     if case['expect']['rearrangements'] > 100000: continue
