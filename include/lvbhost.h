@@ -111,6 +111,8 @@ typedef struct
     uint64_t seed;
     int32_t algorithm;        /* 0: alternate NNI/SPR (reference -a 0, Solve.c:288-297);
                                  1: TBR with probability t/t0, else NNI/SPR (-a 1, Solve.c:421-426);
+                                 2: probabilities from the three move counters (-a 2, Solve.c:253-259, 452-466;
+                                    refreshed per batch);
                                  10/11/12: NNI only / SPR only / TBR only */
     int32_t cooling_schedule; /* 0 geometric (0.99^n t0), 1 linear (Solve.c:409-443) */
     int32_t batch;            /* candidates scored per device step (speculative) */

@@ -295,6 +295,16 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
     int64_t iter = 0;         // Anneal's `iter` (alternation), also our consumed-proposal count
     int64_t current_iter = 0; // *current_iter (re-root ticks)
     double probs[3] = {0, 0, 0}; // trops_probs, Solve.c:210: every proposal is TBR until the first cooling step
+    // -a 2 (Solve.c:253-259, 452-466): probabilities follow three counters; in the reference the two
+    // kinds NOT tried gain half a count every iteration (its changeAcc flag is only ever set for -a 1)
+    double counter[3] = {1, 1, 1};
+    auto probs_from_counters = [&] {
+        const long total = (long)(counter[0] + counter[1] + counter[2]); // a long there too
+        for (int i = 0; i < 3; i++)
+            probs[i] = counter[i] / total;
+    };
+    if (p.algorithm == 2)
+        probs_from_counters();
     auto log_point = [&]() {
         if (log_seconds && log_best && res->n_log < p.log_cap)
         {
@@ -335,6 +345,8 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
         if (p.max_proposals > 0)
             room = std::min(room, std::max<int64_t>(1, p.max_proposals - iter));
         const int B = (int)std::max<int64_t>(1, room);
+        if (p.algorithm == 2)
+            probs_from_counters(); // per batch here, per iteration in the reference
 
         // drawing on the device pays once the batch is large (its fixed cost per step is higher,
         // its cost per candidate ~10x lower): mode 2 switches per step
@@ -352,7 +364,7 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
             if (rc != LVBGPU_OK)
                 return rc;
         }
-        ch.kinds.resize(B);
+        ch.kinds.assign(B, -1);
         for (int b = 0; b < B && !ch.on_device; b++)
         {
             int kind;
@@ -386,6 +398,14 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
                 continue; // a device candidate that did not fit its buffers: not a proposal
             current_iter++;
             consumed_now++;
+            if (p.algorithm == 2)
+            {
+                // host-drawn batches know each proposal's kind; device-drawn ones do not bring it back,
+                // there the counters take the expected gain under the batch's probabilities
+                const int k = ch.kinds[b];
+                for (int i = 0; i < 3; i++)
+                    counter[i] += k >= 0 ? (i != k ? 0.5 : 0.0) : 0.5 * (1.0 - probs[i]);
+            }
             // accept / reject (Solve.c:303-378)
             bool take;
             if (len <= cur)

@@ -144,7 +144,7 @@ def main(argv=None) -> int:
     ap.add_argument("-i", dest="infile", default="infile")
     ap.add_argument("-o", dest="out", default="outtree")
     ap.add_argument("-s", dest="seed", type=int, default=int(time.time()) % 900000000)
-    ap.add_argument("-a", dest="algorithm", type=int, default=1)
+    ap.add_argument("-a", dest="algorithm", type=int, choices=[0, 1, 2], default=1)
     ap.add_argument("-c", dest="cooling", choices=["g", "l"], default="g")
     ap.add_argument("-f", dest="fmt", choices=list(host.FORMATS), default="phylip")
     ap.add_argument("--batch", type=int, default=4096)

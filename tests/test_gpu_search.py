@@ -18,11 +18,14 @@ WANT = {c["infile"]: c["expect"] for c in json.loads((GOLD / "ref_tests.json").r
     ("test_treelength_6_thread_2.phy", 1628, 1, 1),
     ("test_treelength_7_thread_2.phy", 1006, 1, 1),
     ("test_treelength_6_thread_3.phy", 297, None, 2),
-], ids=["5t2-host", "6t2-host", "6t2-device", "7t2-device", "6t3-auto"])
-def test_search_reaches_reference_optimum(tmp_path, phy, score, topologies, on_device):
+    ("test_treelength_7_thread_2.phy", 1006, 1, 0),
+    ("test_treelength_5_thread_2.phy", 1846, None, 1),
+], ids=["5t2-host", "6t2-host", "6t2-device", "7t2-device", "6t3-auto", "7t2-host-a2", "5t2-device-a2"])
+def test_search_reaches_reference_optimum(tmp_path, phy, score, topologies, on_device, request):
     from lvb_amd import search
     out = tmp_path / "outtree"
-    res = search.run(str(GOLD / "ref_tests" / phy), seed=509739986, algorithm=1, batch=64, out=str(out),
+    algorithm = 2 if request.node.callspec.id.endswith("a2") else 1  # -a 2: counter-driven move mix
+    res = search.run(str(GOLD / "ref_tests" / phy), seed=509739986, algorithm=algorithm, batch=64, out=str(out),
                      max_seconds=60, verbose=False, device_proposals=on_device)
     assert res["best_length"] == score, res
     if topologies is not None:
