@@ -54,21 +54,40 @@ struct Chain
     bool on_device = false;          // neighbours drawn on the GPU (lvbgpu_propose_score*)
     std::vector<lvbgpu_edit> fetched; // edits of an accepted device candidate
 
+    std::vector<MoveParams> moves; // host-drawn proposals as parameters
+    bool moves_on_device = false;  // ... scored from the parameters (the device built rewrites and programs)
+    static constexpr int DEVICE_MOVES_MIN = 96; // below this the host's own program builder is quicker
+
     // score B fresh proposals of the given kinds; returns lvbgpu status
     int score(int B)
     {
-        edits.clear();
-        offs.assign(1, 0);
+        static_assert(sizeof(MoveParams) == sizeof(lvbgpu_move), "move layout");
+        moves.clear();
         for (int b = 0; b < B; b++)
-        {
-            propose(tree->topo, kinds[b], tree->rng, edits);
-            offs.push_back((int32_t)edits.size());
-        }
+            moves.push_back(draw_move(tree->topo, kinds[b], tree->rng));
         lens.resize(B);
-        const auto t0 = Clock::now();
-        const int rc = lvbgpu_score_batch(ctx, B, offs.data(), reinterpret_cast<const lvbgpu_edit *>(edits.data()),
-                                          nullptr, lens.data());
-        dev_seconds += since(t0);
+        moves_on_device = B >= DEVICE_MOVES_MIN;
+        int rc;
+        if (moves_on_device)
+        {
+            const auto t0 = Clock::now();
+            rc = lvbgpu_score_moves(ctx, B, reinterpret_cast<const lvbgpu_move *>(moves.data()), lens.data());
+            dev_seconds += since(t0);
+        }
+        else
+        {
+            edits.clear();
+            offs.assign(1, 0);
+            for (const MoveParams &m : moves)
+            {
+                move_edits(tree->topo, m, edits);
+                offs.push_back((int32_t)edits.size());
+            }
+            const auto t0 = Clock::now();
+            rc = lvbgpu_score_batch(ctx, B, offs.data(), reinterpret_cast<const lvbgpu_edit *>(edits.data()), nullptr,
+                                    lens.data());
+            dev_seconds += since(t0);
+        }
         scored += B;
         return rc;
     }
@@ -105,8 +124,11 @@ struct Chain
                 rc = lvbhost_tree_apply(tree, fetched.data(), ne, -1);
             return rc;
         }
-        const Edit *e = edits.data() + offs[b];
-        const int32_t ne = offs[b + 1] - offs[b];
+        std::vector<Edit> one;
+        if (moves_on_device)
+            move_edits(tree->topo, moves[(size_t)b], one); // only the accepted move becomes rewrites on the host
+        const Edit *e = moves_on_device ? one.data() : edits.data() + offs[b];
+        const int32_t ne = moves_on_device ? (int32_t)one.size() : offs[b + 1] - offs[b];
         const auto t0 = Clock::now();
         // asynchronous: the candidate's length is already known from scoring it
         int rc = lvbgpu_commit(ctx, ne, reinterpret_cast<const lvbgpu_edit *>(e), -1, nullptr);

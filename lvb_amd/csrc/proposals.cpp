@@ -166,12 +166,6 @@ int tbr_edits(const Topology &t, int32_t src, int32_t dest, int32_t x, std::vect
     return ov.count();
 }
 
-int propose_nni(const Topology &t, Rng &rng, std::vector<Edit> &out)
-{
-    const int32_t u = t.n + (int32_t)rng.below((uint32_t)(t.nb - t.n)); // any internal node
-    return nni_edits(t, u, rng.uniform() < 0.5, out);
-}
-
 static void draw_spr(const Topology &t, Rng &rng, int32_t &src, int32_t &dest)
 {
     do
@@ -182,36 +176,44 @@ static void draw_spr(const Topology &t, Rng &rng, int32_t &src, int32_t &dest)
     while (!spr_move_allowed(t, src, dest));
 }
 
-int propose_spr(const Topology &t, Rng &rng, std::vector<Edit> &out)
+MoveParams draw_move(const Topology &t, int kind, Rng &rng)
 {
+    if (kind == MOVE_NNI)
+    {
+        const int32_t u = t.n + (int32_t)rng.below((uint32_t)(t.nb - t.n)); // any internal node
+        return {MOVE_NNI, u, rng.uniform() < 0.5 ? 1 : 0, -1};
+    }
     int32_t src, dest;
     draw_spr(t, rng, src, dest);
-    return spr_edits(t, src, dest, out);
-}
-
-int propose_tbr(const Topology &t, Rng &rng, std::vector<Edit> &out)
-{
-    int32_t src, dest;
-    draw_spr(t, rng, src, dest);
+    if (kind == MOVE_SPR)
+        return {MOVE_SPR, src, dest, -1};
     std::vector<int32_t> leaves;
     subtree_leaves(t, src, leaves);
     if (leaves.size() <= 2) // nothing to re-root (TreeOperations.c:436)
-        return spr_edits(t, src, dest, out);
+        return {MOVE_TBR, src, dest, -1};
     int32_t x;
     do
         x = leaves[rng.below((uint32_t)leaves.size())];
     while (x == t.left[src] || x == t.right[src]); // 448-451
-    return tbr_edits(t, src, dest, x, out);
+    return {MOVE_TBR, src, dest, x};
 }
+
+int move_edits(const Topology &t, const MoveParams &m, std::vector<Edit> &out)
+{
+    if (m.kind == MOVE_NNI)
+        return nni_edits(t, m.a, m.b != 0, out);
+    if (m.kind == MOVE_SPR || m.c < 0)
+        return spr_edits(t, m.a, m.b, out);
+    return tbr_edits(t, m.a, m.b, m.c, out);
+}
+
+int propose_nni(const Topology &t, Rng &rng, std::vector<Edit> &out) { return move_edits(t, draw_move(t, MOVE_NNI, rng), out); }
+int propose_spr(const Topology &t, Rng &rng, std::vector<Edit> &out) { return move_edits(t, draw_move(t, MOVE_SPR, rng), out); }
+int propose_tbr(const Topology &t, Rng &rng, std::vector<Edit> &out) { return move_edits(t, draw_move(t, MOVE_TBR, rng), out); }
 
 int propose(const Topology &t, int kind, Rng &rng, std::vector<Edit> &out)
 {
-    switch (kind)
-    {
-    case MOVE_NNI: return propose_nni(t, rng, out);
-    case MOVE_SPR: return propose_spr(t, rng, out);
-    default: return propose_tbr(t, rng, out);
-    }
+    return move_edits(t, draw_move(t, kind < 0 || kind > 2 ? MOVE_TBR : kind, rng), out);
 }
 
 int reroot_edits(const Topology &t, int32_t newroot, std::vector<Edit> &out)

@@ -42,6 +42,17 @@ enum MoveKind
     MOVE_TBR = 2
 };
 
+// One random move as its parameters (the layout of lvbgpu_move in include/lvbgpu.h: NNI a = u, b = 1 to
+// give away u's right child; SPR a = src, b = dest; TBR a = src, b = dest, c = leaf to re-root the
+// moved subtree at, -1 = as SPR), and parameters -> rewrites.  A search can hand the parameters to the
+// device (lvbgpu_score_moves) and only turn the accepted move into rewrites.
+struct MoveParams
+{
+    int32_t kind, a, b, c;
+};
+MoveParams draw_move(const Topology &t, int kind, Rng &rng);
+int move_edits(const Topology &t, const MoveParams &m, std::vector<Edit> &out);
+
 // Each appends the child-pair rewrites of ONE random move to `out` and returns how many.
 int propose_nni(const Topology &t, Rng &rng, std::vector<Edit> &out);
 int propose_spr(const Topology &t, Rng &rng, std::vector<Edit> &out);
