@@ -370,12 +370,20 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 // ---------------------------------------------------------------------------------------------
 // small helpers around the walk
 
-// changes[dst] = 0 for every node a commit program is about to recompute
-__global__ void zero_changes_kernel(unsigned long long *changes, const int32_t *dsts, uint32_t n)
+// changes[dst] = 0 for every node a commit program is about to recompute, plus the two scalars the
+// commit walk accumulates into (the root slot of changes[] and the program's length slot): one launch
+// instead of a launch and two memsets on the accept path
+__global__ void zero_changes_kernel(unsigned long long *changes, const int32_t *dsts, uint32_t n,
+                                    unsigned long long *root_slot, unsigned long long *len_slot)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && dsts[i] >= 0)
         changes[dsts[i]] = 0ull;
+    if (i == 0)
+    {
+        *root_slot = 0ull;
+        *len_slot = 0ull;
+    }
 }
 
 // scalars[0] = sum of changes[first .. last) (all internal nodes); scalars[1] = that + changes[last]
@@ -539,11 +547,11 @@ hipError_t raise_lds_limit()
                                hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
 }
 
-hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, hipStream_t stream)
+hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,
+                               unsigned long long *len_slot, hipStream_t stream)
 {
-    if (n == 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(zero_changes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, changes, dsts, n);
+    hipLaunchKernelGGL(zero_changes_kernel, dim3(n ? (n + 255) / 256 : 1), dim3(256), 0, stream, changes, dsts, n, root_slot,
+                       len_slot);
     return hipGetLastError();
 }
 

@@ -97,7 +97,8 @@ hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
 hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);
-hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, hipStream_t stream);
+hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,
+                               unsigned long long *len_slot, hipStream_t stream);
 // scalars[0] = sum of changes[first, last), scalars[1] = scalars[0] + changes[last] (tree length)
 hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first, uint32_t last, long long *scalars,
                               hipStream_t stream);

@@ -631,15 +631,15 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
     HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
     HIPCHK(ctx, ctx->d_len.reserve(8));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
     if (zero_all)
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
-    else
     {
-        HIPCHK(ctx, launch_zero_changes(ctx->d_changes, (const int32_t *)((const char *)dprog.p + o_d),
-                                        (uint32_t)prog.dsts.size(), ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes + ctx->nb, 0, 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
     }
+    else // the accept path: one small launch clears everything the walk accumulates into
+        HIPCHK(ctx, launch_zero_changes((unsigned long long *)ctx->d_changes, (const int32_t *)((const char *)dprog.p + o_d),
+                                        (uint32_t)prog.dsts.size(), (unsigned long long *)ctx->d_changes + ctx->nb,
+                                        (unsigned long long *)ctx->d_len.p, ctx->stream));
     WalkArgs a = resident_args(ctx, dprog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
