@@ -185,7 +185,11 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         if (dst >= 0)
             a.rows_out[(size_t)dst * a.out_stride4 + col] = acc;
         if (lane == 0 && s)
+        {
             atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
+            if (dst >= 0 && a.s_all_out)
+                atomicAdd(a.s_all_out, (unsigned long long)s); // S_all follows the commit: no separate summing pass
+        }
         k_comb++;
     };
 
@@ -373,12 +377,19 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 // changes[dst] = 0 for every node a commit program is about to recompute, plus the two scalars the
 // commit walk accumulates into (the root slot of changes[] and the program's length slot): one launch
 // instead of a launch and two memsets on the accept path
+// ... and S_all gives up what those nodes had contributed (the walk adds the new counts back)
 __global__ void zero_changes_kernel(unsigned long long *changes, const int32_t *dsts, uint32_t n,
-                                    unsigned long long *root_slot, unsigned long long *len_slot)
+                                    unsigned long long *root_slot, unsigned long long *len_slot,
+                                    unsigned long long *s_all)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && dsts[i] >= 0)
+    {
+        const unsigned long long old = changes[dsts[i]];
         changes[dsts[i]] = 0ull;
+        if (old)
+            atomicAdd(s_all, 0ull - old); // two's complement: subtracts
+    }
     if (i == 0)
     {
         *root_slot = 0ull;
@@ -548,10 +559,10 @@ hipError_t raise_lds_limit()
 }
 
 hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,
-                               unsigned long long *len_slot, hipStream_t stream)
+                               unsigned long long *len_slot, unsigned long long *s_all, hipStream_t stream)
 {
     hipLaunchKernelGGL(zero_changes_kernel, dim3(n ? (n + 255) / 256 : 1), dim3(256), 0, stream, changes, dsts, n, root_slot,
-                       len_slot);
+                       len_slot, s_all);
     return hipGetLastError();
 }
 

@@ -43,6 +43,7 @@ struct WalkArgs
     const long long *s_all;             // resident sum of all internal changes
     unsigned long long *len_out;        // [B], zeroed by the caller
     unsigned long long *changes_out;    // COMMIT: per-node change accumulators, zeroed for dsts
+    unsigned long long *s_all_out;      // COMMIT on the resident tree: running sum of all internal changes (may be null)
     uint32_t in_stride4, out_stride4;   // row strides in 16-byte units
     uint32_t B, ntiles;
     uint32_t ngroups;                   // tiles are dealt to this many groups; one wave walks one (group, candidate)
@@ -98,7 +99,7 @@ hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
 hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);
 hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,
-                               unsigned long long *len_slot, hipStream_t stream);
+                               unsigned long long *len_slot, unsigned long long *s_all, hipStream_t stream);
 // scalars[0] = sum of changes[first, last), scalars[1] = scalars[0] + changes[last] (tree length)
 hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first, uint32_t last, long long *scalars,
                               hipStream_t stream);

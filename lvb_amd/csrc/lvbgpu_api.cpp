@@ -593,10 +593,12 @@ int read_current_length(lvbgpu_ctx *ctx)
 {
     if (!ctx->cur_length_stale)
         return LVBGPU_OK;
-    long long scal[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(scal, ctx->d_scalars, 16, hipMemcpyDeviceToHost, ctx->stream));
+    // length = S_all (kept current by every commit) + the root slot of changes[]
+    long long s_all = 0, root_changes = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&s_all, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&root_changes, ctx->d_changes + ctx->nb, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->cur_length = scal[1];
+    ctx->cur_length = s_all + root_changes;
     ctx->cur_length_stale = false;
     return LVBGPU_OK;
 }
@@ -636,13 +638,18 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
         HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
     }
-    else // the accept path: one small launch clears everything the walk accumulates into
+    else // the accept path: one small launch clears everything the walk accumulates into and takes the
+         // recomputed nodes' old counts out of S_all
         HIPCHK(ctx, launch_zero_changes((unsigned long long *)ctx->d_changes, (const int32_t *)((const char *)dprog.p + o_d),
                                         (uint32_t)prog.dsts.size(), (unsigned long long *)ctx->d_changes + ctx->nb,
-                                        (unsigned long long *)ctx->d_len.p, ctx->stream));
+                                        (unsigned long long *)ctx->d_len.p, (unsigned long long *)ctx->d_scalars,
+                                        ctx->stream));
     WalkArgs a = resident_args(ctx, dprog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
+    if (!zero_all)
+        a.s_all_out = (unsigned long long *)ctx->d_scalars; // the walk adds the new counts: S_all stays current
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
-    HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
+    if (zero_all) // full evaluation: sum once
+        HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
     ctx->cur_length_stale = true;
     return readback ? read_current_length(ctx) : LVBGPU_OK;
 }
