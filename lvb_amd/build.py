@@ -20,8 +20,9 @@ CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 ARCH = "gfx950"
 
-GPU_SOURCES = ["fitch_kernels.hip", "propose_kernels.hip", "lvbgpu_api.cpp", "program.cpp"]
-GPU_HEADERS = ["kernels.hpp", "program.hpp", "pool.hpp"]
+GPU_SOURCES = ["fitch_kernels.hip", "propose_kernels.hip", "api_core.cpp", "api_batch.cpp", "api_propose.cpp",
+               "api_compat.cpp", "api_comm.cpp", "program.cpp"]
+GPU_HEADERS = ["kernels.hpp", "program.hpp", "pool.hpp", "ctx.hpp"]
 COMPAT_SOURCES = ["getplen_adapter.cpp"]
 HOST_SOURCES = ["host_api.cpp", "proposals.cpp", "anneal.cpp", "refsearch.cpp", "program.cpp"]
 HOST_HEADERS = ["program.hpp", "proposals.hpp", "host_tree.hpp"]

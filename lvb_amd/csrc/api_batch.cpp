@@ -1,0 +1,350 @@
+// api_batch.cpp - liblvbgpu.so: candidates given as edits (or whole topologies) -> programs built on the host -> scored.
+#include "ctx.hpp"
+
+extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
+{
+    if (!b)
+        return;
+    if (b->ctx)
+    {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+    }
+    b->d_prog.release();
+    b->d_len.release();
+    b->h_len.release();
+    delete b;
+}
+
+
+namespace lvbgpu_detail
+{
+constexpr int32_t PARALLEL_BUILD_MIN = 512; // below this one thread is faster than waking the pool
+
+// what a batch is made from: edits against the resident tree, or whole topologies
+struct BuildJob
+{
+    const int32_t *edit_offsets = nullptr;
+    const lvbgpu_edit *edits = nullptr;
+    const int32_t *roots = nullptr;
+    const int32_t *left = nullptr, *right = nullptr; // full mode: [B][2n-3]
+    bool full = false;
+};
+
+// whole-tree programs of trees [b0, b1)
+void build_slice_full(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const BuildJob &job)
+{
+    w.topo_version = ~0ull; // the private topology is overwritten below
+    w.pb.resize(ctx->nb);
+    w.prog.toks.clear();
+    w.prog.dsts.clear();
+    w.cands.clear();
+    w.max_stack = 0;
+    w.dirty = 0;
+    w.rc = LVBGPU_OK;
+    for (int32_t b = b0; b < b1; b++)
+    {
+        if (!w.topo.assign((int32_t)ctx->n, job.left + (size_t)b * ctx->nb, job.right + (size_t)b * ctx->nb,
+                           job.roots ? job.roots[b] : 0, &w.why))
+        {
+            w.rc = LVBGPU_E_TOPOLOGY;
+            w.why = "tree " + std::to_string(b) + ": " + w.why;
+            return;
+        }
+        const size_t tok0 = w.prog.toks.size(), dst0 = w.prog.dsts.size();
+        w.prog.max_stack = 0;
+        w.pb.build_full(w.topo, w.prog);
+        CandDesc cd{};
+        cd.tok_off = (uint32_t)tok0;
+        cd.ntok = (uint32_t)(w.prog.toks.size() - tok0);
+        cd.dst_off = (uint32_t)dst0;
+        cd.ncomb = (uint32_t)(w.prog.dsts.size() - dst0);
+        for (size_t i = tok0; i < w.prog.toks.size(); i++)
+            cd.nfresh += (w.prog.toks[i] & TOK_FRESH) ? 1u : 0u;
+        w.cands.push_back(cd);
+        w.max_stack = std::max(w.max_stack, w.prog.max_stack);
+        w.dirty += w.prog.dirty;
+    }
+}
+
+// programs of candidates [b0, b1) with one worker's private topology copy
+void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const BuildJob &job)
+{
+    if (job.full)
+        return build_slice_full(ctx, w, b0, b1, job);
+    const int32_t *edit_offsets = job.edit_offsets;
+    const lvbgpu_edit *edits = job.edits;
+    const int32_t *roots = job.roots;
+    if (w.topo_version != ctx->topo_version)
+    {
+        w.topo = ctx->topo;
+        w.topo_version = ctx->topo_version;
+        w.pb.resize(w.topo.nb);
+    }
+    w.prog.toks.clear();
+    w.prog.dsts.clear();
+    w.cands.clear();
+    w.max_stack = 0;
+    w.dirty = 0;
+    w.rc = LVBGPU_OK;
+    for (int32_t b = b0; b < b1; b++)
+    {
+        const int32_t e0 = edit_offsets[b], e1 = edit_offsets[b + 1];
+        if (e1 < e0)
+        {
+            w.rc = LVBGPU_E_ARG;
+            w.why = "edit_offsets not monotone";
+            return;
+        }
+        const size_t tok0 = w.prog.toks.size(), dst0 = w.prog.dsts.size();
+        w.prog.max_stack = 0;
+        if (!w.pb.build_candidate(w.topo, reinterpret_cast<const Edit *>(edits) + e0, e1 - e0, roots ? roots[b] : -1,
+                                  w.prog, &w.why))
+        {
+            w.rc = LVBGPU_E_TOPOLOGY;
+            w.why = "candidate " + std::to_string(b) + ": " + w.why;
+            return;
+        }
+        CandDesc cd{};
+        cd.tok_off = (uint32_t)tok0;
+        cd.ntok = (uint32_t)(w.prog.toks.size() - tok0);
+        cd.dst_off = (uint32_t)dst0;
+        cd.ncomb = (uint32_t)(w.prog.dsts.size() - dst0);
+        cd.flags = CAND_RESIDENT_BASE;
+        for (size_t i = tok0; i < w.prog.toks.size(); i++)
+            cd.nfresh += (w.prog.toks[i] & TOK_FRESH) ? 1u : 0u;
+        w.cands.push_back(cd);
+        w.max_stack = std::max(w.max_stack, w.prog.max_stack);
+        w.dirty += w.prog.dirty;
+    }
+}
+
+// fill `bt` (new or recycled: its buffers only ever grow) with the programs of B candidates:
+// slices of the batch are built on the pool's threads straight into the pinned upload buffer
+int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job)
+{
+    static_assert(sizeof(lvbgpu_edit) == sizeof(Edit), "edit layout");
+    int T = 1;
+    // whole-tree programs are ~n tokens each: worth the pool from a handful of trees on
+    const int32_t par_min = job.full ? 16 : PARALLEL_BUILD_MIN;
+    if (B >= par_min)
+    {
+        if (!ctx->pool)
+        {
+            const int n = host_threads();
+            if (n > 1)
+                ctx->pool = new (std::nothrow) Pool(n);
+        }
+        if (ctx->pool)
+            T = std::max(1, std::min(ctx->pool->size(), B / (par_min / 2)));
+    }
+    if ((int)ctx->workers.size() < T)
+        ctx->workers.resize(T);
+    auto slice = [&](int t) {
+        build_slice(ctx, ctx->workers[t], (int32_t)((int64_t)B * t / T), (int32_t)((int64_t)B * (t + 1) / T), job);
+    };
+    if (T == 1)
+        slice(0);
+    else
+        ctx->pool->run(T, slice);
+
+    size_t ntok = 0, ndst = 0;
+    std::vector<size_t> tok_base(T), dst_base(T), cand_base(T);
+    int32_t max_stack = 0;
+    int64_t dirty = 0;
+    size_t ncand = 0;
+    for (int t = 0; t < T; t++)
+    {
+        BuildWorker &w = ctx->workers[t];
+        if (w.rc != LVBGPU_OK)
+            return ctx->fail(w.rc, w.why);
+        tok_base[t] = ntok;
+        dst_base[t] = ndst;
+        cand_base[t] = ncand;
+        ntok += w.prog.toks.size();
+        ndst += w.prog.dsts.size();
+        ncand += w.cands.size();
+        max_stack = std::max(max_stack, w.max_stack);
+        dirty += w.dirty;
+    }
+    int rc = check_depth(ctx, max_stack);
+    if (rc != LVBGPU_OK)
+        return rc;
+    if ((uint64_t)B * ctx->ntiles >= (1ull << 31) || ntok >= (1ull << 32))
+        return ctx->fail(LVBGPU_E_ARG, "batch too large: B * tiles must stay below 2^31");
+
+    const size_t o_t = align16((size_t)B * sizeof(CandDesc));
+    const size_t o_d = o_t + align16(ntok * 4);
+    const size_t total = o_d + align16(ndst * 4);
+    HIPCHK(ctx, bt->d_prog.reserve(total));
+    HIPCHK(ctx, ctx->h_pin.reserve(total));
+    char *h = (char *)ctx->h_pin.p;
+    auto gather = [&](int t) {
+        BuildWorker &w = ctx->workers[t];
+        CandDesc *cd = (CandDesc *)h + cand_base[t];
+        for (size_t i = 0; i < w.cands.size(); i++)
+        {
+            cd[i] = w.cands[i];
+            cd[i].tok_off += (uint32_t)tok_base[t];
+            cd[i].dst_off += (uint32_t)dst_base[t];
+        }
+        memcpy(h + o_t + tok_base[t] * 4, w.prog.toks.data(), w.prog.toks.size() * 4);
+        memcpy(h + o_d + dst_base[t] * 4, w.prog.dsts.data(), w.prog.dsts.size() * 4);
+    };
+    if (T == 1)
+        gather(0);
+    else
+        ctx->pool->run(T, gather);
+    HIPCHK(ctx, hipMemcpyAsync(bt->d_prog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+    // h_pin is reused by the next upload.  A recycled step batch is read back (and the stream
+    // drained) by lvbgpu_batch_lengths before anything can build again: no need to wait here.
+    if (!bt->recycled)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    bt->ctx = ctx;
+    bt->B = B;
+    bt->off_toks = o_t;
+    bt->off_dsts = o_d;
+    const void *old_len = bt->d_len.p;
+    HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
+    if (bt->d_len.p != old_len)
+        bt->len_zeroed = false;
+    HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
+    bt->full_mode = job.full;
+    bt->stats.candidates = B;
+    bt->stats.combines = (int64_t)ndst;
+    bt->stats.rows_read = (int64_t)ntok;
+    bt->stats.dirty_nodes = dirty;
+    bt->stats.max_stack = max_stack;
+    bt->stats.algorithmic_bytes = bt->stats.rows_read * ctx->nwords * 8;
+    return LVBGPU_OK;
+}
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
+                                  const int32_t *roots, lvbgpu_batch **out)
+{
+    if (!ctx || !out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    lvbgpu_batch *bt = new (std::nothrow) lvbgpu_batch();
+    if (!bt)
+        return LVBGPU_E_NOMEM;
+    BuildJob job;
+    job.edit_offsets = edit_offsets;
+    job.edits = edits;
+    job.roots = roots;
+    const int rc = build_into(ctx, bt, B, job);
+    if (rc != LVBGPU_OK)
+    {
+        lvbgpu_batch_free(bt);
+        return rc;
+    }
+    *out = bt;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
+{
+    if (!ctx || !b || b->ctx != ctx)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!b->len_zeroed)
+        HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, (size_t)b->B * 8, ctx->stream));
+    b->len_zeroed = false;
+    WalkArgs a = resident_args(ctx, b->d_prog, b->off_toks, b->off_dsts, b->d_len.p, (uint32_t)b->B,
+                               (int32_t)b->stats.max_stack);
+    HIPCHK(ctx, launch_walk(a, false, ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *lengths_out)
+{
+    if (!ctx || !b || b->ctx != ctx || !lengths_out)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // through pinned memory: one DMA, no staging
+    HIPCHK(ctx, hipMemcpyAsync(b->h_len.p, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (b->recycled)
+        HIPCHK(ctx, wait_for_step(ctx, b->B));
+    else
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->recycled)
+    {
+        // clear the slots for the next step now, while the host consumes these lengths
+        HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->d_len.cap, ctx->stream));
+        b->len_zeroed = true;
+    }
+    memcpy(lengths_out, b->h_len.p, (size_t)b->B * 8);
+    for (int32_t i = 0; i < b->B; i++)
+        if (lengths_out[i] <= 0)
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_batch_get_stats(const lvbgpu_batch *b, lvbgpu_batch_stats *out)
+{
+    if (!b || !out)
+        return LVBGPU_E_ARG;
+    *out = b->stats;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets, const lvbgpu_edit *edits,
+                                  const int32_t *roots, int64_t *lengths_out)
+{
+    if (!ctx || !lengths_out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // one recycled batch per context: a search calls this every step, so no allocation here
+    if (!ctx->step_batch)
+    {
+        ctx->step_batch = new (std::nothrow) lvbgpu_batch();
+        if (!ctx->step_batch)
+            return LVBGPU_E_NOMEM;
+        ctx->step_batch->recycled = true;
+    }
+    lvbgpu_batch *b = ctx->step_batch;
+    BuildJob job;
+    job.edit_offsets = edit_offsets;
+    job.edits = edits;
+    job.roots = roots;
+    int rc = build_into(ctx, b, B, job);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_launch(ctx, b);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_lengths(ctx, b, lengths_out);
+    return rc;
+}
+
+extern "C" int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *left, const int32_t *right,
+                                       const int32_t *roots, int64_t *lengths_out)
+{
+    if (!ctx || B < 1 || !left || !right || !lengths_out)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->full_batch)
+    {
+        ctx->full_batch = new (std::nothrow) lvbgpu_batch();
+        if (!ctx->full_batch)
+            return LVBGPU_E_NOMEM;
+        ctx->full_batch->recycled = true;
+    }
+    lvbgpu_batch *bt = ctx->full_batch; // recycled like the step batch
+    BuildJob job;
+    job.left = left;
+    job.right = right;
+    job.roots = roots;
+    job.full = true;
+    int rc = build_into(ctx, bt, B, job);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_launch(ctx, bt);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_lengths(ctx, bt, lengths_out);
+    return rc;
+}
+

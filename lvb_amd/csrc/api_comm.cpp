@@ -1,0 +1,113 @@
+// api_comm.cpp - liblvbgpu.so: the one collective of the path, a min-reduce of the best length over RCCL (loaded at run time).
+#include "ctx.hpp"
+
+namespace lvbgpu_detail
+{
+static Rccl g_rccl;
+} // namespace lvbgpu_detail
+
+// =================================================================================== RCCL
+
+namespace lvbgpu_detail
+{
+bool load_rccl(std::string *why)
+{
+    if (g_rccl.lib)
+        return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *nm : names)
+        if ((g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!g_rccl.lib)
+    {
+        *why = std::string("dlopen librccl.so: ") + dlerror();
+        return false;
+    }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    {
+        *why = "librccl.so lacks the nccl* entry points";
+        return false;
+    }
+    return true;
+}
+constexpr int NCCL_INT64 = 4; // ncclInt64
+constexpr int NCCL_MIN = 3;   // ncclMin
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_comm_unique_id(void *id128)
+{
+    if (!id128)
+        return LVBGPU_E_ARG;
+    std::string why;
+    if (!load_rccl(&why))
+    {
+        g_last_error_noctx = why;
+        return LVBGPU_E_COMM;
+    }
+    const int r = g_rccl.GetUniqueId(id128);
+    if (r != 0)
+    {
+        g_last_error_noctx = std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        return LVBGPU_E_COMM;
+    }
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const void *id128)
+{
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
+        return LVBGPU_E_ARG;
+    std::string why;
+    if (!load_rccl(&why))
+        return ctx->fail(LVBGPU_E_COMM, why);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Id128 id;
+    memcpy(id.bytes, id128, 128);
+    const int r = g_rccl.CommInitRank(&ctx->comm, nranks, id, rank);
+    if (r != 0)
+        return ctx->fail(LVBGPU_E_COMM,
+                         std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    ctx->comm_rank = rank;
+    ctx->comm_size = nranks;
+    HIPCHK(ctx, ctx->d_comm.reserve(16));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value, int32_t *argmin_rank)
+{
+    if (!ctx || !value)
+        return LVBGPU_E_ARG;
+    if (!ctx->comm)
+        return ctx->fail(LVBGPU_E_STATE, "no communicator: call lvbgpu_comm_init first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // one 8-byte min over xGMI finds the best length; a second one over (length, rank) keys
+    // names a rank that holds it.  Lengths are < 2^47 (MAX_M * 2 * MAX_N), ranks < 2^16.
+    long long vals[2] = {(long long)*value, ((long long)*value << 16) | (long long)ctx->comm_rank};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm.p, vals, 16, hipMemcpyHostToDevice, ctx->stream));
+    const int r = g_rccl.AllReduce(ctx->d_comm.p, ctx->d_comm.p, 2, NCCL_INT64, NCCL_MIN, ctx->comm, ctx->stream);
+    if (r != 0)
+        return ctx->fail(LVBGPU_E_COMM,
+                         std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    HIPCHK(ctx, hipMemcpyAsync(vals, ctx->d_comm.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *value = vals[0];
+    if (argmin_rank)
+        *argmin_rank = (int32_t)(vals[1] & 0xFFFF);
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_comm_destroy(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    if (ctx->comm && g_rccl.CommDestroy)
+        (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    return LVBGPU_OK;
+}
+

@@ -1,0 +1,561 @@
+// api_core.cpp - liblvbgpu.so: errors, encoding, context life cycle, the resident tree (set, read back, commit), timers.
+//
+// There is deliberately no CPU implementation of any scoring entry point in this library: without
+// a working HIP device every one of them fails with LVBGPU_E_NODEVICE / LVBGPU_E_HIP.
+#include "ctx.hpp"
+
+namespace lvbgpu_detail
+{
+
+thread_local std::string g_last_error_noctx;
+
+int hip_status_noctx(hipError_t e, const char *what)
+{
+    g_last_error_noctx = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+               ? LVBGPU_E_NODEVICE
+               : (e == hipErrorOutOfMemory ? LVBGPU_E_NOMEM : LVBGPU_E_HIP);
+}
+
+// end of a search step on the context's stream
+hipError_t wait_for_step(lvbgpu_ctx *ctx, int32_t B)
+{
+    if (B > SPIN_WAIT_MAX_B)
+        return hipStreamSynchronize(ctx->stream);
+    hipError_t q;
+    while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady)
+        ;
+    return q;
+}
+
+WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, size_t off_dsts, void *d_len,
+                       uint32_t B, int32_t max_stack)
+{
+    WalkArgs a{};
+    a.rows_in = (const uint4 *)ctx->d_rows;
+    a.rows_out = (uint4 *)ctx->d_rows;
+    a.cands = (const CandDesc *)prog.p;
+    a.toks = (const uint32_t *)((const char *)prog.p + off_toks);
+    a.dsts = (const int32_t *)((const char *)prog.p + off_dsts);
+    a.node_changes = (const long long *)ctx->d_changes;
+    a.s_all = ctx->d_scalars;
+    a.len_out = (unsigned long long *)d_len;
+    a.changes_out = ctx->d_changes;
+    a.in_stride4 = ctx->stride4;
+    a.out_stride4 = ctx->stride4;
+    a.B = B;
+    a.ntiles = ctx->ntiles;
+    a.ngroups = choose_groups(B, ctx->ntiles, ctx->target_waves);
+    a.nitems = B * a.ngroups;
+    a.stack_depth = (uint32_t)std::max(max_stack, 1);
+    a.root_slot = (uint32_t)ctx->nb;
+    return a;
+}
+
+int check_depth(lvbgpu_ctx *ctx, int32_t max_stack)
+{
+    if ((size_t)max_stack * WALK_WAVES * 64 * sizeof(uint4) > MAX_LDS_BYTES)
+        return ctx->fail(LVBGPU_E_ARG, "postorder program needs a deeper operand stack than LDS holds");
+    return LVBGPU_OK;
+}
+
+int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
+{
+    if (n < 3 || nwords < 1 || 2 * n - 3 > MAX_ROWS)
+        return ctx->fail(LVBGPU_E_ARG, "n or nwords out of range");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return ctx->fail(LVBGPU_E_NODEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return ctx->fail(LVBGPU_E_ARG, "device index out of range");
+    ctx->device = device;
+    HIPCHK(ctx, hipSetDevice(device));
+    ctx->n = n;
+    ctx->nwords = nwords;
+    ctx->nb = (int32_t)(2 * n - 3);
+    ctx->ntiles = round_up((uint32_t)nwords, TILE_WORDS) / TILE_WORDS;
+    // tuning knobs for experiments: extra row padding (in tiles) and the wave-count target
+    const char *pad = getenv("LVBGPU_STRIDE_PAD_TILES");
+    ctx->stride_words = (ctx->ntiles + (pad ? (uint32_t)atoi(pad) : 0u)) * TILE_WORDS;
+    ctx->stride4 = ctx->stride_words / 2;
+    if (const char *tw = getenv("LVBGPU_TARGET_WAVES"))
+        ctx->target_waves = (uint32_t)std::max(1, atoi(tw));
+    // (row offsets are 64-bit in the kernels: the tree block is limited by HBM, not by index width)
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev0));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)ctx->nb * ctx->stride_words * 8));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_changes, (size_t)(ctx->nb + 1) * 8));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_scalars, 2 * 8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
+    HIPCHK(ctx, upload_iupac_table());
+    HIPCHK(ctx, raise_lds_limit());
+    ctx->pb.resize(ctx->nb);
+    return LVBGPU_OK;
+}
+
+// everything that is not a leaf word becomes all-ones (inert under fitch); then the leaf rows go
+// from the reference's nibble layout to the device's bit-plane layout (all-ones stays all-ones)
+int finish_rows(lvbgpu_ctx *ctx)
+{
+    HIPCHK(ctx, launch_fill_pad(ctx->d_rows, (uint32_t)ctx->nb, (uint32_t)ctx->nwords, ctx->stride_words,
+                                (uint32_t)ctx->n, ctx->stream));
+    HIPCHK(ctx, launch_relayout((uint4 *)ctx->d_rows, (uint32_t)ctx->n, ctx->stride4, true, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+} // namespace lvbgpu_detail
+
+// =================================================================================== library
+
+extern "C" const char *lvbgpu_strerror(int status)
+{
+    switch (status)
+    {
+    case LVBGPU_OK: return "ok";
+    case LVBGPU_E_ARG: return "bad argument";
+    case LVBGPU_E_NODEVICE: return "no usable HIP device";
+    case LVBGPU_E_HIP: return "HIP call failed";
+    case LVBGPU_E_NOMEM: return "out of memory";
+    case LVBGPU_E_STATE: return "call order violated";
+    case LVBGPU_E_TOPOLOGY: return "not a binary tree rooted at a leaf";
+    case LVBGPU_E_SYMBOL: return "bad base symbol in data matrix";
+    case LVBGPU_E_ZEROLEN: return "tree length is not positive";
+    case LVBGPU_E_COMM: return "RCCL failure";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *lvbgpu_last_error(const lvbgpu_ctx *ctx)
+{
+    return ctx ? ctx->last_error.c_str() : g_last_error_noctx.c_str();
+}
+
+extern "C" int lvbgpu_device_count(void)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess)
+        return hip_status_noctx(e, "hipGetDeviceCount");
+    return count;
+}
+
+extern "C" int lvbgpu_abi_version(void) { return ABI_VERSION; }
+
+extern "C" long lvbgpu_words_per_row(long m)
+{
+    // reference DataOperations.c:446-458: m/16 rounded up
+    return (m >> 4) + ((m & 15) ? 1 : 0);
+}
+
+// =================================================================================== encoding
+
+namespace lvbgpu_detail
+{
+int encode_into(lvbgpu_ctx *ctx, long n, long m, const char *const *rows, uint64_t *d_rows, uint32_t stride_words)
+{
+    const long nwords = lvbgpu_words_per_row(m);
+    DevBuf d_text, d_bad;
+    PinBuf h_text;
+    int rc = LVBGPU_OK;
+    const size_t tbytes = (size_t)n * (size_t)m;
+    hipError_t e;
+    if ((e = h_text.reserve(tbytes)) != hipSuccess || (e = d_text.reserve(tbytes)) != hipSuccess ||
+        (e = d_bad.reserve(8)) != hipSuccess)
+        rc = ctx->fail_hip(e, "encode staging");
+    unsigned long long bad = ~0ull;
+    if (rc == LVBGPU_OK)
+    {
+        for (long i = 0; i < n; i++)
+            memcpy((char *)h_text.p + (size_t)i * m, rows[i], (size_t)m);
+        if ((e = hipMemcpyAsync(d_text.p, h_text.p, tbytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(d_bad.p, &bad, 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+            (e = launch_encode_text((const uint8_t *)d_text.p, (uint32_t)n, (uint64_t)m, (uint32_t)nwords,
+                                    stride_words, d_rows, (unsigned long long *)d_bad.p, ctx->stream)) !=
+                hipSuccess ||
+            (e = hipMemcpyAsync(&bad, d_bad.p, 8, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess)
+            rc = ctx->fail_hip(e, "encode_text");
+    }
+    if (rc == LVBGPU_OK && bad != ~0ull)
+    {
+        const unsigned long long pos = bad - 1;
+        char msg[160];
+        snprintf(msg, sizeof msg, "bad base symbol in data MSA: '%c' (row %llu, column %llu)",
+                 rows[pos / m][pos % m], pos / m, pos % m);
+        rc = ctx->fail(LVBGPU_E_SYMBOL, msg);
+    }
+    d_text.release();
+    d_bad.release();
+    h_text.release();
+    return rc;
+}
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_encode_text(int device, long n, long m, const char *const *rows, uint64_t *out)
+{
+    if (!rows || !out || n < 1 || m < 1)
+        return LVBGPU_E_ARG;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return hip_status_noctx(e == hipSuccess ? hipErrorNoDevice : e, "hipGetDeviceCount");
+    if (device < 0 || device >= count)
+        return LVBGPU_E_ARG;
+    lvbgpu_ctx tmp;
+    tmp.device = device;
+    int rc = LVBGPU_OK;
+    const long nwords = lvbgpu_words_per_row(m);
+    DevBuf d_out;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&tmp.stream)) != hipSuccess ||
+        (e = upload_iupac_table()) != hipSuccess || (e = d_out.reserve((size_t)n * nwords * 8)) != hipSuccess)
+        rc = tmp.fail_hip(e, "encode setup");
+    if (rc == LVBGPU_OK)
+        rc = encode_into(&tmp, n, m, rows, (uint64_t *)d_out.p, (uint32_t)nwords);
+    if (rc == LVBGPU_OK &&
+        (e = hipMemcpy(out, d_out.p, (size_t)n * nwords * 8, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = tmp.fail_hip(e, "encode download");
+    g_last_error_noctx = tmp.last_error;
+    d_out.release();
+    if (tmp.stream)
+        (void)hipStreamDestroy(tmp.stream);
+    return rc;
+}
+
+// =================================================================================== context
+
+extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm)
+        (void)lvbgpu_comm_destroy(ctx);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_rows)
+        (void)hipFree(ctx->d_rows);
+    if (ctx->d_changes)
+        (void)hipFree(ctx->d_changes);
+    if (ctx->d_scalars)
+        (void)hipFree(ctx->d_scalars);
+    delete ctx->pool;
+    ctx->pool = nullptr;
+    ctx->d_topo4.release();
+    ctx->d_pedits.release();
+    ctx->d_pinfo.release();
+    ctx->h_pinfo.release();
+    ctx->d_moves.release();
+    ctx->h_moves.release();
+    for (lvbgpu_batch *rb : {ctx->step_batch, ctx->full_batch, ctx->prop_batch})
+        if (rb)
+        {
+            rb->ctx = nullptr;
+            lvbgpu_batch_free(rb);
+        }
+    ctx->d_len.release();
+    ctx->d_export.release();
+    for (int i = 0; i < lvbgpu_ctx::COMMIT_SLOTS; i++)
+    {
+        ctx->h_commit[i].release();
+        ctx->d_commit[i].release();
+        if (ctx->commit_ev[i])
+            (void)hipEventDestroy(ctx->commit_ev[i]);
+    }
+    ctx->h_pin.release();
+    ctx->d_cin.release();
+    ctx->d_cout.release();
+    ctx->h_cin.release();
+    ctx->h_cout.release();
+    ctx->d_comm.release();
+    if (ctx->ev0)
+        (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1)
+        (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int lvbgpu_create(lvbgpu_ctx **out, int device, long n, long nwords, const uint64_t *leaf_matrix,
+                             long row_stride_words)
+{
+    if (!out || !leaf_matrix || row_stride_words < nwords)
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    lvbgpu_ctx *ctx = new (std::nothrow) lvbgpu_ctx();
+    if (!ctx)
+        return LVBGPU_E_NOMEM;
+    int rc = context_common_init(ctx, device, n, nwords);
+    if (rc == LVBGPU_OK)
+    {
+        hipError_t e = hipMemcpy2DAsync(ctx->d_rows, (size_t)ctx->stride_words * 8, leaf_matrix,
+                                        (size_t)row_stride_words * 8, (size_t)nwords * 8, (size_t)n,
+                                        hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess)
+            rc = ctx->fail_hip(e, "upload leaf matrix");
+    }
+    if (rc == LVBGPU_OK)
+        rc = finish_rows(ctx);
+    if (rc != LVBGPU_OK)
+    {
+        g_last_error_noctx = ctx->last_error;
+        lvbgpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_create_from_text(lvbgpu_ctx **out, int device, long n, long m, const char *const *rows)
+{
+    if (!out || !rows || m < 1)
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    lvbgpu_ctx *ctx = new (std::nothrow) lvbgpu_ctx();
+    if (!ctx)
+        return LVBGPU_E_NOMEM;
+    int rc = context_common_init(ctx, device, n, lvbgpu_words_per_row(m));
+    if (rc == LVBGPU_OK)
+        rc = encode_into(ctx, n, m, rows, ctx->d_rows, ctx->stride_words);
+    if (rc == LVBGPU_OK)
+        rc = finish_rows(ctx);
+    if (rc != LVBGPU_OK)
+    {
+        g_last_error_noctx = ctx->last_error;
+        lvbgpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return LVBGPU_OK;
+}
+
+extern "C" long lvbgpu_n(const lvbgpu_ctx *ctx) { return ctx ? ctx->n : 0; }
+extern "C" long lvbgpu_nwords(const lvbgpu_ctx *ctx) { return ctx ? ctx->nwords : 0; }
+
+// =================================================================================== resident tree
+
+namespace lvbgpu_detail
+{
+// run one stored-result program (full evaluation or commit) against the resident rows and
+// refresh S_all / current length.  `prog` holds node ids.
+// refresh cur_length from the device scalars (after an asynchronous commit)
+int read_current_length(lvbgpu_ctx *ctx)
+{
+    if (!ctx->cur_length_stale)
+        return LVBGPU_OK;
+    // length = S_all (kept current by every commit) + the root slot of changes[]
+    long long s_all = 0, root_changes = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&s_all, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&root_changes, ctx->d_changes + ctx->nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cur_length = s_all + root_changes;
+    ctx->cur_length_stale = false;
+    return LVBGPU_OK;
+}
+
+// readback = false: everything is only enqueued (own pinned slot for the program, no
+// synchronisation); the caller already knows the length from scoring the candidate
+int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool readback)
+{
+    int rc = check_depth(ctx, prog.max_stack);
+    if (rc != LVBGPU_OK)
+        return rc;
+    Packed pk;
+    pk.add(prog, 0, 0, 0, 0);
+    // the program goes through one of a few pinned slots, each guarded by an event, so the host
+    // never waits for the device here
+    const size_t o_t = align16(sizeof(CandDesc));
+    const size_t o_d = o_t + align16(prog.toks.size() * 4);
+    const size_t total = o_d + align16(prog.dsts.size() * 4);
+    const int slot = ctx->commit_slot;
+    ctx->commit_slot = (slot + 1) % lvbgpu_ctx::COMMIT_SLOTS;
+    if (!ctx->commit_ev[slot])
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->commit_ev[slot], hipEventDisableTiming));
+    else
+        HIPCHK(ctx, hipEventSynchronize(ctx->commit_ev[slot])); // long done unless 4 commits are in flight
+    HIPCHK(ctx, ctx->h_commit[slot].reserve(total));
+    HIPCHK(ctx, ctx->d_commit[slot].reserve(total));
+    char *h = (char *)ctx->h_commit[slot].p;
+    memcpy(h, pk.cands.data(), sizeof(CandDesc));
+    memcpy(h + o_t, prog.toks.data(), prog.toks.size() * 4);
+    memcpy(h + o_d, prog.dsts.data(), prog.dsts.size() * 4);
+    DevBuf &dprog = ctx->d_commit[slot];
+    HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
+    HIPCHK(ctx, ctx->d_len.reserve(8));
+    if (zero_all)
+    {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
+    }
+    else // the accept path: one small launch clears everything the walk accumulates into and takes the
+         // recomputed nodes' old counts out of S_all
+        HIPCHK(ctx, launch_zero_changes((unsigned long long *)ctx->d_changes, (const int32_t *)((const char *)dprog.p + o_d),
+                                        (uint32_t)prog.dsts.size(), (unsigned long long *)ctx->d_changes + ctx->nb,
+                                        (unsigned long long *)ctx->d_len.p, (unsigned long long *)ctx->d_scalars,
+                                        ctx->stream));
+    WalkArgs a = resident_args(ctx, dprog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
+    if (!zero_all)
+        a.s_all_out = (unsigned long long *)ctx->d_scalars; // the walk adds the new counts: S_all stays current
+    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+    if (zero_all) // full evaluation: sum once
+        HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
+    ctx->cur_length_stale = true;
+    return readback ? read_current_length(ctx) : LVBGPU_OK;
+}
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32_t *right, int32_t root,
+                               int64_t *length_out)
+{
+    if (!ctx || !left || !right)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string why;
+    Topology t;
+    if (!t.assign((int32_t)ctx->n, left, right, root, &why))
+        return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    ctx->topo = std::move(t);
+    ctx->topo_version++;
+    ctx->have_tree = false;
+    Program prog;
+    ctx->pb.build_full(ctx->topo, prog);
+    int rc = run_commit_program(ctx, prog, true, true);
+    if (rc != LVBGPU_OK)
+        return rc;
+    ctx->have_tree = true;
+    if (length_out)
+        *length_out = ctx->cur_length;
+    if (ctx->cur_length <= 0)
+        return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_current_length(lvbgpu_ctx *ctx, int64_t *length_out)
+{
+    if (!ctx || !length_out)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = read_current_length(ctx);
+    if (rc != LVBGPU_OK)
+        return rc;
+    *length_out = ctx->cur_length;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_get_topology(lvbgpu_ctx *ctx, int32_t *parent, int32_t *left, int32_t *right, int32_t *root)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    if (parent)
+        memcpy(parent, ctx->topo.parent.data(), (size_t)ctx->nb * 4);
+    if (left)
+        memcpy(left, ctx->topo.left.data(), (size_t)ctx->nb * 4);
+    if (right)
+        memcpy(right, ctx->topo.right.data(), (size_t)ctx->nb * 4);
+    if (root)
+        *root = ctx->topo.root;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_get_changes(lvbgpu_ctx *ctx, int64_t *changes)
+{
+    if (!ctx || !changes)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(changes, ctx->d_changes, (size_t)ctx->nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out)
+{
+    if (!ctx || !out || node < 0 || node >= ctx->nb)
+        return LVBGPU_E_ARG;
+    if (node >= ctx->n && !ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // resident rows are bit planes; hand back the reference's nibble layout
+    HIPCHK(ctx, ctx->d_export.reserve((size_t)ctx->stride_words * 8));
+    HIPCHK(ctx, launch_export_row((const uint4 *)(ctx->d_rows + (size_t)node * ctx->stride_words),
+                                  (uint4 *)ctx->d_export.p, ctx->stride4, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_export.p, (size_t)ctx->nwords * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+// =================================================================================== batches
+
+extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit *edits, int32_t root,
+                             int64_t *length_out)
+{
+    if (!ctx || n_edits < 0 || (n_edits > 0 && !edits))
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string why;
+    Program prog;
+    if (!ctx->pb.build_candidate(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, prog, &why))
+        return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    if (!ctx->pb.apply_edits(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, &why))
+        return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+    ctx->topo_version++;
+    // length_out == NULL: the caller knows the length (it scored this candidate): nothing is
+    // read back and nothing waits - the commit is ordered before later work on the stream
+    int rc = run_commit_program(ctx, prog, false, length_out != nullptr);
+    if (rc != LVBGPU_OK)
+    {
+        ctx->have_tree = false; // resident state is no longer trustworthy
+        return rc;
+    }
+    if (length_out)
+    {
+        *length_out = ctx->cur_length;
+        if (ctx->cur_length <= 0)
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    }
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_timer_start(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_synchronize(lvbgpu_ctx *ctx)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LVBGPU_OK;
+}
+
+extern "C" void *lvbgpu_stream(lvbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+

@@ -1,0 +1,265 @@
+// api_propose.cpp - liblvbgpu.so: neighbourhoods whose rewrites and programs are built on the device (drawn there, or named by the host).
+#include "ctx.hpp"
+
+// ---- device-side neighbourhoods
+
+namespace lvbgpu_detail
+{
+// parent | left | right | number of leaves below, for propose_kernel
+int sync_device_topology(lvbgpu_ctx *ctx)
+{
+    if (ctx->d_topo_version == ctx->topo_version)
+        return LVBGPU_OK;
+    const int32_t nb = ctx->nb;
+    const Topology &t = ctx->topo;
+    std::vector<int32_t> host((size_t)4 * nb);
+    memcpy(host.data(), t.parent.data(), (size_t)nb * 4);
+    memcpy(host.data() + nb, t.left.data(), (size_t)nb * 4);
+    memcpy(host.data() + 2 * (size_t)nb, t.right.data(), (size_t)nb * 4);
+    int32_t *leaves = host.data() + 3 * (size_t)nb;
+    // leaves below each node: children before parents via an explicit preorder
+    std::vector<int32_t> order;
+    order.reserve(nb);
+    std::vector<int32_t> st{t.root};
+    while (!st.empty())
+    {
+        const int32_t v = st.back();
+        st.pop_back();
+        order.push_back(v);
+        if (t.left[v] >= 0)
+        {
+            st.push_back(t.left[v]);
+            st.push_back(t.right[v]);
+        }
+    }
+    for (auto it = order.rbegin(); it != order.rend(); ++it)
+    {
+        const int32_t v = *it;
+        leaves[v] = (t.left[v] < 0 || v == t.root) ? 1 : leaves[t.left[v]] + leaves[t.right[v]];
+    }
+    HIPCHK(ctx, ctx->d_topo4.reserve(host.size() * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_topo4.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // `host` goes out of scope
+    ctx->d_topo_version = ctx->topo_version;
+    return LVBGPU_OK;
+}
+} // namespace lvbgpu_detail
+
+namespace lvbgpu_detail
+{
+// why a move named by the host cannot be made on this topology (nullptr: it can).  Same conditions
+// as the generators (mutate_nni / mutate_spr / mutate_tbr, TreeOperations.c:174, 256-271, 450-461).
+const char *move_defect(const Topology &t, const lvbgpu_move &m)
+{
+    const int32_t n = t.n, nb = t.nb, root = t.root;
+    if (m.kind == 0)
+        return (m.a >= n && m.a < nb) ? nullptr : "NNI needs an internal node";
+    if (m.kind != 1 && m.kind != 2)
+        return "kind must be 0 (NNI), 1 (SPR) or 2 (TBR)";
+    const int32_t src = m.a, dest = m.b;
+    if (src < 0 || src >= nb || dest < 0 || dest >= nb)
+        return "node out of range";
+    if (src == root || src == t.left[root] || src == t.right[root])
+        return "the root and its children cannot be pruned";
+    const int32_t sp = t.parent[src];
+    const int32_t ss = t.left[sp] == src ? t.right[sp] : t.left[sp];
+    if (dest == src || dest == sp || dest == ss || dest == root)
+        return "destination is the source, its parent, its sister or the root";
+    for (int32_t p = t.parent[dest]; p != UNSET; p = t.parent[p])
+        if (p == src)
+            return "destination lies inside the pruned subtree";
+    if (m.kind == 2 && m.c >= 0)
+    {
+        const int32_t x = m.c;
+        if (x >= n || x == t.left[src] || x == t.right[src])
+            return "TBR re-roots at a leaf that is not a child of the subtree's top";
+        bool inside = false;
+        for (int32_t p = t.parent[x]; p != UNSET; p = t.parent[p])
+            if (p == src)
+            {
+                inside = true;
+                break;
+            }
+        if (!inside)
+            return "TBR leaf lies outside the pruned subtree";
+    }
+    return nullptr;
+}
+
+int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a, uint32_t mix_b, uint64_t seed,
+                       int64_t *lengths_out, const lvbgpu_move *moves = nullptr)
+{
+    if (!ctx || B < 1 || kind < -3 || kind > 2 || !lengths_out)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    if (ctx->n < 5)
+        return ctx->fail(LVBGPU_E_ARG, "rearrangements need at least 5 taxa");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = sync_device_topology(ctx);
+    if (rc != LVBGPU_OK)
+        return rc;
+    // fixed strides: a program has at most (n-3)+3 tokens; edits are capped (longer TBR paths overflow)
+    const uint32_t stride_t = (uint32_t)ctx->n + 8u;
+    const uint32_t stride_e = (uint32_t)std::min<int64_t>(ctx->nb, 512);
+    if ((uint64_t)B * stride_t >= (1ull << 32) || (uint64_t)B * ctx->ntiles >= (1ull << 31))
+        return ctx->fail(LVBGPU_E_ARG, "batch too large");
+    if (!ctx->prop_batch)
+    {
+        ctx->prop_batch = new (std::nothrow) lvbgpu_batch();
+        if (!ctx->prop_batch)
+            return LVBGPU_E_NOMEM;
+    }
+    lvbgpu_batch *bt = ctx->prop_batch;
+    const size_t o_t = align16((size_t)B * sizeof(CandDesc));
+    const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
+    const size_t total = o_d + align16((size_t)B * stride_t * 4);
+    HIPCHK(ctx, bt->d_prog.reserve(total));
+    const void *old_len = bt->d_len.p;
+    HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
+    if (bt->d_len.p != old_len)
+        bt->len_zeroed = false;
+    HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
+    HIPCHK(ctx, ctx->d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
+    HIPCHK(ctx, ctx->d_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
+    bt->ctx = ctx;
+    bt->B = B;
+    bt->off_toks = o_t;
+    bt->off_dsts = o_d;
+    bt->full_mode = false;
+    bt->stats = lvbgpu_batch_stats{};
+    bt->stats.candidates = B;
+    bt->stats.max_stack = 1; // at most one sibling set waits while the other path is walked
+    ctx->p_stride_t = stride_t;
+    ctx->p_stride_e = stride_e;
+    ctx->p_B = 0;
+    const lvbgpu_move_dev *d_moves = nullptr;
+    if (moves)
+    {
+        static_assert(sizeof(lvbgpu_move) == sizeof(lvbgpu_move_dev), "move layout");
+        // admissibility is an O(depth) walk per move: spread it over the host threads for long batches
+        int T = 1;
+        if (B >= 8192) // measured: waking the pool costs more than it saves below that
+        {
+            if (!ctx->pool && host_threads() > 1)
+                ctx->pool = new (std::nothrow) Pool(host_threads());
+            if (ctx->pool)
+                T = std::max(1, std::min(ctx->pool->size(), B / 1024));
+        }
+        std::vector<int32_t> first_bad((size_t)T, -1);
+        auto check = [&](int t) {
+            for (int32_t b = (int32_t)((int64_t)B * t / T); b < (int32_t)((int64_t)B * (t + 1) / T); b++)
+                if (move_defect(ctx->topo, moves[b]))
+                {
+                    first_bad[(size_t)t] = b;
+                    return;
+                }
+        };
+        if (T == 1)
+            check(0);
+        else
+            ctx->pool->run(T, check);
+        for (int t = 0; t < T; t++)
+            if (first_bad[(size_t)t] >= 0)
+            {
+                const int32_t b = first_bad[(size_t)t];
+                return ctx->fail(LVBGPU_E_TOPOLOGY, "move " + std::to_string(b) + ": " + move_defect(ctx->topo, moves[b]));
+            }
+        HIPCHK(ctx, ctx->d_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
+        HIPCHK(ctx, ctx->h_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
+        memcpy(ctx->h_moves.p, moves, (size_t)B * sizeof(lvbgpu_move)); // pinned staging: the caller's array may go away
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_moves.p, ctx->h_moves.p, (size_t)B * sizeof(lvbgpu_move), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        d_moves = (const lvbgpu_move_dev *)ctx->d_moves.p;
+    }
+    HIPCHK(ctx, launch_propose((const int32_t *)ctx->d_topo4.p, (int32_t)ctx->n, ctx->topo.root, kind, mix_a, mix_b, seed,
+                               (uint32_t)B,
+                               stride_t, stride_e, (uint32_t *)((char *)bt->d_prog.p + o_t),
+                               (int32_t *)((char *)bt->d_prog.p + o_d), (lvbgpu_edit_dev *)ctx->d_pedits.p,
+                               (CandDesc *)bt->d_prog.p, (ProposalInfo *)ctx->d_pinfo.p, d_moves, ctx->stream));
+    rc = lvbgpu_batch_launch(ctx, bt);
+    if (rc != LVBGPU_OK)
+        return rc;
+    // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
+    // when) the caller wants that candidate (lvbgpu_proposal_edits)
+    HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, wait_for_step(ctx, B));
+    HIPCHK(ctx, hipMemsetAsync(bt->d_len.p, 0, bt->d_len.cap, ctx->stream)); // for the next step, off its critical path
+    bt->len_zeroed = true;
+    const int64_t *len = (const int64_t *)bt->h_len.p;
+    for (int32_t b = 0; b < B; b++)
+    {
+        if (len[b] >= PROPOSAL_OVERFLOW_LENGTH)
+        {
+            lengths_out[b] = INT64_MAX;
+            continue;
+        }
+        lengths_out[b] = len[b];
+        if (len[b] <= 0)
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    }
+    ctx->p_B = B;
+    return LVBGPU_OK;
+}
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_propose_score(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint64_t seed, int64_t *lengths_out)
+{
+    if (kind < -1)
+        return LVBGPU_E_ARG;
+    return propose_score_impl(ctx, B, kind, 0, 0, seed, lengths_out);
+}
+
+extern "C" int lvbgpu_score_moves(lvbgpu_ctx *ctx, int32_t B, const lvbgpu_move *moves, int64_t *lengths_out)
+{
+    if (!moves)
+        return LVBGPU_E_ARG;
+    return propose_score_impl(ctx, B, 0, 0, 0, 0, lengths_out, moves);
+}
+
+extern "C" int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_nni, double p_spr, int64_t parity,
+                                          uint64_t seed, int64_t *lengths_out)
+{
+    if (parity >= 0)
+        return propose_score_impl(ctx, B, -2, (uint32_t)(parity & 1), 0, seed, lengths_out);
+    if (!(p_nni >= 0) || !(p_spr >= 0) || p_nni + p_spr > 1.0 + 1e-12)
+        return LVBGPU_E_ARG;
+    auto scaled = [](double p) { return (uint32_t)std::min(4294967295.0, p * 4294967296.0); };
+    return propose_score_impl(ctx, B, -3, scaled(p_nni), scaled(p_nni + p_spr), seed, lengths_out);
+}
+
+extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits,
+                                     int32_t *info4)
+{
+    if (!ctx || !edits || !n_edits)
+        return LVBGPU_E_ARG;
+    if (ctx->p_B <= 0 || b < 0 || b >= ctx->p_B)
+        return ctx->fail(LVBGPU_E_STATE, "no device batch holds that candidate: call lvbgpu_propose_score first");
+    if (ctx->d_topo_version != ctx->topo_version)
+        return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since that batch was drawn");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // this candidate's descriptor, then its edits
+    HIPCHK(ctx, ctx->h_pinfo.reserve(sizeof(ProposalInfo)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinfo.p, (const ProposalInfo *)ctx->d_pinfo.p + b, sizeof(ProposalInfo),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const ProposalInfo pi = *(const ProposalInfo *)ctx->h_pinfo.p;
+    if (pi.overflow)
+        return ctx->fail(LVBGPU_E_ARG, "that candidate overflowed the per-candidate buffers");
+    if (pi.n_edits > cap)
+        return ctx->fail(LVBGPU_E_ARG, "edit buffer too small");
+    static_assert(sizeof(lvbgpu_edit) == sizeof(lvbgpu_edit_dev), "edit layout");
+    HIPCHK(ctx, hipMemcpyAsync(edits, (const lvbgpu_edit_dev *)ctx->d_pedits.p + (size_t)b * ctx->p_stride_e,
+                               (size_t)pi.n_edits * sizeof(lvbgpu_edit), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_edits = pi.n_edits;
+    if (info4)
+    {
+        info4[0] = pi.kind;
+        info4[1] = pi.a;
+        info4[2] = pi.kind == 0 ? pi.flag : pi.b;
+        info4[3] = pi.c;
+    }
+    return LVBGPU_OK;
+}
+

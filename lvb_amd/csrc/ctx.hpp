@@ -1,0 +1,268 @@
+// ctx.hpp - what the api_*.cpp files of liblvbgpu.so share: buffers, the context and batch objects,
+// the error macro, and the few helpers defined in api_core.cpp that the other files call.
+#pragma once
+
+#include "../../include/lvbgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.hpp"
+#include "pool.hpp"
+#include "program.hpp"
+
+using namespace lvbgpu;
+
+namespace lvbgpu_detail
+{
+
+constexpr int ABI_VERSION = 1;
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// growable device buffer
+struct DevBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)4096);
+        want = want + want / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// growable pinned host buffer
+struct PinBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)4096);
+        want = want + want / 4;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// the reference's node record (LVB.h:121-128), as the strict-compat entry sees it
+struct RefNode
+{
+    long parent, left, right, changes;
+    uint64_t *sitestate;
+};
+static_assert(sizeof(RefNode) == 40, "reference node record is 40 bytes");
+
+// RCCL is loaded on demand so that the scoring library does not depend on it at load time
+struct Id128
+{
+    char bytes[128]; // ncclUniqueId
+};
+struct BuildWorker
+{
+    Topology topo;
+    uint64_t topo_version = ~0ull;
+    ProgramBuilder pb;
+    Program prog;
+    std::vector<CandDesc> cands;
+    int32_t max_stack = 0;
+    int64_t dirty = 0;
+    int rc = 0;
+    std::string why;
+};
+
+struct Rccl
+{
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128 /* ncclUniqueId by value */, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+} // namespace lvbgpu_detail
+
+using namespace lvbgpu_detail;
+
+struct lvbgpu_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    long n = 0, nwords = 0;
+    int32_t nb = 0;
+    uint32_t stride_words = 0, stride4 = 0, ntiles = 0;
+    uint32_t target_waves = TARGET_WAVES; // tuning knob (env LVBGPU_TARGET_WAVES)
+
+    uint64_t *d_rows = nullptr;              // [nb][stride_words]
+    unsigned long long *d_changes = nullptr; // [nb + 1]; slot nb = the two root combines
+    long long *d_scalars = nullptr;          // [0] S_all, [1] current length
+    bool have_tree = false;
+    int64_t cur_length = 0;
+
+    Topology topo;
+    uint64_t topo_version = 0; // bumped whenever topo changes (workers keep private copies)
+    ProgramBuilder pb;
+    Pool *pool = nullptr;
+    std::vector<BuildWorker> workers;
+
+    DevBuf d_len; // length slot of single-program launches (set_tree, commit)
+    static constexpr int COMMIT_SLOTS = 4;
+    PinBuf h_commit[COMMIT_SLOTS]; // commit programs in flight (asynchronous commits)
+    DevBuf d_commit[COMMIT_SLOTS];
+    hipEvent_t commit_ev[COMMIT_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int commit_slot = 0;
+    bool cur_length_stale = false; // the device holds a newer length than cur_length
+    DevBuf d_export;      // one row in nibble layout (lvbgpu_get_sets)
+    lvbgpu_batch *step_batch = nullptr; // recycled by lvbgpu_score_batch
+    lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
+    // device-side proposals (lvbgpu_propose_score)
+    lvbgpu_batch *prop_batch = nullptr;
+    DevBuf d_topo4, d_pedits, d_pinfo;
+    PinBuf h_pinfo;
+    DevBuf d_moves; // moves named by the host (lvbgpu_score_moves)
+    PinBuf h_moves;
+    uint64_t d_topo_version = ~0ull;
+    uint32_t p_stride_t = 0, p_stride_e = 0;
+    int32_t p_B = 0; // candidates of the last device batch (0: none)
+    PinBuf h_pin;
+    DevBuf d_cin, d_cout; // strict-compat arenas
+    PinBuf h_cin, h_cout;
+    std::vector<int32_t> slot_of;
+    std::vector<uint32_t> slot_epoch;
+    uint32_t slot_gen = 0;
+
+    void *comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    DevBuf d_comm;
+
+    std::string last_error;
+
+    int fail_hip(hipError_t e, const char *what)
+    {
+        last_error = std::string(what) + ": " + hipGetErrorString(e);
+        return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+                   ? LVBGPU_E_NODEVICE
+                   : (e == hipErrorOutOfMemory ? LVBGPU_E_NOMEM : LVBGPU_E_HIP);
+    }
+    int fail(int code, const std::string &why)
+    {
+        last_error = why;
+        return code;
+    }
+};
+
+struct lvbgpu_batch
+{
+    lvbgpu_ctx *ctx = nullptr;
+    int32_t B = 0;
+    DevBuf d_prog; // [cands][toks][dsts]
+    DevBuf d_len;
+    PinBuf h_len;  // lengths land here after every launch (async copy on the context's stream)
+    size_t off_toks = 0, off_dsts = 0;
+    lvbgpu_batch_stats stats{};
+    bool full_mode = false; // whole topologies: reads leaf rows only
+    // step batches owned by the context (lvbgpu_score_batch / _score_full_batch) run build -> launch
+    // -> lengths back to back, which lets them drop one synchronisation and take the zeroing of the
+    // length slots off the critical path
+    bool recycled = false;
+    bool len_zeroed = false; // d_len was cleared after the previous read-back
+};
+
+// steps up to this many candidates finish within a few hundred microseconds: poll for them instead of
+// sleeping in the runtime (its wake-up costs ~10 us per step)
+constexpr int32_t SPIN_WAIT_MAX_B = 16384;
+
+#define HIPCHK(ctx, call)                                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e__ = (call);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return (ctx)->fail_hip(e__, #call);                                                                        \
+    } while (0)
+
+
+namespace lvbgpu_detail
+{
+extern thread_local std::string g_last_error_noctx; // last error of calls that have no context yet
+
+// pack programs -> one host blob [CandDesc x B][toks][dsts] (16-byte aligned sections)
+struct Packed
+{
+    std::vector<CandDesc> cands;
+    std::vector<uint32_t> toks;
+    std::vector<int32_t> dsts;
+    int32_t max_stack = 0;
+    int64_t dirty = 0;
+    void add(const Program &p, size_t tok0, size_t dst0, long long base, uint32_t flags)
+    {
+        CandDesc cd{};
+        cd.tok_off = (uint32_t)tok0;
+        cd.ntok = (uint32_t)(p.toks.size() - tok0);
+        cd.dst_off = (uint32_t)dst0;
+        cd.ncomb = (uint32_t)(p.dsts.size() - dst0);
+        cd.base = base;
+        cd.flags = flags;
+        for (size_t i = tok0; i < p.toks.size(); i++)
+            cd.nfresh += (p.toks[i] & TOK_FRESH) ? 1u : 0u;
+        cands.push_back(cd);
+    }
+};
+
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// api_core.cpp
+int hip_status_noctx(hipError_t e, const char *what);
+hipError_t wait_for_step(lvbgpu_ctx *ctx, int32_t B);
+WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, size_t off_dsts, void *d_len, uint32_t B,
+                       int32_t max_stack);
+int check_depth(lvbgpu_ctx *ctx, int32_t max_stack);
+int read_current_length(lvbgpu_ctx *ctx);
+int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool readback);
+} // namespace lvbgpu_detail
+
+using namespace lvbgpu_detail;

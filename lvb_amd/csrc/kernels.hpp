@@ -1,4 +1,4 @@
-// kernels.hpp - launch interface between the C ABI (lvbgpu_api.cpp) and fitch_kernels.hip
+// kernels.hpp - launch interface between the C ABI (api_*.cpp) and fitch_kernels.hip
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
 // tests/native/pool_tsan.cpp - the host thread pool and the parallel program build pattern of
-// lvbgpu_api.cpp (build_into: one private Topology + ProgramBuilder per worker, slices of the batch,
+// api_batch.cpp (build_into: one private Topology + ProgramBuilder per worker, slices of the batch,
 // then a parallel gather) under ThreadSanitizer.  Built and run by tests/test_pool_tsan.py.
 // Exit code 0 and "ok" on stdout when the parallel result equals the serial one.
 #include <cstdio>

@@ -1,5 +1,5 @@
 """Race detection for the host side (the reference has none): the thread pool and the
-parallel program-build pattern of lvbgpu_api.cpp under ThreadSanitizer, on the CPU."""
+parallel program-build pattern of api_batch.cpp under ThreadSanitizer, on the CPU."""
 import subprocess
 from pathlib import Path
 
