@@ -190,14 +190,24 @@ def main():
 
     own_comm = False
     if world > 1:
-        # RCCL communicator of the scoring library itself (not torch's): id from rank 0
-        try:
-            uid = ranks.share_bytes(api.comm_unique_id() if rank == 0 else None)
-            ctx.comm_init(world, rank, uid)
-            own_comm = True
-        except api.LvbGpuError as exc:   # keep the scaling run alive: same reduction through torch's RCCL
-            print(f"[rank {rank}] lvbgpu_comm_init failed ({exc}); min-reduce falls back to torch.distributed",
-                  file=sys.stderr)
+        # RCCL communicator of the scoring library itself (not torch's).  Its init is collective, so the
+        # ranks first agree (through torch) that every one of them can take part: a rank that cannot must not
+        # leave the others waiting inside ncclCommInitRank.
+        if ranks.sum_over_ranks(int(api.comm_available())) == world:
+            uid = None
+            if rank == 0:
+                try:
+                    uid = api.comm_unique_id()
+                except api.LvbGpuError as exc:
+                    print(f"[rank 0] lvbgpu_comm_unique_id failed ({exc})", file=sys.stderr)
+            uid = ranks.share_bytes(uid)           # None from rank 0: every rank skips the library's communicator
+            if uid is not None:
+                try:
+                    ctx.comm_init(world, rank, uid)
+                    own_comm = True
+                except api.LvbGpuError as exc:   # keep the scaling run alive: same reduction through torch's RCCL
+                    print(f"[rank {rank}] lvbgpu_comm_init failed ({exc}); min-reduce falls back to torch.distributed",
+                          file=sys.stderr)
         own_comm = bool(ranks.sum_over_ranks(int(own_comm)) == world)
 
     def barrier():

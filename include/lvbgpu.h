@@ -193,6 +193,9 @@ void *lvbgpu_stream(lvbgpu_ctx *ctx); /* hipStream_t, for interop */
 
 /* ---- multi-GPU: best length over independent restarts (one context per process/GPU) ----
  * id is an opaque 128-byte RCCL unique id created on rank 0 and distributed by the launcher. */
+/* LVBGPU_OK if the RCCL library can be loaded in this process (call it on every rank and agree
+ * before any rank enters lvbgpu_comm_init, which is collective) */
+int lvbgpu_comm_available(void);
 int lvbgpu_comm_unique_id(void *id128);
 int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const void *id128);
 int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value /* in: local best, out: global best */,

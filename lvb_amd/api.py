@@ -76,6 +76,7 @@ SIGNATURES = {
     "lvbgpu_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "lvbgpu_synchronize": (C.c_int, [C.c_void_p]),
     "lvbgpu_stream": (C.c_void_p, [C.c_void_p]),
+    "lvbgpu_comm_available": (C.c_int, []),
     "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lvbgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lvbgpu_allreduce_min": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
@@ -338,6 +339,11 @@ class FitchContext:
         who = C.c_int32()
         self._chk(self.lib.lvbgpu_allreduce_min(self.h, C.byref(v), C.byref(who)))
         return v.value, who.value
+
+
+def comm_available() -> bool:
+    """Can this process load RCCL?  Agree on it across ranks before the collective comm_init."""
+    return load_library().lvbgpu_comm_available() == 0
 
 
 def comm_unique_id() -> bytes:

@@ -15,9 +15,13 @@ bool load_rccl(std::string *why)
     if (g_rccl.lib)
         return true;
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // a copy the process already holds (torch brings its own) first: one RCCL per process
     for (const char *nm : names)
-        if ((g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)))
+        if ((g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD)))
             break;
+    for (const char *nm : names)
+        if (!g_rccl.lib)
+            g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (!g_rccl.lib)
     {
         *why = std::string("dlopen librccl.so: ") + dlerror();
@@ -38,6 +42,15 @@ bool load_rccl(std::string *why)
 constexpr int NCCL_INT64 = 4; // ncclInt64
 constexpr int NCCL_MIN = 3;   // ncclMin
 } // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_comm_available(void)
+{
+    std::string why;
+    if (load_rccl(&why))
+        return LVBGPU_OK;
+    g_last_error_noctx = why;
+    return LVBGPU_E_COMM;
+}
 
 extern "C" int lvbgpu_comm_unique_id(void *id128)
 {
