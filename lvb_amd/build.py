@@ -25,7 +25,7 @@ GPU_SOURCES = ["fitch_kernels.hip", "propose_kernels.hip", "api_core.cpp", "api_
 GPU_HEADERS = ["kernels.hpp", "program.hpp", "pool.hpp", "ctx.hpp"]
 COMPAT_SOURCES = ["getplen_adapter.cpp"]
 HOST_SOURCES = ["host_api.cpp", "proposals.cpp", "anneal.cpp", "refsearch.cpp", "program.cpp"]
-HOST_HEADERS = ["program.hpp", "proposals.hpp", "host_tree.hpp"]
+HOST_HEADERS = ["program.hpp", "proposals.hpp", "host_tree.hpp", "refrng.hpp"]
 
 
 def _hipcc() -> str:
