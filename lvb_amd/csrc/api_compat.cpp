@@ -130,7 +130,7 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     HIPCHK(ctx, launch_relayout((uint4 *)((char *)ctx->d_cout.p + oo_rows), n_out, Wp / 2, false, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_cout.p, ctx->d_cout.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_for_step(ctx, 1)); // one small step: poll for it
 
     // write back exactly what the reference's getplen leaves behind (TreeEvaluation.c:228-229)
     const char *hout = (const char *)ctx->h_cout.p;
