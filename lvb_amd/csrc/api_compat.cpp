@@ -121,6 +121,7 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     a.changes_out = (unsigned long long *)((char *)ctx->d_cout.p + oo_ch);
     a.root_slot = n_out;
     a.in_stride4 = Wp / 2;
+    a.nrows = n_in; // rows of this call's staging block
     a.out_stride4 = Wp / 2;
     a.B = 1;
     a.ntiles = ctx->ntiles;

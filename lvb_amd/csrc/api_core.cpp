@@ -42,6 +42,7 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, siz
     a.len_out = (unsigned long long *)d_len;
     a.changes_out = ctx->d_changes;
     a.in_stride4 = ctx->stride4;
+    a.nrows = (uint32_t)ctx->nb;
     a.out_stride4 = ctx->stride4;
     a.B = B;
     a.ntiles = ctx->ntiles;

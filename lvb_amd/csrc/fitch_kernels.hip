@@ -32,6 +32,7 @@
 //
 // No MFMA: bitwise integer streaming, bound by L2/HBM bandwidth and VALU issue.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "kernels.hpp"
@@ -127,7 +128,11 @@ struct OffVec
     uint32_t lo, hi; // one 64-bit value per lane, split over two VGPRs
 };
 
-template <bool COMMIT>
+// WIDE: row offsets kept as 64-bit byte counts in two vectors (tree blocks of 64 GiB and more).  The
+// narrow form - offsets in 16-byte units, 32 bits, the shift folded into the address add - saves three
+// instructions per token, and instructions per token are what bound this kernel (a CU retires about one
+// per cycle over all its waves: profiles/experiments/r01_lds_hot_rows.md).
+template <bool COMMIT, bool WIDE>
 __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 {
     extern __shared__ uint4 lds_stack[]; // operand stack: [wave][level][lane]
@@ -177,6 +182,12 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(lane_ptr + off);
         return make_uint4(v.x, v.y, v.z, v.w);
     };
+    // narrow form: off16 counts 16-byte units; v_lshl_add_u64 shifts it on the way into the add
+    auto load_row16 = [&](uint32_t off16) -> uint4 {
+        asm volatile("" : "+v"(lane_ptr));
+        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(lane_ptr + ((uint64_t)off16 << 4));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
 
     // COMMIT: the combine just done produced node ds[k_comb] with `ch` changes in this lane
     auto produce = [&](uint32_t ch) {
@@ -217,18 +228,21 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
             // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
             const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
             // byte offset of that row, 64 bits in two vectors (the vector unit is not what bounds this loop)
-            const uint64_t myoff64 = (uint64_t)(mytok & TOK_ROW_MASK) * ((uint64_t)a.in_stride4 << 4);
+            const uint64_t myoff64 = WIDE ? (uint64_t)(mytok & TOK_ROW_MASK) * ((uint64_t)a.in_stride4 << 4)
+                                          : (uint64_t)((mytok & TOK_ROW_MASK) * a.in_stride4); // bytes | 16-byte units
             OffVec o0{(uint32_t)myoff64, (uint32_t)(myoff64 >> 32)};
             // the same offsets seen from 1, 2, 3 lanes further down, so that the four refills of a
             // group read lane j of four vectors with ONE scalar index
             auto down = [&](const OffVec &v, uint32_t k) {
                 const int sel = (int)(((lane + k) & 63u) << 2);
                 return OffVec{(uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v.lo),
-                              (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v.hi)};
+                              WIDE ? (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v.hi) : 0u};
             };
             const OffVec o1 = down(o0, 1u), o2 = down(o0, 2u), o3 = down(o0, 3u);
             auto row_at = [&](const OffVec &v, uint32_t j) -> uint4 {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.lo, (int)j);
+                if constexpr (!WIDE)
+                    return load_row16(lo);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)v.hi, (int)j);
                 return load_row(((uint64_t)hi << 32) | lo);
             };
@@ -540,22 +554,39 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
     nblk = (nblk + 7u) & ~7u; // the XCD remap needs a multiple of 8
     const size_t lds = (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4);
     const dim3 grid(nblk), block(WALK_THREADS);
+    // offsets in 16-byte units must fit 32 bits; LVBGPU_WIDE_OFFSETS=1 forces the 64-bit form (tests)
+    static const bool force_wide = [] {
+        const char *e = getenv("LVBGPU_WIDE_OFFSETS");
+        return e && e[0] == '1';
+    }();
+    const bool wide = force_wide || (uint64_t)args.nrows * args.in_stride4 >= (1ull << 32);
     if (commit)
-        hipLaunchKernelGGL((fitch_walk<true>), grid, block, lds, stream, a);
+    {
+        if (wide)
+            hipLaunchKernelGGL((fitch_walk<true, true>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((fitch_walk<true, false>), grid, block, lds, stream, a);
+    }
+    else if (wide)
+        hipLaunchKernelGGL((fitch_walk<false, true>), grid, block, lds, stream, a);
     else
-        hipLaunchKernelGGL((fitch_walk<false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((fitch_walk<false, false>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t raise_lds_limit()
 {
     // whole-tree programs may want more than the default 64 KiB of dynamic LDS
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fitch_walk<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-    if (e != hipSuccess)
-        return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&fitch_walk<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    for (const void *f : {reinterpret_cast<const void *>(&fitch_walk<true, true>),
+                          reinterpret_cast<const void *>(&fitch_walk<true, false>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, true>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, false>)})
+    {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,

@@ -45,6 +45,7 @@ struct WalkArgs
     unsigned long long *changes_out;    // COMMIT: per-node change accumulators, zeroed for dsts
     unsigned long long *s_all_out;      // COMMIT on the resident tree: running sum of all internal changes (may be null)
     uint32_t in_stride4, out_stride4;   // row strides in 16-byte units
+    uint32_t nrows;                     // rows addressable through rows_in (picks 32- or 64-bit row offsets)
     uint32_t B, ntiles;
     uint32_t ngroups;                   // tiles are dealt to this many groups; one wave walks one (group, candidate)
     uint32_t nitems;                    // B * ngroups

@@ -238,3 +238,19 @@ def test_rccl_communicator_single_rank(api):
     assert ctx.allreduce_min(123456789012) == (123456789012, 0)
     assert ctx.allreduce_min(7) == (7, 0)
     ctx.close()
+
+
+def test_wide_row_offset_form_matches_reference(api):
+    """fitch_walk has two address forms: 32-bit offsets in 16-byte units (tree blocks below 64 GiB, every
+    shape above) and 64-bit byte offsets.  LVBGPU_WIDE_OFFSETS=1 forces the second for the whole process, so
+    the same parity cases run once more in ONE child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LVBGPU_WIDE_OFFSETS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "full_evaluation or incremental_batches or full_batch or golden_vectors",
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-500:]
