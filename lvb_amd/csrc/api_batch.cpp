@@ -195,7 +195,13 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
         gather(0);
     else
         ctx->pool->run(T, gather);
-    HIPCHK(ctx, hipMemcpyAsync(bt->d_prog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+    // small recycled steps: lengths return through the walk's last wave, and a small enough batch of
+    // programs is read where it lies (pinned, device-visible) instead of being copied first
+    const uint32_t ngroups = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
+    bt->direct = bt->recycled && ctx->direct_steps && (uint64_t)B * ngroups <= DIRECT_STEP_MAX_ITEMS;
+    bt->in_place = bt->direct && total * ngroups <= DIRECT_READ_MAX_BYTES;
+    if (!bt->in_place)
+        HIPCHK(ctx, hipMemcpyAsync(bt->d_prog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
     // h_pin is reused by the next upload.  A recycled step batch is read back (and the stream
     // drained) by lvbgpu_batch_lengths before anything can build again: no need to wait here.
     if (!bt->recycled)
@@ -251,27 +257,64 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
     if (!ctx || !b || b->ctx != ctx)
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!b->len_zeroed)
-        HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, (size_t)b->B * 8, ctx->stream));
+    if (!b->len_zeroed) // the whole buffer: a direct step's last wave re-zeroes only the B slots it used
+        HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->recycled ? b->d_len.cap : (size_t)b->B * 8, ctx->stream));
     b->len_zeroed = false;
-    WalkArgs a = resident_args(ctx, b->d_prog, b->off_toks, b->off_dsts, b->d_len.p, (uint32_t)b->B,
-                               (int32_t)b->stats.max_stack);
+    WalkArgs a = resident_args(ctx, b->in_place ? ctx->h_pin.p : b->d_prog.p, b->off_toks, b->off_dsts, b->d_len.p,
+                               (uint32_t)b->B, (int32_t)b->stats.max_stack);
+    if (b->direct)
+    {
+        a.host_len = (unsigned long long *)b->h_len.p;
+        a.done_count = (uint32_t *)(ctx->d_scalars + 2);
+        a.host_flag = (uint32_t *)ctx->h_step.p;
+        a.step_seq = ++ctx->step_seq;
+    }
     HIPCHK(ctx, launch_walk(a, false, ctx->stream));
     return LVBGPU_OK;
 }
+
+namespace lvbgpu_detail
+{
+// a direct step's lengths are in h_len once the walk's last wave has released the step's sequence number
+static hipError_t wait_for_direct_step(lvbgpu_ctx *ctx)
+{
+    const uint32_t *flag = (const uint32_t *)ctx->h_step.p;
+    for (uint32_t spins = 1;; spins++)
+    {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->step_seq)
+            return hipSuccess;
+        if ((spins & 1023u) == 0)
+        {
+            // a finished (or failed) stream ends the wait whatever the flag says: after the kernel
+            // everything it wrote is visible
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q != hipErrorNotReady)
+                return q;
+        }
+    }
+}
+} // namespace lvbgpu_detail
 
 extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *lengths_out)
 {
     if (!ctx || !b || b->ctx != ctx || !lengths_out)
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // through pinned memory: one DMA, no staging
-    HIPCHK(ctx, hipMemcpyAsync(b->h_len.p, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (b->recycled)
-        HIPCHK(ctx, wait_for_step(ctx, b->B));
+    if (b->direct)
+    {
+        HIPCHK(ctx, wait_for_direct_step(ctx));
+        b->len_zeroed = true; // by the walk's last wave
+    }
     else
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (b->recycled)
+    {
+        // through pinned memory: one DMA, no staging
+        HIPCHK(ctx, hipMemcpyAsync(b->h_len.p, b->d_len.p, (size_t)b->B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (b->recycled)
+            HIPCHK(ctx, wait_for_step(ctx, b->B));
+        else
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (b->recycled && !b->direct)
     {
         // clear the slots for the next step now, while the host consumes these lengths
         HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->d_len.cap, ctx->stream));

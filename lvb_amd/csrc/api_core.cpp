@@ -28,15 +28,15 @@ hipError_t wait_for_step(lvbgpu_ctx *ctx, int32_t B)
     return q;
 }
 
-WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, size_t off_dsts, void *d_len,
+WalkArgs resident_args(lvbgpu_ctx *ctx, const void *prog, size_t off_toks, size_t off_dsts, void *d_len,
                        uint32_t B, int32_t max_stack)
 {
     WalkArgs a{};
     a.rows_in = (const uint4 *)ctx->d_rows;
     a.rows_out = (uint4 *)ctx->d_rows;
-    a.cands = (const CandDesc *)prog.p;
-    a.toks = (const uint32_t *)((const char *)prog.p + off_toks);
-    a.dsts = (const int32_t *)((const char *)prog.p + off_dsts);
+    a.cands = (const CandDesc *)prog;
+    a.toks = (const uint32_t *)((const char *)prog + off_toks);
+    a.dsts = (const int32_t *)((const char *)prog + off_dsts);
     a.node_changes = (const long long *)ctx->d_changes;
     a.s_all = ctx->d_scalars;
     a.len_out = (unsigned long long *)d_len;
@@ -88,9 +88,13 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)ctx->nb * ctx->stride_words * 8));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_changes, (size_t)(ctx->nb + 1) * 8));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_scalars, 2 * 8));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_scalars, 4 * 8)); // [2]: finished-wave count of direct steps
     HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 32, ctx->stream));
+    HIPCHK(ctx, ctx->h_step.reserve(64));
+    memset(ctx->h_step.p, 0, 64);
+    if (const char *ds = getenv("LVBGPU_DIRECT_STEPS"))
+        ctx->direct_steps = ds[0] != '0';
     HIPCHK(ctx, upload_iupac_table());
     HIPCHK(ctx, raise_lds_limit());
     ctx->pb.resize(ctx->nb);
@@ -251,6 +255,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->h_pinfo.release();
     ctx->d_moves.release();
     ctx->h_moves.release();
+    ctx->h_step.release();
+    ctx->d_tmp_changes.release();
     for (lvbgpu_batch *rb : {ctx->step_batch, ctx->full_batch, ctx->prop_batch})
         if (rb)
         {
@@ -385,26 +391,53 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
     memcpy(h + o_t, prog.toks.data(), prog.toks.size() * 4);
     memcpy(h + o_d, prog.dsts.data(), prog.dsts.size() * 4);
     DevBuf &dprog = ctx->d_commit[slot];
-    HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
     HIPCHK(ctx, ctx->d_len.reserve(8));
     if (zero_all)
     {
+        // full evaluation: everything is cleared, every node recomputed, the counts summed once
+        HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
+        WalkArgs a = resident_args(ctx, dprog.p, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
+        HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+        HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
     }
-    else // the accept path: one small launch clears everything the walk accumulates into and takes the
-         // recomputed nodes' old counts out of S_all
+    else if (!ctx->direct_steps)
+    {
+        // LVBGPU_DIRECT_STEPS=0: copy, one small launch that clears what the walk accumulates into and takes
+        // the recomputed nodes' old counts out of S_all, then the walk
+        HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
         HIPCHK(ctx, launch_zero_changes((unsigned long long *)ctx->d_changes, (const int32_t *)((const char *)dprog.p + o_d),
                                         (uint32_t)prog.dsts.size(), (unsigned long long *)ctx->d_changes + ctx->nb,
                                         (unsigned long long *)ctx->d_len.p, (unsigned long long *)ctx->d_scalars,
                                         ctx->stream));
-    WalkArgs a = resident_args(ctx, dprog, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
-    if (!zero_all)
+        WalkArgs a = resident_args(ctx, dprog.p, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
         a.s_all_out = (unsigned long long *)ctx->d_scalars; // the walk adds the new counts: S_all stays current
-    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
-    if (zero_all) // full evaluation: sum once
-        HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
+        HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+    }
+    else
+    {
+        // the accept path is ONE launch: the walk's last wave settles changes[] and S_all itself (fused
+        // commit, kernels.hpp), and a small program is read where it lies in the pinned slot
+        const uint32_t ngroups = choose_groups(1, ctx->ntiles, ctx->target_waves);
+        const bool in_place = total * ngroups <= DIRECT_READ_MAX_BYTES;
+        if (!in_place)
+            HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)(ctx->nb + 1) * 8));
+        if (!ctx->tmp_changes_zeroed)
+        {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
+            ctx->tmp_changes_zeroed = true;
+        }
+        WalkArgs a = resident_args(ctx, in_place ? (const void *)h : dprog.p, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
+        a.s_all_out = (unsigned long long *)ctx->d_scalars;
+        a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
+        a.done_count = (uint32_t *)(ctx->d_scalars + 2);
+        HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream)); // the slot is free once the walk has read it
+    }
     ctx->cur_length_stale = true;
     return readback ? read_current_length(ctx) : LVBGPU_OK;
 }

@@ -170,6 +170,13 @@ struct lvbgpu_ctx
     uint32_t p_stride_t = 0, p_stride_e = 0;
     int32_t p_B = 0; // candidates of the last device batch (0: none)
     PinBuf h_pin;
+    // direct steps: small batches whose programs the walk reads straight from h_pin and whose lengths its last
+    // wave writes straight into the batch's pinned buffer; the host polls h_step's first word for step_seq
+    PinBuf h_step;
+    uint32_t step_seq = 0;
+    bool direct_steps = true; // env LVBGPU_DIRECT_STEPS=0 turns them off (A/B measurements)
+    DevBuf d_tmp_changes;     // fused commits: per-combine accumulators, zero between launches
+    bool tmp_changes_zeroed = false;
     DevBuf d_cin, d_cout; // strict-compat arenas
     PinBuf h_cin, h_cout;
     std::vector<int32_t> slot_of;
@@ -211,11 +218,19 @@ struct lvbgpu_batch
     // length slots off the critical path
     bool recycled = false;
     bool len_zeroed = false; // d_len was cleared after the previous read-back
+    bool direct = false;     // this step's lengths come back through the walk's last wave (no copy, no stream wait)
+    bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
 };
 
 // steps up to this many candidates finish within a few hundred microseconds: poll for them instead of
 // sleeping in the runtime (its wake-up costs ~10 us per step)
 constexpr int32_t SPIN_WAIT_MAX_B = 16384;
+// direct steps: lengths come back through the walk's last wave while the launch has at most this many waves
+// (every wave ticks one counter: measured on MI355X a gain up to a few hundred waves, a loss from ~1000) ...
+constexpr uint32_t DIRECT_STEP_MAX_ITEMS = 512;
+// ... and programs are read in place (pinned host memory) while all the waves together fetch at most this much
+// over the host link (measured: faster than the copy up to ~64 KiB, slower beyond)
+constexpr size_t DIRECT_READ_MAX_BYTES = 64u << 10;
 
 #define HIPCHK(ctx, call)                                                                                              \
     do                                                                                                                 \
@@ -258,7 +273,7 @@ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // api_core.cpp
 int hip_status_noctx(hipError_t e, const char *what);
 hipError_t wait_for_step(lvbgpu_ctx *ctx, int32_t B);
-WalkArgs resident_args(lvbgpu_ctx *ctx, const DevBuf &prog, size_t off_toks, size_t off_dsts, void *d_len, uint32_t B,
+WalkArgs resident_args(lvbgpu_ctx *ctx, const void *prog, size_t off_toks, size_t off_dsts, void *d_len, uint32_t B,
                        int32_t max_stack);
 int check_depth(lvbgpu_ctx *ctx, int32_t max_stack);
 int read_current_length(lvbgpu_ctx *ctx);

@@ -197,9 +197,14 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
             a.rows_out[(size_t)dst * a.out_stride4 + col] = acc;
         if (lane == 0 && s)
         {
-            atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
-            if (dst >= 0 && a.s_all_out)
-                atomicAdd(a.s_all_out, (unsigned long long)s); // S_all follows the commit: no separate summing pass
+            if (a.tmp_changes)
+                atomicAdd(a.tmp_changes + k_comb, (unsigned long long)s); // settled by the launch's last wave
+            else
+            {
+                atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
+                if (dst >= 0 && a.s_all_out)
+                    atomicAdd(a.s_all_out, (unsigned long long)s); // S_all follows the commit: no separate summing pass
+            }
         }
         k_comb++;
     };
@@ -381,8 +386,99 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         }
         total += (unsigned long long)base;
     }
-    if (lane == 0)
+    if constexpr (!COMMIT)
+    {
+        if (a.host_len && a.ngroups == 1u)
+        {
+            // direct step, one wave per candidate: `total` is the whole length - straight to the host, and the
+            // last wave to tick releases the flag (every wave's store is system-visible before its tick)
+            if (lane == 0)
+            {
+                __hip_atomic_store(a.host_len + cand, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+                if (atomicAdd(a.done_count, 1u) == a.nitems - 1u)
+                {
+                    __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __threadfence_system();
+                    __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+    }
+    if (lane == 0 && !(COMMIT && a.tmp_changes)) // a fused commit's length is S_all + the root slot
         atomicAdd(a.len_out + cand, total);
+
+    if constexpr (COMMIT)
+    {
+        if (a.tmp_changes)
+        {
+            uint32_t last = 0;
+            if (lane == 0)
+            {
+                __threadfence(); // our partial counts before our tick
+                last = atomicAdd(a.done_count, 1u) == a.nitems - 1u ? 1u : 0u;
+            }
+            if (__builtin_amdgcn_readfirstlane(last))
+            {
+                __threadfence();
+                long long delta = 0;               // new - old over the recomputed internal nodes
+                unsigned long long root_changes = 0; // the two root combines (dst < 0)
+                for (uint32_t i = lane; i < cd.ncomb; i += 64u)
+                {
+                    const unsigned long long v = __hip_atomic_load(a.tmp_changes + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.tmp_changes + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int32_t dst = ds[i];
+                    if (dst >= 0)
+                    {
+                        delta += (long long)v - (long long)a.changes_out[dst];
+                        a.changes_out[dst] = v;
+                    }
+                    else
+                        root_changes += v;
+                }
+                for (int off = 32; off > 0; off >>= 1)
+                {
+                    delta += __shfl_xor(delta, off);
+                    root_changes += __shfl_xor(root_changes, off);
+                }
+                if (lane == 0)
+                {
+                    a.changes_out[a.root_slot] = root_changes;
+                    *a.s_all_out += (unsigned long long)delta;
+                    __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    else
+    {
+        if (a.host_len)
+        {
+            // the launch's last wave hands the lengths to the host itself (threadfence-reduction pattern)
+            uint32_t last = 0;
+            if (lane == 0)
+            {
+                __threadfence(); // our sum before our count
+                last = atomicAdd(a.done_count, 1u) == a.nitems - 1u ? 1u : 0u;
+            }
+            if (__builtin_amdgcn_readfirstlane(last))
+            {
+                __threadfence(); // every wave's sum before our reads
+                for (uint32_t i = lane; i < a.B; i += 64u)
+                {
+                    const unsigned long long v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.len_out + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next step
+                    __hip_atomic_store(a.host_len + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (lane == 0)
+                    __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system(); // the wave's stores (all lanes) before the flag
+                if (lane == 0)
+                    __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -54,6 +54,18 @@ struct WalkArgs
     uint32_t tiles_per, tiles_rem, inv_B;
     uint32_t stack_depth;               // operand-stack levels per wave in LDS (>= 1)
     uint32_t root_slot;                 // COMMIT: changes_out slot that collects the two root combines
+    // direct steps (small batches, host_len != null): the last wave of the launch to finish copies the B lengths
+    // into host-mapped memory, clears the length slots and the counter, and releases *host_flag = step_seq.
+    // The host polls that word: no copy engine and no stream wait on the step's critical path.
+    unsigned long long *host_len;       // [B] in pinned host memory
+    uint32_t *done_count;               // device word, zero between launches
+    uint32_t *host_flag;                // pinned host word
+    uint32_t step_seq;
+    // fused commits (COMMIT, tmp_changes != null): the waves accumulate combine k's changes in tmp_changes[k]
+    // (zero between launches); the last wave to finish moves them into changes_out[], keeps *s_all_out current
+    // with the difference to what those nodes held before, and clears tmp_changes and done_count again - no
+    // separate zeroing launch in front of a commit.
+    unsigned long long *tmp_changes;
 };
 
 // how many tile groups to cut ntiles into for a batch of B candidates

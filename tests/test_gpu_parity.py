@@ -240,15 +240,17 @@ def test_rccl_communicator_single_rank(api):
     ctx.close()
 
 
-def test_wide_row_offset_form_matches_reference(api):
+def test_wide_offsets_and_copy_path_steps_match_reference(api):
     """fitch_walk has two address forms: 32-bit offsets in 16-byte units (tree blocks below 64 GiB, every
     shape above) and 64-bit byte offsets.  LVBGPU_WIDE_OFFSETS=1 forces the second for the whole process, so
-    the same parity cases run once more in ONE child process with it set."""
+    the same parity cases run once more in ONE child process with it set.  The same child turns direct steps
+    and fused commits off (LVBGPU_DIRECT_STEPS=0): the copy / zeroing-launch forms of a step and of a commit
+    stay covered as well."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LVBGPU_WIDE_OFFSETS="1")
+    env = dict(os.environ, LVBGPU_WIDE_OFFSETS="1", LVBGPU_DIRECT_STEPS="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu",
                         "-q", "-x", "-k", "full_evaluation or incremental_batches or full_batch or golden_vectors",
                         "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
