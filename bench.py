@@ -284,7 +284,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "lvbgpu::fitch_walk<false>", "launch_ms": launch_ms,
+            "kernel": "lvbgpu::fitch_walk<false, false>", "launch_ms": launch_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "algorithmic bytes = (D+3) clean rows x nwords x 8 per candidate; rows are re-read from "
                     "the XCD L2 / Infinity Cache, so achieved may exceed the HBM figure",

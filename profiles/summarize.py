@@ -16,7 +16,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-KERNEL = "fitch_walk<false>"
+KERNEL = "fitch_walk<false,"  # <COMMIT=false, WIDE=...>
 
 
 def main(tag: str) -> None:
