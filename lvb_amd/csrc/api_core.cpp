@@ -55,7 +55,8 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const void *prog, size_t off_toks, size_
 
 int check_depth(lvbgpu_ctx *ctx, int32_t max_stack)
 {
-    if ((size_t)max_stack * WALK_WAVES * 64 * sizeof(uint4) > MAX_LDS_BYTES)
+    // two more KiB per wave than the stack itself: a commit walk parks at least one produced set (and the counts)
+    if ((size_t)(std::max(max_stack, 1) + 2) * WALK_WAVES * 64 * sizeof(uint4) > MAX_LDS_BYTES)
         return ctx->fail(LVBGPU_E_ARG, "postorder program needs a deeper operand stack than LDS holds");
     return LVBGPU_OK;
 }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     uint4 acc;
     uint32_t sp = 0;       // stack pointer (levels)
     uint32_t nonempty = 0; // sites with non-empty intersection, this lane, whole program
-    uint32_t k_comb = 0;   // combines done (index into ds[])
+    [[maybe_unused]] uint32_t k_comb = 0; // COMMIT: combines done in this tile (index into ds[])
     uint4 *const my_stack = lds_stack + (size_t)wave * a.stack_depth * 64u + lane;
 
     // row at byte offset `off` (wave-uniform) from rows_in -> this lane's group.  lane_ptr (rows_in +
@@ -189,24 +189,54 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         return make_uint4(v.x, v.y, v.z, v.w);
     };
 
-    // COMMIT: the combine just done produced node ds[k_comb] with `ch` changes in this lane
-    auto produce = [&](uint32_t ch) {
-        const int32_t dst = ds[k_comb];
-        const uint32_t s = wave_sum_bits(ch, 6); // ch <= 32
-        if (dst >= 0)
-            a.rows_out[(size_t)dst * a.out_stride4 + col] = acc;
-        if (lane == 0 && s)
+    // COMMIT with defer_slots: [slot][lane] sets and [slot] counts of the combines not yet written out
+    uint4 *const my_rows = lds_stack + (size_t)WALK_WAVES * a.stack_depth * 64u + (size_t)wave * a.defer_slots * 64u + lane;
+    uint32_t *const my_cnt = reinterpret_cast<uint32_t *>(lds_stack + (size_t)WALK_WAVES * (a.stack_depth + a.defer_slots) * 64u) +
+                             (size_t)wave * a.defer_slots;
+    uint32_t pend = 0;      // combines waiting in LDS
+    uint32_t k_flushed = 0; // combines of this tile already written out
+    auto add_count = [&](uint32_t k, int32_t dst, uint32_t s) {
+        if (a.tmp_changes)
+            atomicAdd(a.tmp_changes + k, (unsigned long long)s); // settled by the launch's last wave
+        else
         {
-            if (a.tmp_changes)
-                atomicAdd(a.tmp_changes + k_comb, (unsigned long long)s); // settled by the launch's last wave
-            else
-            {
-                atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
-                if (dst >= 0 && a.s_all_out)
-                    atomicAdd(a.s_all_out, (unsigned long long)s); // S_all follows the commit: no separate summing pass
-            }
+            atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
+            if (dst >= 0 && a.s_all_out)
+                atomicAdd(a.s_all_out, (unsigned long long)s); // S_all follows the commit: no separate summing pass
         }
+    };
+    // write out what waits in LDS: destinations fetched with one vector load BEFORE the first store, so the
+    // burst itself never waits on memory; lane s adds combine s's count (at most 64 slots)
+    auto flush = [&]() {
+        if (pend == 0)
+            return;
+        const int32_t mydst = lane < pend ? ds[k_flushed + lane] : -1;
+        const uint32_t mycnt = lane < pend ? my_cnt[lane] : 0u;
+        for (uint32_t s = 0; s < pend; s++)
+        {
+            const int32_t dst = __builtin_amdgcn_readlane(mydst, (int)s);
+            if (dst >= 0)
+                a.rows_out[(size_t)dst * a.out_stride4 + col] = my_rows[(size_t)s * 64u];
+        }
+        if (mycnt)
+            add_count(k_flushed + lane, mydst, mycnt);
+        k_flushed += pend;
+        pend = 0;
+        // drain here, once per burst: with a write possibly in flight the compiler would turn every later wait
+        // for a row into vmcnt(0) (reads and writes complete out of order with respect to each other)
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt and lgkmcnt untouched
+    };
+    // COMMIT: the combine just done produced node ds[k_comb] with `ch` changes in this lane; set and count wait
+    // in LDS for the next burst
+    auto produce = [&](uint32_t ch) {
+        const uint32_t s = wave_sum_bits(ch, 6); // ch <= 32
+        my_rows[(size_t)pend * 64u] = acc;
+        if (lane == 0)
+            my_cnt[pend] = s;
+        pend++;
         k_comb++;
+        if (__builtin_expect(pend == a.defer_slots, 0))
+            flush();
     };
 
     // One token = one combine, acc = fitch(acc, row), and ONE scalar test.  The scalar unit is shared by
@@ -226,7 +256,10 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     {
         acc = ones;
         if constexpr (COMMIT)
+        {
             k_comb = 0;
+            k_flushed = 0;
+        }
         for (uint32_t c0 = 0; c0 < cd.ntok; c0 += 64u)
         {
             const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
@@ -354,6 +387,8 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
             if (left > 6u)
                 step(jl + 2u, f & 64u, rc);
         }
+        if constexpr (COMMIT)
+            flush(); // this tile's last sets (col moves on with the tile)
     }
 
     // changes of this lane = 32 sites per combine (and per chain start, see step) minus the non-empty ones
@@ -648,7 +683,24 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
     a.inv_B = a.B == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / a.B);
     uint32_t nblk = (a.nitems + WALK_WAVES - 1) / WALK_WAVES;
     nblk = (nblk + 7u) & ~7u; // the XCD remap needs a multiple of 8
-    const size_t lds = (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4);
+    size_t lds = (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4);
+    a.defer_slots = 0;
+    if (commit)
+    {
+        // what LDS is left after the operand stack holds produced sets until a burst: 1 KiB per slot and wave
+        // (+ 4 bytes for its count); at least one slot (check_depth leaves room for it)
+        static const uint32_t max_slots = [] {
+            const char *e = getenv("LVBGPU_DEFER_SLOTS"); // tests: small bursts
+            const int v = e ? atoi(e) : 32;
+            return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+        }();
+        const uint32_t per_wave_kib = MAX_LDS_BYTES / WALK_WAVES / 1024u;
+        if (per_wave_kib < a.stack_depth + 2u)
+            return hipErrorInvalidValue;
+        const uint32_t room = per_wave_kib - a.stack_depth - 1u;
+        a.defer_slots = room < max_slots ? room : max_slots;
+        lds += (size_t)WALK_WAVES * a.defer_slots * (64u * sizeof(uint4) + sizeof(uint32_t));
+    }
     const dim3 grid(nblk), block(WALK_THREADS);
     // offsets in 16-byte units must fit 32 bits; LVBGPU_WIDE_OFFSETS=1 forces the 64-bit form (tests)
     static const bool force_wide = [] {

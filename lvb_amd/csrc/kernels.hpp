@@ -66,6 +66,11 @@ struct WalkArgs
     // with the difference to what those nodes held before, and clears tmp_changes and done_count again - no
     // separate zeroing launch in front of a commit.
     unsigned long long *tmp_changes;
+    // COMMIT: produced sets and their counts wait in LDS, this many per wave, and go out in bursts (filled by
+    // launch_walk, >= 1 for COMMIT).  A store or atomic inside the chain makes every wait for a
+    // row a full drain of the memory counter (reads and writes return out of order with respect to each other),
+    // which turns the 4-deep load ring into one round trip per token.
+    uint32_t defer_slots;
 };
 
 // how many tile groups to cut ntiles into for a batch of B candidates
