@@ -252,6 +252,21 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
     uint32_t nonempty_rare = 0; // kept apart so the hot path's counter has a single definition
 
+    // what the length's base needs (the cached changes of this candidate's dirty nodes, S_all) is requested
+    // here, together with the first rows, instead of as three dependent round trips after the walk - a small
+    // launch is a chain of round trips and nothing else
+    long long sub_early = 0, s_all_early = 0;
+    if (group == 0 && (cd.flags & CAND_RESIDENT_BASE))
+    {
+        for (uint32_t i = lane; i < cd.ncomb; i += 64u)
+        {
+            const int32_t dst = ds[i];
+            if (dst >= 0)
+                sub_early += a.node_changes[dst];
+        }
+        s_all_early = *a.s_all;
+    }
+
     for (uint32_t tile = tile_begin; tile < tile_end; tile++, col += 64u, lane_ptr += 1024)
     {
         acc = ones;
@@ -408,16 +423,10 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         long long base = cd.base;
         if (cd.flags & CAND_RESIDENT_BASE)
         {
-            long long sub = 0;
-            for (uint32_t i = lane; i < cd.ncomb; i += 64u)
-            {
-                const int32_t dst = ds[i];
-                if (dst >= 0)
-                    sub += a.node_changes[dst];
-            }
+            long long sub = sub_early;
             for (int off = 32; off > 0; off >>= 1)
                 sub += __shfl_xor(sub, off);
-            base += *a.s_all - sub;
+            base += s_all_early - sub;
         }
         total += (unsigned long long)base;
     }
