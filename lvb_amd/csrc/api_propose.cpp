@@ -168,35 +168,51 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
         HIPCHK(ctx, ctx->d_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
         HIPCHK(ctx, ctx->h_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
         memcpy(ctx->h_moves.p, moves, (size_t)B * sizeof(lvbgpu_move)); // pinned staging: the caller's array may go away
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_moves.p, ctx->h_moves.p, (size_t)B * sizeof(lvbgpu_move), hipMemcpyHostToDevice,
-                                   ctx->stream));
-        d_moves = (const lvbgpu_move_dev *)ctx->d_moves.p;
-    }
-    HIPCHK(ctx, launch_propose((const int32_t *)ctx->d_topo4.p, (int32_t)ctx->n, ctx->topo.root, kind, mix_a, mix_b, seed,
-                               (uint32_t)B,
-                               stride_t, stride_e, (uint32_t *)((char *)bt->d_prog.p + o_t),
-                               (int32_t *)((char *)bt->d_prog.p + o_d), (lvbgpu_edit_dev *)ctx->d_pedits.p,
-                               (CandDesc *)bt->d_prog.p, (ProposalInfo *)ctx->d_pinfo.p, d_moves, ctx->stream));
-    rc = lvbgpu_batch_launch(ctx, bt);
-    if (rc != LVBGPU_OK)
-        return rc;
-    // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
-    // when) the caller wants that candidate (lvbgpu_proposal_edits)
-    HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, wait_for_step(ctx, B));
-    HIPCHK(ctx, hipMemsetAsync(bt->d_len.p, 0, bt->d_len.cap, ctx->stream)); // for the next step, off its critical path
-    bt->len_zeroed = true;
-    const int64_t *len = (const int64_t *)bt->h_len.p;
-    for (int32_t b = 0; b < B; b++)
-    {
-        if (len[b] >= PROPOSAL_OVERFLOW_LENGTH)
+        // a short list is read by the generator where it lies (16 bytes per thread, once); a long one is copied
+        if (ctx->direct_steps && (size_t)B * sizeof(lvbgpu_move) <= DIRECT_READ_MAX_BYTES)
+            d_moves = (const lvbgpu_move_dev *)ctx->h_moves.p;
+        else
         {
-            lengths_out[b] = INT64_MAX;
-            continue;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_moves.p, ctx->h_moves.p, (size_t)B * sizeof(lvbgpu_move),
+                                       hipMemcpyHostToDevice, ctx->stream));
+            d_moves = (const lvbgpu_move_dev *)ctx->d_moves.p;
         }
-        lengths_out[b] = len[b];
-        if (len[b] <= 0)
-            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+    }
+    // the generator keeps its root-ward paths in LDS; when LDS is too small for the deepest possible path and a
+    // candidate does overflow, the batch is generated once more with the paths in scratch memory
+    for (int attempt = 0; attempt < 2; attempt++)
+    {
+        bool paths_capped = false;
+        HIPCHK(ctx, launch_propose((const int32_t *)ctx->d_topo4.p, (int32_t)ctx->n, ctx->topo.root, kind, mix_a, mix_b, seed,
+                                   (uint32_t)B, stride_t, stride_e, (uint32_t *)((char *)bt->d_prog.p + o_t),
+                                   (int32_t *)((char *)bt->d_prog.p + o_d), (lvbgpu_edit_dev *)ctx->d_pedits.p,
+                                   (CandDesc *)bt->d_prog.p, (ProposalInfo *)ctx->d_pinfo.p, d_moves, attempt > 0,
+                                   &paths_capped, ctx->stream));
+        rc = lvbgpu_batch_launch(ctx, bt);
+        if (rc != LVBGPU_OK)
+            return rc;
+        // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
+        // when) the caller wants that candidate (lvbgpu_proposal_edits)
+        HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, wait_for_step(ctx, B));
+        HIPCHK(ctx, hipMemsetAsync(bt->d_len.p, 0, bt->d_len.cap, ctx->stream)); // for the next step, off its critical path
+        bt->len_zeroed = true;
+        const int64_t *len = (const int64_t *)bt->h_len.p;
+        bool overflowed = false;
+        for (int32_t b = 0; b < B; b++)
+        {
+            if (len[b] >= PROPOSAL_OVERFLOW_LENGTH)
+            {
+                lengths_out[b] = INT64_MAX;
+                overflowed = true;
+                continue;
+            }
+            lengths_out[b] = len[b];
+            if (len[b] <= 0)
+                return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+        }
+        if (!(overflowed && paths_capped))
+            break;
     }
     ctx->p_B = B;
     return LVBGPU_OK;

@@ -110,8 +110,8 @@ struct ProposalInfo
 hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
                           uint64_t seed, uint32_t B,
                           uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves,
-                          hipStream_t stream);
+                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves, bool scratch_paths,
+                          bool *paths_capped, hipStream_t stream);
 
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();

@@ -14,6 +14,8 @@
 // merge, and the common path to the root; no general postorder is needed here (the general builder
 // stays on the host: program.cpp).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "kernels.hpp"
@@ -140,28 +142,73 @@ struct SprView
     }
 };
 
-constexpr int MAX_PATH = 768; // nodes of one root-ward path kept per thread (scratch memory); longer -> overflow flag
+constexpr int MAX_PATH = 768; // nodes of one root-ward path kept per thread; longer -> overflow flag
+
+// One root-ward path of a thread.  In LDS (16-bit node numbers, element i of thread t at [i * 64 + t]: conflict-free)
+// when the block's LDS holds it next to the topology, else in thread-private scratch memory, where every access is
+// a trip to the cache hierarchy - the generator is a chain of dependent accesses and nothing else.
+template <bool IN_LDS>
+struct PathStore;
+template <>
+struct PathStore<true>
+{
+    uint16_t *p;
+    int cap;
+    __device__ int32_t get(int i) const { return (int32_t)p[(size_t)i * 64u]; }
+    __device__ void set(int i, int32_t v) { p[(size_t)i * 64u] = (uint16_t)v; }
+};
+template <>
+struct PathStore<false>
+{
+    int32_t buf[MAX_PATH];
+    static constexpr int cap = MAX_PATH;
+    __device__ int32_t get(int i) const { return buf[i]; }
+    __device__ void set(int i, int32_t v) { buf[i] = v; }
+};
 
 } // namespace
 
 // kind_all: 0 NNI, 1 SPR, 2 TBR; -1: candidate b gets kind b % 3; -2: NNI/SPR alternate by the
 // parity of (mix_a + b) (reference -a 0, Solve.c:288-297); -3: drawn per candidate, NNI below
 // threshold mix_a, SPR below mix_b, else TBR, both scaled to 2^32 (reference -a 1, Solve.c:262-283)
+template <bool LDS_PATHS>
 __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const int32_t *right, const int32_t *leaves,
                                int32_t n, int32_t root, int32_t kind_all, uint32_t mix_a, uint32_t mix_b,
                                uint64_t seed, uint32_t B, uint32_t stride_t,
                                uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                               CandDesc *cands, ProposalInfo *info, int32_t use_lds, const lvbgpu_move_dev *moves)
+                               CandDesc *cands, ProposalInfo *info, int32_t use_lds, const lvbgpu_move_dev *moves,
+                               int32_t path_cap)
 {
     // The walk below is pointer chasing (two root-ward paths, a random descent for TBR): from global
     // memory every step is an L2 round trip.  When the four arrays fit, the block first copies them
     // into LDS (coalesced) and chases there.
-    extern __shared__ int32_t lds_topo[];
+    extern __shared__ __attribute__((aligned(16))) int32_t lds_topo[];
     const int32_t nb_all = 2 * n - 3;
     if (use_lds)
     {
-        for (int32_t i = (int32_t)threadIdx.x; i < 4 * nb_all; i += (int32_t)blockDim.x)
-            lds_topo[i] = parent[i]; // parent | left | right | leaves are contiguous (launch_propose)
+        // parent | left | right | leaves are contiguous and 16-byte aligned (launch_propose): 4 * nb ints = nb
+        // 16-byte pieces.  Eight loads in flight per thread: one wave copies 16 KB, and a loop of single dwords
+        // (62 dependent-looking round trips) was most of this kernel's time on small batches.
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(parent);
+        uint4 *dst4 = reinterpret_cast<uint4 *>(lds_topo);
+        for (int32_t i0 = 0; i0 < nb_all; i0 += 8 * (int32_t)blockDim.x)
+        {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const int32_t i = i0 + u * (int32_t)blockDim.x + (int32_t)threadIdx.x;
+                if (i < nb_all)
+                    v[u] = src4[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const int32_t i = i0 + u * (int32_t)blockDim.x + (int32_t)threadIdx.x;
+                if (i < nb_all)
+                    dst4[i] = v[u];
+            }
+        }
         __syncthreads();
         parent = lds_topo;
         left = lds_topo + nb_all;
@@ -286,7 +333,17 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
         pi.a = src;
         pi.b = dest;
 
-        int32_t buf1[MAX_PATH], buf2[MAX_PATH]; // root-ward paths (thread-private scratch)
+        PathStore<LDS_PATHS> buf1, buf2; // root-ward paths
+        if constexpr (LDS_PATHS)
+        {
+            // behind the topology copy: [2][path_cap][64 threads] node numbers
+            uint16_t *paths = reinterpret_cast<uint16_t *>(lds_topo + 4 * nb_all);
+            buf1.p = paths + threadIdx.x;
+            buf1.cap = path_cap;
+            buf2.p = paths + (size_t)path_cap * 64u + threadIdx.x;
+            buf2.cap = path_cap;
+        }
+        const int cap = buf1.cap;
         int32_t top = src;   // what hangs under sp next to dest
         bool have_acc = false; // a chain inside the moved subtree already feeds sp
         if (kind == 2 && t.leaves[src] > 2 && !(moves && given.c < 0))
@@ -311,29 +368,30 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             pi.c = x;
             // path P0 = parent(x) .. Pk = src; walk it from the bottom to emit edits, then emit the
             // chain from Pk upwards: Pk (other child, displaced(k-1)), Pi (displaced(i-1)), P0 (x)
-            int32_t *path = buf1;
+            PathStore<LDS_PATHS> &path = buf1;
             int k = 0;
-            for (int32_t p = t.parent[x]; p != src && k < MAX_PATH - 1; p = t.parent[p])
-                path[k++] = p;
-            if (k >= MAX_PATH - 1)
+            for (int32_t p = t.parent[x]; p != src && k < cap - 1; p = t.parent[p])
+                path.set(k++, p);
+            if (k >= cap - 1)
                 e.overflow = true;
-            path[k] = src;
+            path.set(k, src);
             // displaced[i] = the child of Pi that is not P(i-1) (for i = 0: the sister of x)
             // edits
             int32_t displaced = t.sister(x);
-            e.edit(path[0], path[1], x);
+            e.edit(path.get(0), path.get(1), x);
             for (int i = 1; i < k; i++)
             {
-                const int32_t pi_ = path[i];
-                const int32_t other = (t.left[pi_] == path[i - 1]) ? t.right[pi_] : t.left[pi_];
-                e.edit(pi_, path[i + 1], displaced);
+                const int32_t pi_ = path.get(i);
+                const int32_t other = (t.left[pi_] == path.get(i - 1)) ? t.right[pi_] : t.left[pi_];
+                e.edit(pi_, path.get(i + 1), displaced);
                 displaced = other;
             }
             {
                 const int32_t l = t.left[src], r = t.right[src];
-                e.edit(src, l == path[k - 1] ? displaced : l, l == path[k - 1] ? r : displaced);
+                const int32_t below_src = path.get(k - 1);
+                e.edit(src, l == below_src ? displaced : l, l == below_src ? r : displaced);
                 // chain bottom: src's two (clean) children in the new topology
-                e.tok(l == path[k - 1] ? r : l, TOK_FRESH);
+                e.tok(l == below_src ? r : l, TOK_FRESH);
                 e.tok(displaced, 0);
                 e.dst(src);
             }
@@ -341,16 +399,16 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             for (int i = k - 1; i >= 1; i--)
             {
                 // clean child of Pi in the new topology = displaced(i-1) = child of P(i-1) not on the path
-                const int32_t below_node = path[i - 1];
+                const int32_t below_node = path.get(i - 1);
                 const int32_t dis = (i - 1 == 0) ? t.sister(x)
-                                                 : ((t.left[below_node] == path[i - 2]) ? t.right[below_node]
-                                                                                        : t.left[below_node]);
+                                                 : ((t.left[below_node] == path.get(i - 2)) ? t.right[below_node]
+                                                                                            : t.left[below_node]);
                 e.tok(dis, 0);
-                e.dst(path[i]);
+                e.dst(path.get(i));
             }
             e.tok(x, 0);
-            e.dst(path[0]);
-            top = path[0];
+            e.dst(path.get(0));
+            top = path.get(0);
             have_acc = true;
         }
         const SprView nv{t, sp, ss, pp, dp, dest, top};
@@ -372,25 +430,25 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             e.edit(sp, dest, top);
         }
         // path A: sp upwards in the new topology (excluding the root)
-        int32_t *pa = buf1; // the TBR path above is no longer needed (top is saved)
+        PathStore<LDS_PATHS> &pa = buf1; // the TBR path above is no longer needed (top is saved)
         int na = 0;
-        for (int32_t v = sp; v != root && na < MAX_PATH; v = nv.parent(v))
-            pa[na++] = v;
-        if (na >= MAX_PATH)
+        for (int32_t v = sp; v != root && na < cap; v = nv.parent(v))
+            pa.set(na++, v);
+        if (na >= cap)
             e.overflow = true;
         // path B: pp upwards until it meets A or the root.  Both paths end just below the root, so
         // what they share is a common suffix: walk B to the top, then strip the suffix (linear,
         // instead of searching A for every node of B)
-        int32_t *pb = buf2;
+        PathStore<LDS_PATHS> &pb = buf2;
         int nbp = 0, meet_a = -1;
         if (pp != root)
         {
-            for (int32_t v = pp; v != root && nbp < MAX_PATH; v = nv.parent(v))
-                pb[nbp++] = v;
-            if (nbp >= MAX_PATH)
+            for (int32_t v = pp; v != root && nbp < cap; v = nv.parent(v))
+                pb.set(nbp++, v);
+            if (nbp >= cap)
                 e.overflow = true;
             int common = 0;
-            while (common < na && common < nbp && pa[na - 1 - common] == pb[nbp - 1 - common])
+            while (common < na && common < nbp && pa.get(na - 1 - common) == pb.get(nbp - 1 - common))
                 common++;
             if (common > 0)
             {
@@ -413,15 +471,15 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             e.dst(sp);
             for (int i = 1; i < upto; i++)
             {
-                e.tok(nv.other_child(pa[i], pa[i - 1]), 0);
-                e.dst(pa[i]);
+                e.tok(nv.other_child(pa.get(i), pa.get(i - 1)), 0);
+                e.dst(pa.get(i));
             }
         };
         if (nbp == 0)
         {
             // pp is the root, or pp already lies on A: one chain
             chain_from_sp(na);
-            last = pa[na - 1];
+            last = pa.get(na - 1);
         }
         else
         {
@@ -431,15 +489,15 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
             {
                 // B: pp (ss, other) ... up to the node below sp, then all of A with the chain as dirty child
                 int32_t l, r;
-                nv.children(pb[0], l, r);
+                nv.children(pb.get(0), l, r);
                 uint32_t push = have_acc ? TOK_PUSH : 0u;
                 e.tok(l, TOK_FRESH | push);
                 e.tok(r, 0);
-                e.dst(pb[0]);
+                e.dst(pb.get(0));
                 for (int i = 1; i < nbp; i++)
                 {
-                    e.tok(nv.other_child(pb[i], pb[i - 1]), 0);
-                    e.dst(pb[i]);
+                    e.tok(nv.other_child(pb.get(i), pb.get(i - 1)), 0);
+                    e.dst(pb.get(i));
                 }
                 // sp: children (dest = top of B chain [dirty], top)
                 if (have_acc)
@@ -451,10 +509,10 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
                 }
                 for (int i = 1; i < na; i++)
                 {
-                    e.tok(nv.other_child(pa[i], pa[i - 1]), 0);
-                    e.dst(pa[i]);
+                    e.tok(nv.other_child(pa.get(i), pa.get(i - 1)), 0);
+                    e.dst(pa.get(i));
                 }
-                last = pa[na - 1];
+                last = pa.get(na - 1);
             }
             else
             {
@@ -462,24 +520,24 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
                 const int a_len = meet_a >= 0 ? meet_a : na;
                 chain_from_sp(a_len);
                 int32_t l, r;
-                nv.children(pb[0], l, r);
+                nv.children(pb.get(0), l, r);
                 e.tok(l, TOK_FRESH | TOK_PUSH);
                 e.tok(r, 0);
-                e.dst(pb[0]);
+                e.dst(pb.get(0));
                 for (int i = 1; i < nbp; i++)
                 {
-                    e.tok(nv.other_child(pb[i], pb[i - 1]), 0);
-                    e.dst(pb[i]);
+                    e.tok(nv.other_child(pb.get(i), pb.get(i - 1)), 0);
+                    e.dst(pb.get(i));
                 }
                 if (meet_a >= 0)
                 {
-                    e.merge(pa[meet_a]); // both children of the meeting node are dirty
+                    e.merge(pa.get(meet_a)); // both children of the meeting node are dirty
                     for (int i = meet_a + 1; i < na; i++)
                     {
-                        e.tok(nv.other_child(pa[i], pa[i - 1]), 0);
-                        e.dst(pa[i]);
+                        e.tok(nv.other_child(pa.get(i), pa.get(i - 1)), 0);
+                        e.dst(pa.get(i));
                     }
-                    last = pa[na - 1];
+                    last = pa.get(na - 1);
                 }
                 else
                 {
@@ -526,25 +584,50 @@ __global__ void propose_kernel(const int32_t *parent, const int32_t *left, const
 hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
                           uint64_t seed, uint32_t B,
                           uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves, hipStream_t stream)
+                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves, bool scratch_paths,
+                          bool *paths_capped, hipStream_t stream)
 {
     const int32_t nb = 2 * n - 3;
+    static const hipError_t raised = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
+    const size_t lds_max = raised == hipSuccess ? 160u * 1024u : 64u * 1024u;
     // the topology in LDS when it fits (16 bytes per node; 160 KB of LDS per CU): up to ~5000 taxa
     size_t lds = (size_t)nb * 16u;
     int32_t use_lds = 1;
-    if (lds > 64u * 1024u)
+    if (lds > lds_max)
     {
-        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (raised != hipSuccess || lds > 160u * 1024u)
-        {
-            lds = 0;
-            use_lds = 0;
-        }
+        lds = 0;
+        use_lds = 0;
     }
-    hipLaunchKernelGGL(propose_kernel, dim3((B + 63) / 64), dim3(64), lds, stream, topo4, topo4 + nb, topo4 + 2 * nb,
-                       topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts, edits, cands,
-                       info, use_lds, moves);
+    // ... and behind it the threads' two root-ward paths: 256 bytes per path element and block.  No path has
+    // more than n - 2 nodes; with less room than that a deep tree can overflow a candidate, which the caller
+    // answers by running the batch again with the paths in scratch memory (*paths_capped says it may help)
+    int32_t path_cap = 0;
+    if (use_lds && !scratch_paths && nb <= 65535)
+    {
+        const size_t room = (lds_max - lds) / 256u;
+        const size_t want = (size_t)std::min(n, MAX_PATH);
+        path_cap = (int32_t)std::min(room, want);
+        if (path_cap < 64 && path_cap < n - 1)
+            path_cap = 0; // too little to be worth a second launch now and then
+    }
+    if (paths_capped)
+        *paths_capped = path_cap > 0 && path_cap < std::min(n - 1, MAX_PATH);
+    const dim3 grid((B + 63) / 64), block(64);
+    if (path_cap > 0)
+        hipLaunchKernelGGL(propose_kernel<true>, grid, block, lds + (size_t)path_cap * 256u, stream, topo4, topo4 + nb,
+                           topo4 + 2 * nb, topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts,
+                           edits, cands, info, use_lds, moves, path_cap);
+    else
+        hipLaunchKernelGGL(propose_kernel<false>, grid, block, lds, stream, topo4, topo4 + nb, topo4 + 2 * nb,
+                           topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts, edits, cands,
+                           info, use_lds, moves, 0);
     return hipGetLastError();
 }
 

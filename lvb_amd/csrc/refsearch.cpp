@@ -422,16 +422,21 @@ struct Driver
     {
         const int32_t B = (int32_t)cands.size();
         lens.resize((size_t)B);
-        int rc;
-        if (device_moves_min >= 0 && B >= device_moves_min)
+        int rc = LVBGPU_OK;
+        bool on_device = device_moves_min >= 0 && B >= device_moves_min;
+        if (on_device)
         {
             // long batch: 16 bytes per proposal go to the device, which builds the programs itself
             const auto t0 = Clock::now();
             rc = lvbgpu_score_moves(ctx, B, moves.data(), lens.data());
             dev_seconds += since(t0);
             device_move_steps++;
+            // a move the device generator could not represent in its fixed buffers has no length: this run must
+            // not guess, so the whole batch goes through the host's program builder instead
+            if (rc == LVBGPU_OK && std::find(lens.begin(), lens.end(), INT64_MAX) != lens.end())
+                on_device = false;
         }
-        else
+        if (rc == LVBGPU_OK && !on_device)
         {
             edits.clear();
             offs.assign(1, 0);
