@@ -214,11 +214,12 @@ def main():
         ctx.synchronize()
         ranks.barrier()
 
-    for b in batches:          # setup, not warm-up: every resident batch is scored once, and its first read-back
-        b.launch()             # maps its pinned buffer (not a per-step cost); any --warmup / --steps then works
-        b.lengths()
+    for b in batches:          # setup, not warm-up: every resident batch is scored once, so that any --warmup /
+        b.launch()             # --steps (even 0 / 1) reads back lengths that exist
     for i in range(args.warmup):
         batches[i % len(batches)].launch()
+    for b in batches:          # the first read-back after a run of launches costs the runtime several milliseconds
+        b.lengths()            # once (pinned-buffer mapping, signal pool): not a per-step cost, so it happens here
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
