@@ -30,6 +30,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+L2_PATH_PROBE_GBS = 31000.0  # tools/l2_probe.hip on MI355X: the walk's access pattern, loads only
 MOVES = {"nni": 0, "spr": 1, "tbr": 2}
 
 
@@ -290,6 +291,10 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "algorithmic bytes = (D+3) clean rows x nwords x 8 per candidate; rows are re-read from "
                     "the XCD L2 / Infinity Cache, so achieved may exceed the HBM figure",
+            # the ceiling that does bound this kernel: what a pure-load probe with the same access pattern reads
+            # through the L2 -> CU path on this chip (tools/l2_probe.hip)
+            "cache_path": {"ceiling": L2_PATH_PROBE_GBS, "unit": "GB/s", "frac": achieved / L2_PATH_PROBE_GBS,
+                           "source": "tools/l2_probe.hip measured on MI355X (not re-measured in this run)"},
         },
     }
     if args.e2e_steps > 0:
