@@ -179,14 +179,38 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     HIPCHK(ctx, bt->d_prog.reserve(total));
     HIPCHK(ctx, ctx->h_pin.reserve(total));
     char *h = (char *)ctx->h_pin.p;
+    // big launches: longest programs first.  The chip runs ~12 rounds of waves per launch at B = 4096 and a wave's
+    // time follows its token count (3 .. 60+), so whatever runs last decides the tail: let that be the short ones.
+    // Candidate b's descriptor (and so its length slot) moves to position slot_of[b]; lvbgpu_batch_lengths undoes it.
+    bt->slot_of.clear();
+    if (B >= LPT_MIN_B && ctx->lpt_order)
+    {
+        uint32_t max_tok = 0;
+        for (int t = 0; t < T; t++)
+            for (const CandDesc &c : ctx->workers[t].cands)
+                max_tok = std::max(max_tok, c.ntok);
+        std::vector<uint32_t> start((size_t)max_tok + 2, 0); // counting sort, descending token count, stable
+        for (int t = 0; t < T; t++)
+            for (const CandDesc &c : ctx->workers[t].cands)
+                start[max_tok - c.ntok + 1]++;
+        for (size_t i = 1; i < start.size(); i++)
+            start[i] += start[i - 1];
+        bt->slot_of.resize((size_t)B);
+        size_t b = 0;
+        for (int t = 0; t < T; t++)
+            for (const CandDesc &c : ctx->workers[t].cands)
+                bt->slot_of[b++] = (int32_t)start[max_tok - c.ntok]++;
+    }
     auto gather = [&](int t) {
         BuildWorker &w = ctx->workers[t];
-        CandDesc *cd = (CandDesc *)h + cand_base[t];
+        CandDesc *cd = (CandDesc *)h;
         for (size_t i = 0; i < w.cands.size(); i++)
         {
-            cd[i] = w.cands[i];
-            cd[i].tok_off += (uint32_t)tok_base[t];
-            cd[i].dst_off += (uint32_t)dst_base[t];
+            const size_t b = cand_base[t] + i;
+            CandDesc &out = cd[bt->slot_of.empty() ? b : (size_t)bt->slot_of[b]];
+            out = w.cands[i];
+            out.tok_off += (uint32_t)tok_base[t];
+            out.dst_off += (uint32_t)dst_base[t];
         }
         memcpy(h + o_t + tok_base[t] * 4, w.prog.toks.data(), w.prog.toks.size() * 4);
         memcpy(h + o_d + dst_base[t] * 4, w.prog.dsts.data(), w.prog.dsts.size() * 4);
@@ -320,7 +344,11 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
         HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->d_len.cap, ctx->stream));
         b->len_zeroed = true;
     }
-    memcpy(lengths_out, b->h_len.p, (size_t)b->B * 8);
+    if (b->slot_of.empty())
+        memcpy(lengths_out, b->h_len.p, (size_t)b->B * 8);
+    else // candidates were laid out longest program first
+        for (int32_t i = 0; i < b->B; i++)
+            lengths_out[i] = ((const int64_t *)b->h_len.p)[b->slot_of[(size_t)i]];
     for (int32_t i = 0; i < b->B; i++)
         if (lengths_out[i] <= 0)
             return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");

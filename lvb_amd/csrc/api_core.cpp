@@ -96,6 +96,8 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     memset(ctx->h_step.p, 0, 64);
     if (const char *ds = getenv("LVBGPU_DIRECT_STEPS"))
         ctx->direct_steps = ds[0] != '0';
+    if (const char *lp = getenv("LVBGPU_LPT"))
+        ctx->lpt_order = lp[0] != '0';
     HIPCHK(ctx, upload_iupac_table());
     HIPCHK(ctx, raise_lds_limit());
     ctx->pb.resize(ctx->nb);

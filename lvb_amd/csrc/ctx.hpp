@@ -175,6 +175,7 @@ struct lvbgpu_ctx
     PinBuf h_step;
     uint32_t step_seq = 0;
     bool direct_steps = true; // env LVBGPU_DIRECT_STEPS=0 turns them off (A/B measurements)
+    bool lpt_order = true;    // env LVBGPU_LPT=0: keep big batches in the caller's order on the device
     DevBuf d_tmp_changes;     // fused commits: per-combine accumulators, zero between launches
     bool tmp_changes_zeroed = false;
     DevBuf d_cin, d_cout; // strict-compat arenas
@@ -220,6 +221,7 @@ struct lvbgpu_batch
     bool len_zeroed = false; // d_len was cleared after the previous read-back
     bool direct = false;     // this step's lengths come back through the walk's last wave (no copy, no stream wait)
     bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
+    std::vector<int32_t> slot_of; // big batches: candidate b sits at position slot_of[b] (longest program first)
 };
 
 // steps up to this many candidates finish within a few hundred microseconds: poll for them instead of
@@ -231,6 +233,7 @@ constexpr uint32_t DIRECT_STEP_MAX_ITEMS = 512;
 // ... and programs are read in place (pinned host memory) while all the waves together fetch at most this much
 // over the host link (measured: faster than the copy up to ~64 KiB, slower beyond)
 constexpr size_t DIRECT_READ_MAX_BYTES = 64u << 10;
+constexpr int32_t LPT_MIN_B = 2048; // from here on a launch is many rounds of waves and its tail shows
 
 #define HIPCHK(ctx, call)                                                                                              \
     do                                                                                                                 \

@@ -107,6 +107,29 @@ def test_incremental_batches_and_commits_match_reference(api, ob, n, m, seed):
         rr.close()
 
 
+def test_big_batch_keeps_the_callers_order(api, ob):
+    """From 2048 candidates on the library lays a batch out longest program first (the launch's tail) and
+    un-permutes the lengths on the way back: 3000 mixed NNI/SPR/TBR neighbours, each against the reference."""
+    _ref_or_skip(ob)
+    n, m, seed, B = 33, 2049, 41, 3000
+    rr = ob.RefRun(rows=synth.treelike_rows(n, m, seed), seed=seed)
+    try:
+        ctx = api.FitchContext(rr.enc())
+        assert rr.getplen(0) == ctx.set_tree(_i32(rr.tree(0)[1]), _i32(rr.tree(0)[2]), rr.root(0))
+        _, cl, cr, _, _ = rr.tree(0)
+        cands, expect = [], []
+        for b in range(B):
+            rr.mutate(b % 3)
+            _, nl, nr, _, _ = rr.tree(1)
+            cands.append(api.edits_between(cl, cr, nl, nr))
+            expect.append(rr.getplen(1))
+        assert len(set(expect)) > 20                      # a permutation mistake cannot hide behind equal lengths
+        assert np.array_equal(ctx.score_batch(cands), np.array(expect))
+        ctx.close()
+    finally:
+        rr.close()
+
+
 @pytest.mark.parametrize("n,m,seed", [(12, 300, 11), (64, 10000, 12)])
 def test_full_batch_matches_reference(api, ob, n, m, seed):
     _ref_or_skip(ob)
