@@ -179,27 +179,44 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     HIPCHK(ctx, bt->d_prog.reserve(total));
     HIPCHK(ctx, ctx->h_pin.reserve(total));
     char *h = (char *)ctx->h_pin.p;
-    // big launches: longest programs first.  The chip runs ~12 rounds of waves per launch at B = 4096 and a wave's
-    // time follows its token count (3 .. 60+), so whatever runs last decides the tail: let that be the short ones.
-    // Candidate b's descriptor (and so its length slot) moves to position slot_of[b]; lvbgpu_batch_lengths undoes it.
+    // big launches: within each run of `chunk` candidates, longest programs first.  The chip runs ~12 rounds of
+    // waves per launch at B = 4096 and a wave's time follows its token count (3 .. 60+), so whatever runs last
+    // decides the tail: let that be short ones.  Chunks (an eighth of the batch), not one global order: every XCD
+    // takes a contiguous slice of the candidate list and must get the same mix of long and short (a global order
+    // cost 7 % at B = 16 384).  Candidate b's descriptor (and so its length slot) moves to position slot_of[b];
+    // lvbgpu_batch_lengths undoes it.
     bt->slot_of.clear();
     if (B >= LPT_MIN_B && ctx->lpt_order)
     {
-        uint32_t max_tok = 0;
-        for (int t = 0; t < T; t++)
-            for (const CandDesc &c : ctx->workers[t].cands)
-                max_tok = std::max(max_tok, c.ntok);
-        std::vector<uint32_t> start((size_t)max_tok + 2, 0); // counting sort, descending token count, stable
-        for (int t = 0; t < T; t++)
-            for (const CandDesc &c : ctx->workers[t].cands)
-                start[max_tok - c.ntok + 1]++;
-        for (size_t i = 1; i < start.size(); i++)
-            start[i] += start[i - 1];
+        std::vector<uint32_t> ntok_of((size_t)B);
+        {
+            size_t b = 0;
+            for (int t = 0; t < T; t++)
+                for (const CandDesc &c : ctx->workers[t].cands)
+                    ntok_of[b++] = c.ntok;
+        }
+        static const int32_t nchunks = [] {
+            const char *e = getenv("LVBGPU_LPT_CHUNKS");
+            const int v = e ? atoi(e) : 8;
+            return v < 1 ? 1 : v;
+        }();
+        const int32_t chunk = std::max(64, B / nchunks);
         bt->slot_of.resize((size_t)B);
-        size_t b = 0;
-        for (int t = 0; t < T; t++)
-            for (const CandDesc &c : ctx->workers[t].cands)
-                bt->slot_of[b++] = (int32_t)start[max_tok - c.ntok]++;
+        std::vector<uint32_t> start;
+        for (int32_t c0 = 0; c0 < B; c0 += chunk)
+        {
+            const int32_t c1 = std::min(B, c0 + chunk);
+            uint32_t max_tok = 0;
+            for (int32_t b = c0; b < c1; b++)
+                max_tok = std::max(max_tok, ntok_of[(size_t)b]);
+            start.assign((size_t)max_tok + 2, 0); // counting sort, descending token count, stable
+            for (int32_t b = c0; b < c1; b++)
+                start[max_tok - ntok_of[(size_t)b] + 1]++;
+            for (size_t i = 1; i < start.size(); i++)
+                start[i] += start[i - 1];
+            for (int32_t b = c0; b < c1; b++)
+                bt->slot_of[(size_t)b] = c0 + (int32_t)start[max_tok - ntok_of[(size_t)b]]++;
+        }
     }
     auto gather = [&](int t) {
         BuildWorker &w = ctx->workers[t];
