@@ -9,7 +9,10 @@
 namespace lvbgpu
 {
 
-constexpr uint32_t WALK_WAVES = 4;                // waves per workgroup
+#ifndef LVB_WALK_WAVES
+#define LVB_WALK_WAVES 4
+#endif
+constexpr uint32_t WALK_WAVES = LVB_WALK_WAVES;   // waves per workgroup
 constexpr uint32_t WALK_THREADS = 64 * WALK_WAVES;
 constexpr uint32_t TILE_WORDS = 128;              // 64 lanes x 16 B = 128 reference words (2048 sites) per wave tile
 constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
