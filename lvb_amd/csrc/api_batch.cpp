@@ -19,7 +19,7 @@ extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
 
 namespace lvbgpu_detail
 {
-constexpr int32_t PARALLEL_BUILD_MIN = 512; // below this one thread is faster than waking the pool
+constexpr int32_t PARALLEL_BUILD_MIN = 256; // below this one thread is as fast (a pool run costs a few microseconds)
 
 // what a batch is made from: edits against the resident tree, or whole topologies
 struct BuildJob
