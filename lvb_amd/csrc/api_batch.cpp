@@ -13,6 +13,7 @@ extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
     b->d_prog.release();
     b->d_len.release();
     b->h_len.release();
+    b->h_stage.release();
     delete b;
 }
 
@@ -177,8 +178,11 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     const size_t o_d = o_t + align16(ntok * 4);
     const size_t total = o_d + align16(ndst * 4);
     HIPCHK(ctx, bt->d_prog.reserve(total));
-    HIPCHK(ctx, ctx->h_pin.reserve(total));
-    char *h = (char *)ctx->h_pin.p;
+    // staging: a recycled step batch owns its pinned buffer (several may be in flight, lvbgpu_score_batch);
+    // a batch the caller holds goes through the context's and waits for the copy below
+    PinBuf &stage = bt->recycled ? bt->h_stage : ctx->h_pin;
+    HIPCHK(ctx, stage.reserve(total));
+    char *h = (char *)stage.p;
     // big launches: within each run of `chunk` candidates, longest programs first.  The chip runs ~12 rounds of
     // waves per launch at B = 4096 and a wave's time follows its token count (3 .. 60+), so whatever runs last
     // decides the tail: let that be short ones.  Chunks (an eighth of the batch), not one global order: every XCD
@@ -301,7 +305,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
     if (!b->len_zeroed) // the whole buffer: a direct step's last wave re-zeroes only the B slots it used
         HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->recycled ? b->d_len.cap : (size_t)b->B * 8, ctx->stream));
     b->len_zeroed = false;
-    WalkArgs a = resident_args(ctx, b->in_place ? ctx->h_pin.p : b->d_prog.p, b->off_toks, b->off_dsts, b->d_len.p,
+    WalkArgs a = resident_args(ctx, b->in_place ? b->h_stage.p : b->d_prog.p, b->off_toks, b->off_dsts, b->d_len.p,
                                (uint32_t)b->B, (int32_t)b->stats.max_stack);
     if (b->direct)
     {
@@ -388,24 +392,37 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // one recycled batch per context: a search calls this every step, so no allocation here
-    if (!ctx->step_batch)
+    // recycled batches owned by the context: a search calls this every step, so no allocation here.  A big batch
+    // is cut into STEP_PIPELINE pieces: while the device walks one piece the host threads build the next, so the
+    // device time of all but the last piece hides behind program building (the larger part of such a step).
+    // pieces of at least STEP_PIPELINE_PIECE candidates: smaller ones do not keep all host threads busy
+    const int K = ctx->pipeline_steps ? std::max(1, std::min(lvbgpu_ctx::STEP_PIPELINE, B / STEP_PIPELINE_PIECE)) : 1;
+    int rc = LVBGPU_OK;
+    for (int k = 0; k < K && rc == LVBGPU_OK; k++)
     {
-        ctx->step_batch = new (std::nothrow) lvbgpu_batch();
-        if (!ctx->step_batch)
-            return LVBGPU_E_NOMEM;
-        ctx->step_batch->recycled = true;
+        lvbgpu_batch *&b = ctx->step_batch[k];
+        if (!b)
+        {
+            b = new (std::nothrow) lvbgpu_batch();
+            if (!b)
+                return LVBGPU_E_NOMEM;
+            b->recycled = true;
+        }
+        const int32_t c0 = (int32_t)((int64_t)B * k / K), c1 = (int32_t)((int64_t)B * (k + 1) / K);
+        BuildJob job;
+        job.edit_offsets = edit_offsets + c0; // offsets stay absolute into `edits`
+        job.edits = edits;
+        job.roots = roots ? roots + c0 : nullptr;
+        rc = build_into(ctx, b, c1 - c0, job);
+        if (rc == LVBGPU_OK)
+            rc = lvbgpu_batch_launch(ctx, b);
+        else if (rc == LVBGPU_E_TOPOLOGY || rc == LVBGPU_E_ARG)
+            ctx->last_error += " (piece starting at candidate " + std::to_string(c0) + ")";
     }
-    lvbgpu_batch *b = ctx->step_batch;
-    BuildJob job;
-    job.edit_offsets = edit_offsets;
-    job.edits = edits;
-    job.roots = roots;
-    int rc = build_into(ctx, b, B, job);
-    if (rc == LVBGPU_OK)
-        rc = lvbgpu_batch_launch(ctx, b);
-    if (rc == LVBGPU_OK)
-        rc = lvbgpu_batch_lengths(ctx, b, lengths_out);
+    for (int k = 0; k < K && rc == LVBGPU_OK; k++)
+        rc = lvbgpu_batch_lengths(ctx, ctx->step_batch[k], lengths_out + (int64_t)B * k / K);
+    if (rc != LVBGPU_OK) // leave nothing in flight that reads the staging buffers
+        (void)hipStreamSynchronize(ctx->stream);
     return rc;
 }
 

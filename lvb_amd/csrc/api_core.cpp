@@ -98,6 +98,9 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
         ctx->direct_steps = ds[0] != '0';
     if (const char *lp = getenv("LVBGPU_LPT"))
         ctx->lpt_order = lp[0] != '0';
+    if (const char *pl = getenv("LVBGPU_PIPELINE"))
+        ctx->pipeline_steps = pl[0] != '0';
+    static_assert(lvbgpu_ctx::STEP_PIPELINE == 4, "lvbgpu_destroy lists the step batches");
     HIPCHK(ctx, upload_iupac_table());
     HIPCHK(ctx, raise_lds_limit());
     ctx->pb.resize(ctx->nb);
@@ -260,7 +263,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->h_moves.release();
     ctx->h_step.release();
     ctx->d_tmp_changes.release();
-    for (lvbgpu_batch *rb : {ctx->step_batch, ctx->full_batch, ctx->prop_batch})
+    for (lvbgpu_batch *rb : {ctx->step_batch[0], ctx->step_batch[1], ctx->step_batch[2], ctx->step_batch[3], ctx->full_batch,
+                             ctx->prop_batch})
         if (rb)
         {
             rb->ctx = nullptr;

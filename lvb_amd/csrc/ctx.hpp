@@ -158,7 +158,9 @@ struct lvbgpu_ctx
     int commit_slot = 0;
     bool cur_length_stale = false; // the device holds a newer length than cur_length
     DevBuf d_export;      // one row in nibble layout (lvbgpu_get_sets)
-    lvbgpu_batch *step_batch = nullptr; // recycled by lvbgpu_score_batch
+    static constexpr int STEP_PIPELINE = 4;
+    lvbgpu_batch *step_batch[STEP_PIPELINE] = {nullptr, nullptr, nullptr, nullptr}; // recycled by lvbgpu_score_batch
+    bool pipeline_steps = true; // env LVBGPU_PIPELINE=0: one build, one launch per lvbgpu_score_batch
     lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
     // device-side proposals (lvbgpu_propose_score)
     lvbgpu_batch *prop_batch = nullptr;
@@ -211,6 +213,7 @@ struct lvbgpu_batch
     DevBuf d_prog; // [cands][toks][dsts]
     DevBuf d_len;
     PinBuf h_len;  // lengths land here after every launch (async copy on the context's stream)
+    PinBuf h_stage; // recycled batches: the programs as the host built them (copied from here, or read in place)
     size_t off_toks = 0, off_dsts = 0;
     lvbgpu_batch_stats stats{};
     bool full_mode = false; // whole topologies: reads leaf rows only
@@ -233,6 +236,7 @@ constexpr uint32_t DIRECT_STEP_MAX_ITEMS = 512;
 // ... and programs are read in place (pinned host memory) while all the waves together fetch at most this much
 // over the host link (measured: faster than the copy up to ~64 KiB, slower beyond)
 constexpr size_t DIRECT_READ_MAX_BYTES = 64u << 10;
+constexpr int32_t STEP_PIPELINE_PIECE = 2048; // lvbgpu_score_batch cuts a batch into up to 4 pieces of at least this size
 constexpr int32_t LPT_MIN_B = 2048; // from here on a launch is many rounds of waves and its tail shows
 
 #define HIPCHK(ctx, call)                                                                                              \

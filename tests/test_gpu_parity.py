@@ -108,8 +108,9 @@ def test_incremental_batches_and_commits_match_reference(api, ob, n, m, seed):
 
 
 def test_big_batch_keeps_the_callers_order(api, ob):
-    """From 2048 candidates on the library lays a batch out longest program first (the launch's tail) and
-    un-permutes the lengths on the way back: 3000 mixed NNI/SPR/TBR neighbours, each against the reference."""
+    """From 2048 candidates on the library lays a resident batch out longest program first (the launch's tail)
+    and un-permutes the lengths on the way back, and lvbgpu_score_batch pipelines its pieces: 3000 mixed
+    NNI/SPR/TBR neighbours, each against the reference."""
     _ref_or_skip(ob)
     n, m, seed, B = 33, 2049, 41, 3000
     rr = ob.RefRun(rows=synth.treelike_rows(n, m, seed), seed=seed)
@@ -124,7 +125,15 @@ def test_big_batch_keeps_the_callers_order(api, ob):
             cands.append(api.edits_between(cl, cr, nl, nr))
             expect.append(rr.getplen(1))
         assert len(set(expect)) > 20                      # a permutation mistake cannot hide behind equal lengths
+        # a resident batch is reordered as a whole ...
+        resident = ctx.build_batch(cands)
+        resident.launch()
+        assert np.array_equal(resident.lengths(), np.array(expect))
+        resident.free()
+        # ... and lvbgpu_score_batch cuts a batch of this size into pieces that are built while the previous one
+        # is walked: the pieces' lengths must land where the caller's candidates are
         assert np.array_equal(ctx.score_batch(cands), np.array(expect))
+        assert np.array_equal(ctx.score_batch(cands[:2049]), np.array(expect[:2049]))
         ctx.close()
     finally:
         rr.close()
