@@ -23,14 +23,19 @@
 //   * the running node set lives in 4 VGPRs; sibling sets that must wait for the other subtree sit
 //     on an operand stack in LDS (ds_write_b128 / ds_read_b128, 1 KiB per level per wave: two
 //     levels for NNI/SPR/TBR deltas, up to log2(n)+1 for whole-tree programs);
-//   * union counts are reduced across the wave with ballot + scalar popcount bit-slices (SALU,
-//     result in an SGPR) and added with one integer atomic per (candidate, tile): integer addition
-//     commutes, so lengths are bit-exact whatever the arrival order;
+//   * union counts are reduced across the wave (a butterfly over the LDS crossbar for a program's total,
+//     ballot + scalar popcount bit-slices for a commit's per-node counts) and added with one integer atomic
+//     per wave: integer addition commutes, so lengths are bit-exact whatever the arrival order;
+//   * the commit form parks produced sets and counts in LDS and writes them out in bursts, so that the load
+//     ring's counted waits survive (a write in flight would turn each of them into vmcnt(0));
+//   * small launches hand their results to the host themselves: the last wave to finish (a counter every wave
+//     ticks) copies lengths into pinned memory and releases a flag (direct steps), or settles changes[] and
+//     S_all after a commit (fused commits);
 //   * blockIdx -> work mapping is XCD-aware: items are ordered tile-major and each of the 8 XCDs
 //     takes a contiguous eighth, so the waves resident on one XCD read the same column slice of
 //     the resident tree and hit that XCD's private 4 MiB L2 (measured hit rate 97 %).
 //
-// No MFMA: bitwise integer streaming, bound by L2/HBM bandwidth and VALU issue.
+// No MFMA: bitwise integer streaming, bound by the L2 -> CU path.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>
@@ -130,8 +135,8 @@ struct OffVec
 
 // WIDE: row offsets kept as 64-bit byte counts in two vectors (tree blocks of 64 GiB and more).  The
 // narrow form - offsets in 16-byte units, 32 bits, the shift folded into the address add - saves three
-// instructions per token, and instructions per token are what bound this kernel (a CU retires about one
-// per cycle over all its waves: profiles/experiments/r01_lds_hot_rows.md).
+// instructions per token: 2.3 % of the launch (the loop sits within 7 % of what the L2 -> CU path delivers,
+// instruction count is the second-order term: DESIGN.md section 3).
 template <bool COMMIT, bool WIDE>
 __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 {
@@ -239,10 +244,10 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
             flush();
     };
 
-    // One token = one combine, acc = fitch(acc, row), and ONE scalar test.  The scalar unit is shared by
-    // the CU's four SIMDs and is what bounds this loop (tools/l2_probe3.hip: beyond ~4 scalar
-    // instructions per 1 KiB load the read rate falls, VALU work up to 16 per load is free), so
-    // everything rare is folded behind a single precomputed bit per token:
+    // One token = one combine, acc = fitch(acc, row), and ONE scalar test: 15 instructions, of which the load
+    // is what the loop waits for.  Scalar instructions are the ones that cost when added (tools/l2_probe3.hip:
+    // beyond ~4 per 1 KiB load the read rate falls, VALU work up to 16 per load is free), so everything rare is
+    // folded behind a single precomputed bit per token:
     //   * a chain start (FRESH) needs acc = row.  Instead of testing for it, the token BEFORE it
     //     leaves acc = all-ones (after pushing the old acc if the chain start says PUSH): then the
     //     ordinary combine gives fitch(all, row) = row and counts 32 non-empty sites, which cd.nfresh
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
             const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
             // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
             const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
-            // byte offset of that row, 64 bits in two vectors (the vector unit is not what bounds this loop)
+            // that row's offset: bytes in two vectors (WIDE) or 16-byte units in one
             const uint64_t myoff64 = WIDE ? (uint64_t)(mytok & TOK_ROW_MASK) * ((uint64_t)a.in_stride4 << 4)
                                           : (uint64_t)((mytok & TOK_ROW_MASK) * a.in_stride4); // bytes | 16-byte units
             OffVec o0{(uint32_t)myoff64, (uint32_t)(myoff64 >> 32)};
