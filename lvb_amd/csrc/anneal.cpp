@@ -25,6 +25,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "host_tree.hpp"
@@ -56,7 +57,15 @@ struct Chain
 
     std::vector<MoveParams> moves; // host-drawn proposals as parameters
     bool moves_on_device = false;  // ... scored from the parameters (the device built rewrites and programs)
-    static constexpr int DEVICE_MOVES_MIN = 96; // below this the host's own program builder is quicker
+    // below this the host's own program builder (its threads) is quicker than the generator kernel's fixed cost
+    static int device_moves_min()
+    {
+        static const int v = [] {
+            const char *e = getenv("LVBHOST_DEVICE_MOVES_MIN");
+            return e ? atoi(e) : 96;
+        }();
+        return v;
+    }
 
     // score B fresh proposals of the given kinds; returns lvbgpu status
     int score(int B)
@@ -66,7 +75,7 @@ struct Chain
         for (int b = 0; b < B; b++)
             moves.push_back(draw_move(tree->topo, kinds[b], tree->rng));
         lens.resize(B);
-        moves_on_device = B >= DEVICE_MOVES_MIN;
+        moves_on_device = B >= device_moves_min();
         int rc;
         if (moves_on_device)
         {

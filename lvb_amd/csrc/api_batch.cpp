@@ -127,7 +127,12 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     static_assert(sizeof(lvbgpu_edit) == sizeof(Edit), "edit layout");
     int T = 1;
     // whole-tree programs are ~n tokens each: worth the pool from a handful of trees on
-    const int32_t par_min = job.full ? 16 : PARALLEL_BUILD_MIN;
+    static const int32_t par_min_edits = [] {
+        const char *e = getenv("LVBGPU_PAR_MIN"); // candidates from which a build uses the pool (two per thread at least)
+        const int v = e ? atoi(e) : PARALLEL_BUILD_MIN;
+        return (int32_t)(v < 2 ? 2 : v);
+    }();
+    const int32_t par_min = job.full ? 16 : par_min_edits;
     if (B >= par_min)
     {
         if (!ctx->pool)
@@ -255,9 +260,11 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     bt->B = B;
     bt->off_toks = o_t;
     bt->off_dsts = o_d;
-    const void *old_len = bt->d_len.p;
+    // a buffer that grew holds whatever its new memory held - and may well sit at the old address, so it is
+    // the capacity that tells, not the pointer
+    const size_t old_len_cap = bt->d_len.cap;
     HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
-    if (bt->d_len.p != old_len)
+    if (bt->d_len.cap != old_len_cap)
         bt->len_zeroed = false;
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     bt->full_mode = job.full;
@@ -372,7 +379,8 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
             lengths_out[i] = ((const int64_t *)b->h_len.p)[b->slot_of[(size_t)i]];
     for (int32_t i = 0; i < b->B; i++)
         if (lengths_out[i] <= 0)
-            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (candidate " + std::to_string(i) + " of " +
+                                                   std::to_string(b->B) + " scored " + std::to_string(lengths_out[i]) + ")");
     return LVBGPU_OK;
 }
 

@@ -472,7 +472,7 @@ extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32
     if (length_out)
         *length_out = ctx->cur_length;
     if (ctx->cur_length <= 0)
-        return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+        return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (full evaluation gave " + std::to_string(ctx->cur_length) + ")");
     return LVBGPU_OK;
 }
 
@@ -564,7 +564,7 @@ extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit
     {
         *length_out = ctx->cur_length;
         if (ctx->cur_length <= 0)
-            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (length after the commit: " + std::to_string(ctx->cur_length) + ")");
     }
     return LVBGPU_OK;
 }

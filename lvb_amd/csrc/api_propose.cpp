@@ -115,9 +115,11 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
     const size_t total = o_d + align16((size_t)B * stride_t * 4);
     HIPCHK(ctx, bt->d_prog.reserve(total));
-    const void *old_len = bt->d_len.p;
+    // a buffer that grew holds whatever its new memory held - and may well sit at the old address, so it is
+    // the capacity that tells, not the pointer
+    const size_t old_len_cap = bt->d_len.cap;
     HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
-    if (bt->d_len.p != old_len)
+    if (bt->d_len.cap != old_len_cap)
         bt->len_zeroed = false;
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     HIPCHK(ctx, ctx->d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
@@ -209,7 +211,8 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
             }
             lengths_out[b] = len[b];
             if (len[b] <= 0)
-                return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0");
+                return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (device-built candidate " + std::to_string(b) +
+                                                       " of " + std::to_string(B) + " scored " + std::to_string(len[b]) + ")");
         }
         if (!(overflowed && paths_capped))
             break;

@@ -20,6 +20,7 @@
 #include "../../include/lvbhost.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -687,7 +688,11 @@ extern "C" int lvbhost_reference_search(lvbgpu_ctx *ctx, const lvbhost_refsearch
     d.ctx = ctx;
     d.max_batch = std::min<int32_t>(p->max_batch, (int32_t)REROOT_INTERVAL - 1);
     d.min_len = (double)p->min_len_tree;
-    d.device_moves_min = p->device_moves_min == 0 ? 128 : (int32_t)std::min<int64_t>(p->device_moves_min, 1 << 30);
+    static const int default_moves_min = [] {
+        const char *e = getenv("LVBHOST_DEVICE_MOVES_MIN");
+        return e ? atoi(e) : 128;
+    }();
+    d.device_moves_min = p->device_moves_min == 0 ? default_moves_min : (int32_t)std::min<int64_t>(p->device_moves_min, 1 << 30);
     d.pb.resize(2 * n - 3);
     if (!d.rng.seed(p->seed))
         return LVBGPU_E_ARG;

@@ -166,3 +166,27 @@ def test_moves_the_generators_could_not_make_are_refused():
             assert ei.value.status == -6, mv
     finally:
         ctx.close()
+
+
+def test_batches_that_grow_and_shrink_keep_their_length_slots_clean(mods):
+    """The recycled batches zero their length slots off the critical path and remember that they did.  A
+    buffer that grows must forget it - its new memory holds whatever was there before, and the allocator likes
+    to hand back the old address (a search at 500 taxa died with a candidate scored -4.6e18 that way).  Sizes
+    that cross every growth step of the buffers, each batch against the host-built programs of the same moves."""
+    api, host = mods
+    n, m = 40, 600
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 77))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=78)
+    tree.upload(ctx)
+    rng = host.RefRng(79)
+    for B in (8, 513, 64, 700, 1100, 100, 2600, 300, 5300, 11000, 640):
+        moves = np.array([tree.ref_draw_move(rng, b % 3) for b in range(B)], dtype=api.MOVE_DTYPE)
+        edits = [tree.move_edits(mv) for mv in moves]
+        want = ctx.score_batch(edits)
+        assert want.min() > 0
+        assert np.array_equal(ctx.score_moves(moves), want), B
+        assert np.array_equal(ctx.score_batch(edits), want), B
+        lens = ctx.propose_score(B, -1, 5 * B)
+        assert lens.min() > 0 and np.array_equal(lens, ctx.propose_score(B, -1, 5 * B)), B
+    ctx.close()
