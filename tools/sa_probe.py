@@ -1,35 +1,31 @@
-"""Batched annealing and the reference's trajectory at a given shape under the current thresholds (GPU box).
-    python tools/sa_probe.py [taxa sites]"""
-import os
-import sys
-import time
+#!/usr/bin/env python3
+"""Time the batched SA host end to end on a synthetic alignment (GPU box)."""
+import argparse, json, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from lvb_amd import api, host
+from tests import synth
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lvb_amd import api, host  # noqa: E402
-from tests import synth  # noqa: E402
-
-n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (500, 50000)
-rows, minlen = host.prepare_alignment(synth.treelike_rows(n, m, 3))
+ap = argparse.ArgumentParser()
+ap.add_argument("--taxa", type=int, default=500); ap.add_argument("--sites", type=int, default=50000)
+ap.add_argument("--batch", type=int, default=256); ap.add_argument("--seconds", type=float, default=5.0)
+ap.add_argument("--alg", type=int, default=0); ap.add_argument("--t0", type=float, default=0.0)
+ap.add_argument("--device-proposals", type=int, default=0)
+a = ap.parse_args()
+rows, minlen = host.prepare_alignment(synth.treelike_rows(a.taxa, a.sites, 3))
 ctx = api.FitchContext(text_rows=rows)
-for seed in (5, 6):
-    tree = host.HostTree(n, seed=seed)
-    tree.upload(ctx)
-    p = host.anneal_defaults()
-    p.seed = seed
-    p.min_len_tree = minlen
-    t0 = time.perf_counter()
-    res, _ = host.anneal(ctx, tree, p)
-    print(f"anneal seed {seed}: {time.perf_counter() - t0:.3f} s wall, best {res['best_length']}, "
-          f"{res['device_steps']} steps, {res['scored']} scored", flush=True)
-    tree.close()
-for seed in (77,):
-    p = host.refsearch_defaults()
-    p.seed = seed
-    p.algorithm = 1
-    p.min_len_tree = minlen
-    t0 = time.perf_counter()
-    res, tree = host.reference_search(ctx.h, p)
-    print(f"exact seed {seed}: {time.perf_counter() - t0:.3f} s wall, {res['rearrangements']} rearrangements, "
-          f"score {res['best_length']}, {res['device_steps']} steps ({res['device_move_steps']} from moves)", flush=True)
-    tree.close()
-ctx.close()
+tree = host.HostTree(a.taxa, seed=11)
+print("start length", tree.upload(ctx))
+p = host.anneal_defaults(); p.min_len_tree = minlen; p.batch = a.batch; p.algorithm = a.alg
+p.device_proposals = a.device_proposals
+t = time.perf_counter()
+if a.t0 <= 0:
+    t0 = host.starting_temperature(ctx, tree, p)
+    print("t0", t0, "in", round(time.perf_counter() - t, 2), "s; length now", ctx.current_length())
+else:
+    t0 = a.t0
+p.t0 = t0; p.max_seconds = a.seconds; p.log_cap = 1000
+res, log = host.anneal(ctx, tree, p)
+print(json.dumps(res))
+print(log[:: max(1, len(log) // 15)])
