@@ -119,7 +119,11 @@ int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out /* [nwords] */)
  * Candidate b is the current tree with edits[edit_offsets[b] .. edit_offsets[b+1]) applied and
  * rooted at roots[b] (roots == NULL or roots[b] < 0: same root).  Length semantics are
  * getplen's incremental case: only dirty nodes are recomputed, clean nodes contribute their
- * cached `changes` (TreeEvaluation.c:191-202); nothing resident is modified.            */
+ * cached `changes` (TreeEvaluation.c:191-202); nothing resident is modified.  lengths_out[b]
+ * belongs to candidate b whatever the library does inside: small steps come back without the
+ * copy engine, big batches are walked longest program first and in pieces that overlap program
+ * building with the device (DESIGN.md sections 3 and 7a).  Programs are built by up to
+ * LVBGPU_THREADS host threads, which spin for 0.3 ms after a call before they sleep.   */
 int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets,
                        const lvbgpu_edit *edits, const int32_t *roots, int64_t *lengths_out);
 
