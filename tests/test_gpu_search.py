@@ -65,3 +65,31 @@ def test_two_restarts_share_one_gpu_and_the_best_one_writes_the_trees(tmp_path):
     assert "Restarts (one per GPU):   2" in printed[0] and "Tree score:               1628" in printed[0]
     lines = out.read_text().splitlines()
     assert len(lines) == 1 and lines[0].startswith("(") and lines[0].endswith(");")
+
+
+@pytest.mark.parametrize("alg,proposals", [(0, 0), (12, 0), (1, 2), (2, 1)])
+def test_batched_search_at_the_bench_shape_under_every_kind_of_move(alg, proposals):
+    """500 x 50 000 with NNI / TBR moves and batch sizes that grow to the re-root interval: the runs in which a stale
+    length slot once surfaced.  The search must finish, and the tree it ends on must score, by a
+    full evaluation on a second context, exactly what the search says."""
+    from lvb_amd import api, host
+    from tests import synth
+    n, m = 500, 50000
+    rows, minlen = host.prepare_alignment(synth.treelike_rows(n, m, 3))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=5)
+    start = tree.upload(ctx)
+    p = host.anneal_defaults()
+    p.seed = 5
+    p.min_len_tree = minlen
+    p.algorithm = alg
+    p.device_proposals = proposals
+    p.max_seconds = 4.0
+    res, _ = host.anneal(ctx, tree, p)
+    assert 0 < res["best_length"] < start
+    _, left, right = tree.arrays()
+    check = api.FitchContext(text_rows=rows)
+    assert check.set_tree(left, right, tree.root) == res["final_length"] == ctx.current_length()
+    check.close()
+    tree.close()
+    ctx.close()
