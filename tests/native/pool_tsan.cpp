@@ -4,7 +4,9 @@
 // Exit code 0 and "ok" on stdout when the parallel result equals the serial one.
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../lvb_amd/csrc/pool.hpp"
@@ -78,6 +80,29 @@ int main()
         // move on: accept one candidate so the next round sees another tree
         if (!serial.apply_edits(cur, edits.data() + offs[5], offs[6] - offs[5], -1, &why))
             return 3;
+    }
+    // the pool's own protocol: runs with fewer tasks than threads (workers that sit a generation out), runs back to
+    // back (workers still spinning) and runs after a pause longer than the spin window (workers asleep)
+    {
+        std::vector<long> hits(T, 0); // task t only ever touches hits[t]
+        long expect[8] = {0};
+        uint64_t x = 12345;
+        for (int run = 0; run < 3000; run++)
+        {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            const int active = 1 + (int)((x >> 33) % (uint64_t)T);
+            pool.run(active, [&](int t) { hits[t] += t + 1; });
+            for (int t = 0; t < active; t++)
+                expect[t] += t + 1;
+            if (run % 500 == 499)
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        for (int t = 0; t < T; t++)
+            if (hits[t] != expect[t])
+            {
+                printf("pool protocol: task %d ran %ld, expected %ld\n", t, hits[t], expect[t]);
+                return 4;
+            }
     }
     printf("ok\n");
     return 0;
