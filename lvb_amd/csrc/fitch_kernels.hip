@@ -715,6 +715,14 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         a.defer_slots = room < max_slots ? room : max_slots;
         lds += (size_t)WALK_WAVES * a.defer_slots * (64u * sizeof(uint4) + sizeof(uint32_t));
     }
+    // measurement knob: extra dynamic LDS per workgroup caps the waves a CU can hold (160 KiB per CU, 4 waves per
+    // workgroup): LVBGPU_LDS_PAD_KB=36 -> 16 waves per CU, 76 -> 8
+    static const size_t lds_pad = [] {
+        const char *e = getenv("LVBGPU_LDS_PAD_KB");
+        return e ? (size_t)atoi(e) * 1024u : (size_t)0;
+    }();
+    if (lds + lds_pad <= MAX_LDS_BYTES)
+        lds += lds_pad;
     const dim3 grid(nblk), block(WALK_THREADS);
     // offsets in 16-byte units must fit 32 bits; LVBGPU_WIDE_OFFSETS=1 forces the 64-bit form (tests)
     static const bool force_wide = [] {
