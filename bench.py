@@ -3,23 +3,40 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the configuration the headline metric is quoted on):
-synthetic 500-taxon x 50 000-site DNA alignment, SPR neighbourhood; one "step" = one launch of
-the scoring kernel over one resident batch of B candidate topologies (edits against the resident
-current tree).  Alignment, tree and candidate programs are already in HBM when the timed region
-starts.  For N > 1 every rank is an independent restart (own seed, own start tree, own
-candidates) on its own GPU; the only collective is an RCCL min-reduce of the best length.
+Workload (BASELINE.json configs[2], the configuration the headline metric is quoted on): synthetic
+500-taxon x 50 000-site DNA alignment, SPR neighbourhood, B = 4096 candidates per step.
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).  `cpu_baseline` times LVB's
-own CPU path (the reference compiled into oracle/_ref, or our C restatement if that did not
-travel) on the host cores, on a bounded sample of the same workload.
+One "step" is SURVEY.md 8(d)(i)'s unit: batch submit -> lengths on the host.  Per step the library draws B
+random neighbours of the resident tree, builds their programs and scores them on the GPU, and the B lengths
+are on the host before the next step starts (`lvbgpu_propose_score`).  Alignment and current tree are in HBM
+when the timed region starts; nothing else is.  `value` = candidates of all ranks / wall time of K steps.
+
+Beside it, in the same JSON line:
+  kernel_only   the scoring kernel alone, replaying resident pre-built batches (round 1's headline)
+  roofline      the dominant kernel (fitch_walk<false,false>) against the L2 -> CU path that bounds it: duration
+                from HIP events around every walk of the timed region, ceiling from the guide (34.5 TB/s) and
+                from a pure-load probe with the walk's access pattern run in this process; `hbm` = measured HBM
+                traffic (rocprofv3 PMC, profiles/traffic.json) over the same duration against 8 TB/s
+  mixed_walk    the same measurements on a tree mixed by >= 3000 accepted moves (longer dirty paths), with the
+                CPU reference timed on that very tree
+  cpu_baseline  LVB's own CPU path (the compiled reference, oracle/_ref) on the SAME tree and neighbourhood
+                as the headline leg, one core and all cores
+  shapes        B = 256 / 1024 and the i.i.d.-uniform alignment (SURVEY.md 8d "U")
+  anneal        best-length-vs-wallclock of the batched SA host
+
+For N > 1 every rank is an independent restart (own seed, own start tree, own candidates) on its own GPU; the
+only collective is the min-reduce of the best length (`lvbgpu_allreduce_min`, RCCL).  Started without
+WORLD_SIZE, `--gpus N` spawns the N ranks itself (this process never touches a GPU then).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -29,12 +46,13 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-L2_PATH_PROBE_GBS = 31000.0  # tools/l2_probe.hip on MI355X: the walk's access pattern, loads only
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 MOVES = {"nni": 0, "spr": 1, "tbr": 2}
+KERNEL = "lvbgpu::fitch_walk<false, false>"
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -43,23 +61,98 @@ def parse_args():
     ap.add_argument("--sites", type=int, default=50000)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--move", choices=list(MOVES), default="spr")
-    ap.add_argument("--nbatches", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--nbatches", type=int, default=4, help="kernel_only leg: distinct resident batches cycled through")
     ap.add_argument("--walk", type=int, default=75, help="accepted random moves applied to the start tree "
-                    "before measuring (BASELINE.md: 300 proposals, every 4th accepted)")
+                    "before the headline leg (BASELINE.md: 300 proposals, every 4th accepted)")
+    ap.add_argument("--mixed-walk", type=int, default=3000, help="accepted random moves behind the mixed_walk leg "
+                    "(0 = skip it)")
     ap.add_argument("--dist", choices=["tree", "uniform"], default="tree",
                     help="synthetic alignment: tree-like (generator T of SURVEY.md 8d) or i.i.d. uniform (U)")
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each cpu_baseline timing")
     ap.add_argument("--anneal-seconds", type=float, default=4.0,
-                    help="after the timed region, run the batched SA host end to end for this long and report "
-                         "best-length-vs-wallclock (0 = skip)")
+                    help="run the batched SA host end to end for this long and report best-length-vs-wallclock (0 = skip)")
     ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
-    ap.add_argument("--e2e-steps", type=int, default=40,
-                    help="after the timed region: steps of lvbgpu_propose_score (neighbours drawn, programmed and "
-                         "scored on the GPU, lengths back on the host) to report the end-to-end rate (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 and uniform-alignment legs")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed region and its roofline only (profiling runs: every scoring walk of the process is "
+                         "then one of the headline's device-built batches)")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="rehearse the N-rank flow without GPUs: ranks are spawned, meet over gloo, reduce a fake best "
+                         "length; no scoring (CPU test of the launch plumbing)")
+    return ap.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------------------- launching N ranks
+
+def spawn_ranks(args) -> int:
+    """--gpus N without WORLD_SIZE: start the N ranks as child processes.  This process makes no GPU call
+    (a process that has touched the GPU must not start others on this pool); it relays rank 0's line."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, failed = "", []
+    deadline = time.time() + 3000
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for r, p in enumerate(procs):
+            if p.wait(timeout=max(1.0, deadline - time.time())) != 0:
+                failed.append(r)
+    except subprocess.TimeoutExpired:
+        failed.append(-1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if failed:
+        print(f"bench.py: rank(s) {failed} failed", file=sys.stderr)
+        sys.stdout.write(out0)
+        return 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(lines[-1])
+    return 0
+
+
+def dry_rank_main(args) -> None:
+    """The rank flow of rank_main with the GPU taken out: rendezvous, barriers, max-over-ranks timing and a
+    min-reduce of a stand-in best length, all over gloo."""
+    from lvb_amd.launch import Ranks
+    ranks = Ranks(backend="gloo")
+    if ranks.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}")
+    ranks.barrier()
+    t0 = time.perf_counter()
+    best_local = 1000 + 7 * ((ranks.rank + 1) % ranks.world)    # the minimum sits on the last rank
+    best = -ranks.max_over_ranks(-float(best_local))
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    seeds = ranks.sum_over_ranks(ranks.restart_seed(args.seed))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "candidate trees scored/sec (Fitch getplen), 500 taxa x 50k sites", "value": 0.0,
+            "unit": "trees/s", "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic", "dry": True,
+            "config": {"workload": "dry run of the rank flow: no GPU, nothing scored",
+                       "parallelism": f"{ranks.world} ranks over gloo (on GPUs: one independent restart per GPU, "
+                                      "best length min-reduced by lvbgpu_allreduce_min over RCCL)",
+                       "best_length": int(best), "seed_sum": seeds}}), flush=True)
+    ranks.close()
+
+
+# ----------------------------------------------------------------------------------------- workload pieces
 
 def synth_rows(n: int, m: int, seed: int, dist: str = "tree") -> list[bytes]:
     """Generator T of SURVEY.md 8(d): taxon 0 uniform, taxon i copies taxon (i-1)//2 with 10 % substitutions;
@@ -68,80 +161,181 @@ def synth_rows(n: int, m: int, seed: int, dist: str = "tree") -> list[bytes]:
     return treelike_rows(n, m, seed) if dist == "tree" else uniform_rows(n, m, seed)
 
 
-def cpu_all_cores(taxa: int, sites_seed, kind: int, seconds: float):
-    """One independent reference chain per host core, at the same time (separate processes: the
-    reference is non-reentrant).  -> aggregate trees/s and the core count used."""
-    import subprocess
-    sites, seed = sites_seed
+def random_walk(ctx, tree, kind: int, moves: int) -> int:
+    """`moves` accepted random moves on the resident tree (host generator, committed on the device)."""
+    length = ctx.current_length()
+    for _ in range(moves):
+        e = tree.propose(kind)
+        length = ctx.commit(e)
+        tree.apply(e)
+    return length
+
+
+def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, seed0: int, reduce_best=None):
+    """The metric's step, `steps` times: draw + program + score B neighbours on the GPU, lengths on the host.
+    -> dict(elapsed_s [max over ranks], launch_ms [mean walk duration, HIP events], best, stats)."""
+    for i in range(warmup):
+        ctx.propose_score(B, kind, seed0 - 1 - i)
+    ctx.synchronize()
+    ranks.barrier()
+    ctx.walk_timing(True)
+    best = np.iinfo(np.int64).max
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lens = ctx.propose_score(B, kind, seed0 + i)
+        best = min(best, int(lens.min()))
+    t_steps = time.perf_counter() - t0
+    best_global = reduce_best(best) if reduce_best else best
+    ctx.synchronize()
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    walk_ms, walks = ctx.walk_timing_read()
+    ctx.walk_timing(False)
+    # what those batches cost: the draw is a function of (seed, b), so re-drawing a few of the timed seeds
+    # (outside the timed region) gives exactly their counts
+    picks = sorted({seed0 + int(round(k * (steps - 1) / 7)) for k in range(8)}) if steps > 0 else []
+    st = []
+    for s in picks:
+        ctx.propose_score(B, kind, s)
+        st.append(ctx.proposal_stats())
+    mean = lambda key: float(np.mean([x[key] for x in st])) if st else 0.0
+    return {
+        "elapsed_s": ranks.max_over_ranks(elapsed), "steps_s_local": t_steps,
+        "launch_ms": walk_ms / max(walks, 1), "walks": walks, "best": best_global, "best_local": best,
+        "alg_bytes": mean("algorithmic_bytes"), "mean_dirty": mean("dirty_nodes") / max(mean("candidates"), 1.0),
+        "scored_per_step": mean("candidates"),
+    }
+
+
+def kernel_only(ctx, tree, B: int, kind: int, nbatches: int, steps: int, warmup: int):
+    """Round 1's headline: `nbatches` pre-built resident batches replayed, nothing but the scoring kernel."""
+    from lvb_amd import api
+    batches = []
+    for _ in range(nbatches):
+        offs, edits = tree.propose_batch(kind, B)
+        bh = api.C.c_void_p()
+        ctx._chk(ctx.lib.lvbgpu_batch_build(ctx.h, B, offs, edits.ctypes.data, None, api.C.byref(bh)))
+        batches.append(api.Batch(ctx, bh, B))
+    stats = [b.stats() for b in batches]
+    for b in batches:
+        b.launch()
+    for i in range(warmup):
+        batches[i % nbatches].launch()
+    for b in batches:
+        b.lengths()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for i in range(steps):
+        batches[i % nbatches].launch()
+    kernel_ms = ctx.timer_stop()
+    wall = time.perf_counter() - t0
+    launched = [stats[i % nbatches] for i in range(steps)]
+    alg = float(np.mean([s["algorithmic_bytes"] for s in launched]))
+    d = float(np.mean([s["dirty_nodes"] / s["candidates"] for s in launched]))
+    for b in batches:
+        b.lengths()
+        b.free()
+    launch_ms = kernel_ms / steps
+    return {"value": B * steps / wall, "unit": "trees/s", "launch_ms": launch_ms, "mean_dirty_nodes": round(d, 2),
+            "achieved_gbs": alg / (launch_ms * 1e-3) / 1e9, "algorithmic_bytes_per_launch": alg,
+            "what": f"{nbatches} resident host-built batches (longest program first) replayed: kernel launches only, "
+                    "lengths read once after the loop"}
+
+
+def roofline_block(ctx, B: int, alg_bytes: float, launch_ms: float, mean_dirty: float, traffic, probe_reps: int = 20):
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    probe = ctx.probe_l2(B, max(8, int(round(mean_dirty + 3))), probe_reps)
+    out = {
+        "bound": "l2", "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
+        "traffic": traffic, "kernel": KERNEL, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
+        "probe": {"value": probe, "unit": "GB/s", "frac": achieved / probe if probe > 0 else None,
+                  "source": "lvbgpu_probe_l2 in this process: pure loads, the walk's geometry and access pattern"},
+        "note": "algorithmic bytes = (D+3) clean rows x nwords x 8 per candidate (SURVEY.md 8d), D measured on the "
+                "timed batches; the rows are served by the XCD L2s (97 % hit rate), so the bound is the L2 -> CU "
+                "path, not HBM; `hbm` below is what actually crosses the HBM interface",
+    }
+    if traffic:
+        gbs = traffic / (launch_ms * 1e-3) / 1e9
+        out["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                      "reuse": alg_bytes / traffic,
+                      "source": "rocprofv3 PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, profiles/traffic.json"}
+    return out
+
+
+def cpu_reference_on_tree(rows, kind: int, budget_s: float, tree_arrays, expect_length, taxa_sites_seed, all_cores=True):
+    """LVB's CPU path on the tree the GPU leg scored: the compiled reference's mutate_* (incl. its treecopy) +
+    incremental getplen over random neighbours of that tree (nothing accepted, so the tree and the
+    dirty-path lengths stay the GPU leg's)."""
+    from oracle import binding as ob
+    if ob.load_ref() is None:
+        return None
+    parent, left, right, root = tree_arrays
+    rr = ob.RefRun(rows=rows, seed=12345, nproc=1)
+    try:
+        rr.set_topology(parent, left, right, root)
+        full = rr.getplen(0)
+        tg, tm, _, _ = rr.time_proposals(kind, 20, 0)
+        per = max((tg + tm) / 20, 1e-6)
+        reps = int(max(50, min(20000, budget_s / per)))
+        tg, tm, _, ds = rr.time_proposals(kind, reps, 0)
+        tfull, _ = rr.time_full(3)
+        out = {
+            "value": reps / (tg + tm), "unit": "trees/s", "cores": 1, "kind": "reference",
+            "mean_dirty_nodes": round(ds / reps, 2), "getplen_only_trees_per_s": reps / tg,
+            "tree_length_matches_gpu": bool(full == expect_length),
+            "sample": f"{reps} {['NNI', 'SPR', 'TBR'][kind]} neighbours of the GPU leg's own tree (reference mutate incl. "
+                      f"treecopy {1e3 * tm / reps:.3f} ms + incremental getplen {1e3 * tg / reps:.3f} ms, serial branch); "
+                      f"full getplen {1e3 * tfull / 3:.2f} ms",
+        }
+    finally:
+        rr.close()
+    if all_cores:
+        out["all_cores"] = cpu_all_cores(kind, min(budget_s, 8.0), tree_arrays, taxa_sites_seed)
+    return out
+
+
+def cpu_all_cores(kind: int, seconds: float, tree_arrays, taxa_sites_seed):
+    """One reference process per host core at the same time (the reference is non-reentrant), each
+    scoring random neighbours of the same tree."""
+    taxa, sites, seed, dist = taxa_sites_seed
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 32))
-    cmd = [sys.executable, "-m", "oracle.cpu_bench", "--taxa", str(taxa), "--sites", str(sites), "--seed", str(seed),
-           "--kind", str(kind), "--seconds", str(seconds)]
-    procs = [subprocess.Popen(cmd + ["--chain", str(c)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                              text=True) for c in range(cores)]
-    rate = 0.0
-    done = 0
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=seconds * 6 + 120)
-            d = json.loads(out.strip().splitlines()[-1])
-            rate += d["reps"] / (d["t_getplen"] + d["t_mutate"])
-            done += 1
-        except Exception:
-            p.kill()
-    return {"value": rate, "unit": "trees/s", "cores": done,
-            "sample": f"{done} concurrent single-threaded reference chains, {seconds:.0f} s each"}
+    with tempfile.TemporaryDirectory() as td:
+        tf = Path(td) / "tree.npz"
+        parent, left, right, root = tree_arrays
+        np.savez(tf, parent=parent, left=left, right=right, root=root)
+        cmd = [sys.executable, "-m", "oracle.cpu_bench", "--taxa", str(taxa), "--sites", str(sites), "--seed", str(seed),
+               "--dist", dist, "--kind", str(kind), "--seconds", str(seconds), "--tree", str(tf)]
+        procs = [subprocess.Popen(cmd + ["--chain", str(c)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                  text=True) for c in range(cores)]
+        rate, done, dirty = 0.0, 0, 0.0
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=seconds * 6 + 120)
+                d = json.loads(out.strip().splitlines()[-1])
+                rate += d["reps"] / (d["t_getplen"] + d["t_mutate"])
+                dirty += d["dirty"]
+                done += 1
+            except Exception:
+                p.kill()
+    return {"value": rate, "unit": "trees/s", "cores": done, "mean_dirty_nodes": round(dirty / max(done, 1), 2),
+            "sample": f"{done} concurrent single-threaded reference processes, {seconds:.0f} s each, same tree"}
 
 
-def cpu_baseline(rows, kind: int, budget_s: float, spot, args_sites_seed=None):
-    """LVB's CPU path on this host: reference mutate_* + getplen (incl. its per-proposal treecopy)."""
+def cpu_port_baseline(rows, kind: int, budget_s: float, tree):
+    """Fallback when the compiled reference did not travel: our C restatement (oracle/fitch_oracle.c)."""
     from oracle import binding as ob
-    cores = 1
-    if ob.load_ref() is not None:
-        rr = ob.RefRun(rows=rows, seed=12345, nproc=1)
-        try:
-            rr.getplen(0)
-            # calibrate on a few proposals, then size the sample to the budget
-            tg, tm, _, _ = rr.time_proposals(kind, 20, 4)
-            per = max((tg + tm) / 20, 1e-6)
-            reps = int(max(50, min(20000, budget_s / per)))
-            tg, tm, cs, ds = rr.time_proposals(kind, reps, 4)
-            tfull, _ = rr.time_full(3)
-            # spot parity: the reference's full evaluation of the bench's own start tree
-            check = None
-            if spot is not None:
-                left, right, root, length = spot
-                ot = ob.OracleTree(rr.n, rr.nwords, rr.enc())
-                from tests.helpers import parents_of
-                l64, r64 = np.asarray(left, np.int64), np.asarray(right, np.int64)
-                ot.set_topology(parents_of(l64, r64), l64, r64, root)
-                check = bool(ot.getplen() == length)
-            all_cores = cpu_all_cores(len(rows), args_sites_seed, kind, min(budget_s, 8.0))
-            return {
-                "value": reps / (tg + tm), "unit": "trees/s", "cores": cores, "kind": "reference",
-                "all_cores": all_cores,
-                "sample": f"{reps} {['NNI', 'SPR', 'TBR'][kind]} proposals (mutate incl. treecopy + incremental "
-                          f"getplen, serial branch), every 4th accepted, same alignment; getplen alone "
-                          f"{reps / tg:.0f}/s ({1e3 * tg / reps:.3f} ms), mutate {1e3 * tm / reps:.3f} ms, "
-                          f"full getplen {1e3 * tfull / 3:.2f} ms, mean dirty {ds / reps:.1f}",
-                "getplen_only_trees_per_s": reps / tg,
-                "start_tree_length_matches_cpu": check,
-            }
-        finally:
-            rr.close()
-    # fallback: our C restatement (the reference did not travel)
-    from lvb_amd import host
+    from tests.helpers import apply_edits, parents_of
     enc = ob.encode_rows(rows)
     n, nwords = enc.shape
-    tree = host.HostTree(n, seed=12345)
     _, left, right = tree.arrays()
-    from tests.helpers import apply_edits, parents_of
     cur = ob.OracleTree(n, nwords, enc)
     l64, r64 = left.astype(np.int64), right.astype(np.int64)
     cur.set_topology(parents_of(l64, r64), l64, r64, tree.root)
     cur.getplen()
     prop = ob.OracleTree(n, nwords)
-    t_total, reps = 0.0, 0
+    t_total, reps, dirty = 0.0, 0, 0
     while t_total < budget_s and reps < 20000:
         edits = tree.propose(kind)
         prog = tree.program(mode=0, edits=edits)
@@ -153,40 +347,51 @@ def cpu_baseline(rows, kind: int, budget_s: float, spot, args_sites_seed=None):
         prop.mark_dirty([d for d in prog["dsts"] if d >= 0])
         prop.getplen()
         t_total += time.perf_counter() - t0
+        dirty += prog["dirty"]
         reps += 1
     return {"value": reps / t_total, "unit": "trees/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} proposals through oracle/fitch_oracle.c (treecopy + incremental getplen)"}
+            "mean_dirty_nodes": round(dirty / max(reps, 1), 2),
+            "sample": f"{reps} neighbours of the GPU leg's tree through oracle/fitch_oracle.c (treecopy + incremental getplen)"}
 
 
-def main():
-    args = parse_args()
+def tree_arrays_of(tree):
+    p, l, r = tree.arrays()
+    return p.astype(np.int64), l.astype(np.int64), r.astype(np.int64), int(tree.root)
+
+
+def load_traffic(args, mixed: bool):
+    tfile = ROOT / "profiles" / "traffic.json"
+    if not tfile.exists():
+        return None
+    t = json.loads(tfile.read_text())
+    for e in t if isinstance(t, list) else [t]:
+        if (e.get("taxa"), e.get("sites"), e.get("batch"), e.get("move"), bool(e.get("mixed_walk", False))) == \
+                (args.taxa, args.sites, args.batch, args.move, mixed):
+            return e["hbm_bytes_per_launch"]   # rocprofv3 PMC passes (profiles/collect.sh), gfx950-corrected
+    return None
+
+
+# ----------------------------------------------------------------------------------------- one rank
+
+def rank_main(args) -> None:
     from lvb_amd.launch import Ranks
     ranks = Ranks()                       # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
-    rank, world, local_rank = ranks.rank, ranks.world, ranks.local_rank
-    if world != args.gpus and world > 1:
+    rank, world = ranks.rank, ranks.world
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from lvb_amd import api, host
 
     kind = MOVES[args.move]
+    B = args.batch
     t_setup = time.perf_counter()
-    rows, min_len = host.prepare_alignment(synth_rows(args.taxa, args.sites, args.seed, args.dist))
+    raw_rows = synth_rows(args.taxa, args.sites, args.seed, args.dist)
+    rows, min_len = host.prepare_alignment(raw_rows)
     ctx = api.FitchContext(text_rows=rows, device=ranks.device)    # encode on the device
     tree = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed))  # each rank: its own restart
-    length = tree.upload(ctx)
-    for _ in range(args.walk):                                      # short random walk, as BASELINE.md
-        e = tree.propose(kind)
-        length = ctx.commit(e)
-        tree.apply(e)
-    spot = (tree.arrays()[1].copy(), tree.arrays()[2].copy(), tree.root, length)
-
-    batches = []
-    for b in range(args.nbatches):
-        offs, edits = tree.propose_batch(kind, args.batch)
-        bh = api.C.c_void_p()
-        ctx._chk(ctx.lib.lvbgpu_batch_build(ctx.h, args.batch, offs, edits.ctypes.data, None, api.C.byref(bh)))
-        batches.append(api.Batch(ctx, bh, args.batch))
-    stats = [b.stats() for b in batches]
+    tree.upload(ctx)
+    length = random_walk(ctx, tree, kind, args.walk)                # short random walk, as BASELINE.md
+    fresh_arrays = tree_arrays_of(tree)
     setup_s = time.perf_counter() - t_setup
 
     own_comm = False
@@ -194,6 +399,7 @@ def main():
         # RCCL communicator of the scoring library itself (not torch's).  Its init is collective, so the
         # ranks first agree (through torch) that every one of them can take part: a rank that cannot must not
         # leave the others waiting inside ncclCommInitRank.
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # a failing ncclCommInitRank says why on stderr
         if ranks.sum_over_ranks(int(api.comm_available())) == world:
             uid = None
             if rank == 0:
@@ -211,63 +417,28 @@ def main():
                           file=sys.stderr)
         own_comm = bool(ranks.sum_over_ranks(int(own_comm)) == world)
 
-    def barrier():
-        ctx.synchronize()
-        ranks.barrier()
-
-    for b in batches:          # setup, not warm-up: every resident batch is scored once, so that any --warmup /
-        b.launch()             # --steps (even 0 / 1) reads back lengths that exist
-    for i in range(args.warmup):
-        batches[i % len(batches)].launch()
-    for b in batches:          # the first read-back after a run of launches costs the runtime several milliseconds
-        b.lengths()            # once (pinned-buffer mapping, signal pool): not a per-step cost, so it happens here
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for i in range(args.steps):
-        batches[i % len(batches)].launch()
-    kernel_ms = ctx.timer_stop()  # HIP events on the stream the kernels run on
-    t_gpu_done = time.perf_counter()
-    best_local = min(int(b.lengths().min()) for b in batches)
-    best_global = best_local
-    if world > 1:
+    def reduce_best(best_local: int) -> int:
+        if world == 1:
+            return best_local
         if own_comm:
-            best_global, _ = ctx.allreduce_min(best_local)
-        else:
-            best_global = -ranks.max_over_ranks(-float(best_local))
-            best_global = int(best_global)
-    t_reduced = time.perf_counter()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    print(f"[rank {rank}] timed region: launches+sync {1e3 * (t_gpu_done - t0):.2f} ms (events {kernel_ms:.2f} ms), "
-          f"lengths+min-reduce {1e3 * (t_reduced - t_gpu_done):.2f} ms, barrier {1e3 * (t0 + elapsed - t_reduced):.2f} ms",
+            return ctx.allreduce_min(best_local)[0]
+        return int(-ranks.max_over_ranks(-float(best_local)))
+
+    # ---- the timed region: K steps of submit -> lengths on the host (+ the min-reduce over ranks)
+    head = submit_to_lengths(ctx, ranks, B, kind, args.steps, args.warmup, 1000, reduce_best)
+    total_trees = head["scored_per_step"] * args.steps * world if head["scored_per_step"] else B * args.steps * world
+    print(f"[rank {rank}] timed region {1e3 * head['elapsed_s']:.2f} ms for {args.steps} steps "
+          f"(local loop {1e3 * head['steps_s_local']:.2f} ms), walk {head['launch_ms'] * 1e3:.1f} us x {head['walks']}",
           file=sys.stderr)
 
-    elapsed = ranks.max_over_ranks(elapsed)   # the slowest rank defines the step time
-
-    # per-launch accounting for the roofline: average over the batches actually launched
-    launched = [stats[i % len(batches)] for i in range(args.steps)]
-    alg_bytes = float(np.mean([s["algorithmic_bytes"] for s in launched]))
-    mean_dirty = float(np.mean([s["dirty_nodes"] / s["candidates"] for s in launched]))
-    launch_ms = kernel_ms / args.steps
-    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-
-    traffic = None
-    tfile = ROOT / "profiles" / "traffic.json"
-    if tfile.exists():
-        t = json.loads(tfile.read_text())
-        if (t.get("taxa"), t.get("sites"), t.get("batch"), t.get("move")) == (args.taxa, args.sites, args.batch, args.move):
-            traffic = t["hbm_bytes_per_launch"]   # rocprofv3 PMC passes (profiles/collect.sh), gfx950-corrected
-
-    total_trees = args.batch * args.steps * world
     out = {
         "metric": "candidate trees scored/sec (Fitch getplen), 500 taxa x 50k sites",
-        "value": total_trees / elapsed,
+        "value": total_trees / head["elapsed_s"],
         "unit": "trees/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step": 1e3 * head["elapsed_s"] / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -276,41 +447,70 @@ def main():
         "config": {
             "workload": f"{args.taxa} taxa x {args.sites} sites synthetic DNA "
                         f"({'tree-like, 10% substitutions' if args.dist == 'tree' else 'i.i.d. uniform'}), "
-                        f"{args.move.upper()} neighbourhood, incremental getplen semantics, "
-                        f"B={args.batch} candidates per step, {args.nbatches} resident batches cycled",
+                        f"{args.move.upper()} neighbourhood, incremental getplen semantics, B={B} candidates per step; "
+                        f"a step = submit -> lengths on the host (lvbgpu_propose_score: neighbours drawn, programmed "
+                        f"and scored on the GPU); start tree + {args.walk} accepted moves",
             "taxa": args.taxa, "sites_after_constant_cut": len(rows[0]), "nwords": ctx.nwords,
-            "batch": args.batch, "move": args.move, "mean_dirty_nodes": round(mean_dirty, 2),
-            "parallelism": f"{world} independent restart(s), one per GPU; RCCL min-reduce of best length"
-                           + ("" if world == 1 else (" (lvbgpu_allreduce_min)" if own_comm else " (torch fallback)")),
-            "best_length": best_global, "min_len_tree": min_len, "setup_seconds": round(setup_s, 2),
+            "batch": B, "move": args.move, "mean_dirty_nodes": round(head["mean_dirty"], 2),
+            "parallelism": f"{world} independent restart(s), one per GPU; best length min-reduced over RCCL"
+                           + ("" if world == 1 else (" by lvbgpu_allreduce_min" if own_comm else " (torch fallback)")),
+            "best_length": head["best"], "min_len_tree": min_len, "setup_seconds": round(setup_s, 2),
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "lvbgpu::fitch_walk<false, false>", "launch_ms": launch_ms,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "algorithmic bytes = (D+3) clean rows x nwords x 8 per candidate; rows are re-read from "
-                    "the XCD L2 / Infinity Cache, so achieved may exceed the HBM figure",
-            # the ceiling that does bound this kernel: what a pure-load probe with the same access pattern reads
-            # through the L2 -> CU path on this chip (tools/l2_probe.hip)
-            "cache_path": {"ceiling": L2_PATH_PROBE_GBS, "unit": "GB/s", "frac": achieved / L2_PATH_PROBE_GBS,
-                           "source": "tools/l2_probe.hip measured on MI355X (not re-measured in this run)"},
-        },
+        "roofline": roofline_block(ctx, B, head["alg_bytes"], head["launch_ms"], head["mean_dirty"],
+                                   load_traffic(args, False)),
     }
-    if args.e2e_steps > 0:
-        # nothing resident but the tree: every step draws B fresh neighbours on the device
-        ctx.propose_score(args.batch, kind, 1)
-        ctx.synchronize()
-        te = time.perf_counter()
-        for i in range(args.e2e_steps):
-            ctx.propose_score(args.batch, kind, 1000 + i)
-        te = time.perf_counter() - te
-        out["end_to_end"] = {
-            "value": args.batch * args.e2e_steps / te, "unit": "trees/s", "steps": args.e2e_steps,
-            "what": "lvbgpu_propose_score per step: draw B neighbours + build their programs + score on the GPU, "
-                    "lengths and move descriptors copied back to the host (not part of `value`)",
+    steps_side = max(20, min(args.steps, 100))
+    if not args.headline_only:
+        out["kernel_only"] = kernel_only(ctx, tree, B, kind, args.nbatches, steps_side, min(args.warmup, 10))
+
+    extras = rank == 0 and world == 1 and not args.headline_only
+    if extras and not args.no_cpu_baseline and args.dist == "tree":
+        cb = cpu_reference_on_tree(rows, kind, args.cpu_seconds, fresh_arrays, length,
+                                   (args.taxa, args.sites, args.seed, args.dist))
+        out["cpu_baseline"] = cb if cb is not None else cpu_port_baseline(rows, kind, args.cpu_seconds, tree)
+
+    if extras and not args.no_shapes:
+        shapes = {}
+        for b in (256, 1024):
+            r = submit_to_lengths(ctx, ranks, b, kind, steps_side, 5, 5000)
+            shapes[f"B{b}"] = {"value": r["scored_per_step"] * steps_side / r["elapsed_s"], "unit": "trees/s",
+                               "ms_per_step": 1e3 * r["elapsed_s"] / steps_side, "walk_ms": r["launch_ms"],
+                               "mean_dirty_nodes": round(r["mean_dirty"], 2)}
+        if args.dist == "tree":
+            # SURVEY.md 8(d) "U": i.i.d. uniform cells (almost every combine is a union), same start tree
+            urows, _ = host.prepare_alignment(synth_rows(args.taxa, args.sites, args.seed, "uniform"))
+            uctx = api.FitchContext(text_rows=urows, device=ranks.device)
+            _, ul, ur = (a.copy() for a in tree.arrays())
+            uctx.set_tree(ul, ur, tree.root)
+            r = submit_to_lengths(uctx, ranks, B, kind, steps_side, 5, 1000)
+            shapes["uniform"] = {"value": r["scored_per_step"] * steps_side / r["elapsed_s"], "unit": "trees/s",
+                                 "ms_per_step": 1e3 * r["elapsed_s"] / steps_side, "walk_ms": r["launch_ms"],
+                                 "mean_dirty_nodes": round(r["mean_dirty"], 2), "batch": B,
+                                 "sites_after_constant_cut": len(urows[0])}
+            uctx.close()
+        out["shapes"] = shapes
+
+    if extras and args.mixed_walk > 0:
+        # the shape an annealing run spends its time on: the walk drifts toward uniform-random trees whose
+        # root-ward paths are 2-3x longer.  Same legs, same tree for GPU and CPU.
+        mtree = host.HostTree(left=tree.arrays()[1], right=tree.arrays()[2], root=tree.root, seed=args.seed * 31 + 7)
+        mlen = random_walk(ctx, mtree, kind, args.mixed_walk)
+        m = submit_to_lengths(ctx, ranks, B, kind, steps_side, 5, 9000)
+        mw = {
+            "accepted_moves": args.walk + args.mixed_walk, "mean_dirty_nodes": round(m["mean_dirty"], 2),
+            "value": m["scored_per_step"] * steps_side / m["elapsed_s"], "unit": "trees/s",
+            "ms_per_step": 1e3 * m["elapsed_s"] / steps_side, "steps": steps_side,
+            "roofline": roofline_block(ctx, B, m["alg_bytes"], m["launch_ms"], m["mean_dirty"], load_traffic(args, True), 10),
+            "kernel_only": kernel_only(ctx, mtree, B, kind, args.nbatches, steps_side, 5),
         }
-    if args.anneal_seconds > 0:
+        if not args.no_cpu_baseline and args.dist == "tree":
+            mw["cpu_baseline"] = cpu_reference_on_tree(rows, kind, args.cpu_seconds, tree_arrays_of(mtree), mlen,
+                                                       (args.taxa, args.sites, args.seed, args.dist), all_cores=False)
+        out["mixed_walk"] = mw
+        # back to the headline tree for the annealing leg
+        tree.upload(ctx)
+
+    if args.anneal_seconds > 0 and not args.headline_only and (extras or world > 1):
         # second half of the metric: best length vs wall clock, whole host loop included
         # (proposal generation, program build, H2D, kernels, D2H, accept/commit) - not part of `value`
         p = host.anneal_defaults()
@@ -323,25 +523,33 @@ def main():
         p.log_cap = 4096
         res, log = host.anneal(ctx, tree, p)
         keep = log[:: max(1, len(log) // 12)] + log[-1:]
-        out["anneal"] = {
-            "seconds": round(res["seconds"], 3), "start_length": res["start_length"],
-            "best_length": res["best_length"], "scored": res["scored"], "consumed": res["consumed"],
-            "accepted": res["accepted"], "device_steps": res["device_steps"],
-            "scored_per_s": round(res["scored"] / res["seconds"]), "consumed_per_s": round(res["consumed"] / res["seconds"]),
-            "device_fraction": round(res["seconds_device"] / res["seconds"], 3), "batch": args.anneal_batch,
-            "t_final": res["t_final"], "temperatures": res["temperatures"], "frozen": res["frozen"],
-            "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
-        }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dist == "tree":
-        out["cpu_baseline"] = cpu_baseline(rows, kind, args.cpu_seconds, spot, (args.sites, args.seed))
-    for b in batches:
-        b.free()
+        if rank == 0:
+            out["anneal"] = {
+                "seconds": round(res["seconds"], 3), "start_length": res["start_length"],
+                "best_length": res["best_length"], "scored": res["scored"], "consumed": res["consumed"],
+                "accepted": res["accepted"], "device_steps": res["device_steps"],
+                "scored_per_s": round(res["scored"] / res["seconds"]), "consumed_per_s": round(res["consumed"] / res["seconds"]),
+                "device_fraction": round(res["seconds_device"] / res["seconds"], 3), "batch": args.anneal_batch,
+                "t_final": res["t_final"], "temperatures": res["temperatures"], "frozen": res["frozen"],
+                "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
+            }
     tree.close()
     ctx.close()
     ranks.close()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+
+def main() -> int:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)          # before anything here can touch a GPU
+    if args.dry_ranks:
+        dry_rank_main(args)
+    else:
+        rank_main(args)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

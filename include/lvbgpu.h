@@ -133,7 +133,7 @@ int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets,
 int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edit_offsets,
                        const lvbgpu_edit *edits, const int32_t *roots, lvbgpu_batch **out);
 int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *batch);
-int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *batch, int64_t *lengths_out);
+int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *batch, int64_t *lengths_out); /* LVBGPU_E_STATE before a launch */
 int lvbgpu_batch_get_stats(const lvbgpu_batch *batch, lvbgpu_batch_stats *out);
 void lvbgpu_batch_free(lvbgpu_batch *batch);
 
@@ -154,6 +154,9 @@ int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_nni, double 
                                uint64_t seed, int64_t *lengths_out);
 int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits,
                           int32_t *info4);
+/* counts of the LAST device-built batch (as lvbgpu_batch_get_stats gives for host-built ones; candidates that
+ * overflowed are left out): reads the batch's descriptors back - for measurement, not for the search */
+int lvbgpu_proposal_stats(lvbgpu_ctx *ctx, lvbgpu_batch_stats *out);
 /* the same with the moves NAMED by the host (a search that draws its own neighbours, e.g. with the
  * reference's random stream, but wants no host work per candidate beyond 16 bytes): the device turns
  * each move into its child-pair rewrites and its program, as mutate_nni/spr/tbr + the dirty marking
@@ -194,6 +197,18 @@ int lvbgpu_timer_start(lvbgpu_ctx *ctx);
 int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms); /* synchronises */
 int lvbgpu_synchronize(lvbgpu_ctx *ctx);
 void *lvbgpu_stream(lvbgpu_ctx *ctx); /* hipStream_t, for interop */
+
+/* per-kernel timing for the roofline line: while enabled, every scoring walk the library launches (batch
+ * launches, lvbgpu_score_batch, lvbgpu_propose_score*, lvbgpu_score_moves) is bracketed by HIP events on
+ * the context's stream; _read waits for the walks in flight and returns the sum of their durations and
+ * their number since timing was enabled.  Commit walks are not counted. */
+int lvbgpu_walk_timing(lvbgpu_ctx *ctx, int enable);
+int lvbgpu_walk_timing_read(lvbgpu_ctx *ctx, double *total_ms, int64_t *launches);
+/* what the memory path the walk is bound by delivers on this device, measured now: a pure-load kernel with
+ * the walk's launch geometry and access pattern (one wave per (tile, candidate), XCD-aware order,
+ * rows_per_wave pseudo-random rows of the resident block per tile, 4 or 8 loads of 1 KiB in flight,
+ * one XOR per 16 bytes) over B candidates, `reps` launches; *gb_per_s = the better of the two. */
+int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave, int32_t reps, double *gb_per_s);
 
 /* ---- multi-GPU: best length over independent restarts (one context per process/GPU) ----
  * id is an opaque 128-byte RCCL unique id created on rank 0 and distributed by the launcher. */

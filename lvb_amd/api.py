@@ -69,12 +69,16 @@ SIGNATURES = {
     "lvbgpu_propose_score_mixed": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_uint64,
                                             _i64p]),
     "lvbgpu_proposal_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _i32p]),
+    "lvbgpu_proposal_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
     "lvbgpu_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "lvbgpu_getplen_compat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_int64)]),
     "lvbgpu_timer_start": (C.c_int, [C.c_void_p]),
     "lvbgpu_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "lvbgpu_synchronize": (C.c_int, [C.c_void_p]),
+    "lvbgpu_walk_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "lvbgpu_walk_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "lvbgpu_probe_l2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "lvbgpu_stream": (C.c_void_p, [C.c_void_p]),
     "lvbgpu_comm_available": (C.c_int, []),
     "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -294,6 +298,12 @@ class FitchContext:
         self._chk(self.lib.lvbgpu_proposal_edits(self.h, int(b), buf.ctypes.data, cap, C.byref(k), info))
         return buf[: k.value].copy(), info
 
+    def proposal_stats(self) -> dict:
+        """Counts of the last device-built batch (candidates, combines, rows_read, dirty_nodes, ...)."""
+        st = BatchStats()
+        self._chk(self.lib.lvbgpu_proposal_stats(self.h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in BatchStats._fields_}
+
     def score_full_batch(self, lefts, rights, roots=None) -> np.ndarray:
         l = np.ascontiguousarray(lefts, dtype=np.int32)
         r = np.ascontiguousarray(rights, dtype=np.int32)
@@ -328,6 +338,21 @@ class FitchContext:
 
     def synchronize(self) -> None:
         self._chk(self.lib.lvbgpu_synchronize(self.h))
+
+    def walk_timing(self, enable: bool) -> None:
+        self._chk(self.lib.lvbgpu_walk_timing(self.h, 1 if enable else 0))
+
+    def walk_timing_read(self) -> tuple[float, int]:
+        """(sum of the scoring walks' durations in ms, their number) since walk_timing(True)."""
+        ms, k = C.c_double(), C.c_int64()
+        self._chk(self.lib.lvbgpu_walk_timing_read(self.h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+    def probe_l2(self, B: int, rows_per_wave: int = 24, reps: int = 20) -> float:
+        """GB/s a pure-load kernel with the walk's geometry and access pattern reads on this device now."""
+        out = C.c_double()
+        self._chk(self.lib.lvbgpu_probe_l2(self.h, B, rows_per_wave, reps, C.byref(out)))
+        return out.value
 
     # ---- multi-GPU
     def comm_init(self, nranks: int, rank: int, unique_id: bytes) -> None:

@@ -9,6 +9,8 @@ extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
     {
         (void)hipSetDevice(b->ctx->device);
         (void)hipStreamSynchronize(b->ctx->stream);
+        auto &held = b->ctx->held;
+        held.erase(std::remove(held.begin(), held.end(), b), held.end());
     }
     b->d_prog.release();
     b->d_len.release();
@@ -300,6 +302,7 @@ extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
         lvbgpu_batch_free(bt);
         return rc;
     }
+    ctx->held.push_back(bt);
     *out = bt;
     return LVBGPU_OK;
 }
@@ -321,7 +324,23 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         a.host_flag = (uint32_t *)ctx->h_step.p;
         a.step_seq = ++ctx->step_seq;
     }
+    if (ctx->walk_timing)
+    {
+        if (ctx->wt_pending == lvbgpu_ctx::WT_RING)
+        {
+            const int rc = walk_timing_drain(ctx);
+            if (rc != LVBGPU_OK)
+                return rc;
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->wt_ev[2 * ctx->wt_pending], ctx->stream));
+    }
     HIPCHK(ctx, launch_walk(a, false, ctx->stream));
+    if (ctx->walk_timing)
+    {
+        HIPCHK(ctx, hipEventRecord(ctx->wt_ev[2 * ctx->wt_pending + 1], ctx->stream));
+        ctx->wt_pending++;
+    }
+    b->launched = true;
     return LVBGPU_OK;
 }
 
@@ -351,6 +370,8 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
 {
     if (!ctx || !b || b->ctx != ctx || !lengths_out)
         return LVBGPU_E_ARG;
+    if (!b->launched)
+        return ctx->fail(LVBGPU_E_STATE, "this batch was never launched: call lvbgpu_batch_launch first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (b->direct)
     {

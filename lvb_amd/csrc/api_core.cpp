@@ -285,6 +285,13 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->h_cin.release();
     ctx->h_cout.release();
     ctx->d_comm.release();
+    ctx->d_probe_sink.release();
+    for (lvbgpu_batch *hb : ctx->held) // the caller still owns them; they must not reach into a dead context
+        hb->ctx = nullptr;
+    ctx->held.clear();
+    for (hipEvent_t ev : ctx->wt_ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
     if (ctx->ev0)
         (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1)
@@ -586,6 +593,89 @@ extern "C" int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms)
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return LVBGPU_OK;
+}
+
+namespace lvbgpu_detail
+{
+// wait for the timed walks still in flight and add their durations up
+int walk_timing_drain(lvbgpu_ctx *ctx)
+{
+    for (int i = 0; i < ctx->wt_pending; i++)
+    {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(ctx->wt_ev[2 * i + 1]));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->wt_ev[2 * i], ctx->wt_ev[2 * i + 1]));
+        ctx->wt_ms += ms;
+        ctx->wt_launches++;
+    }
+    ctx->wt_pending = 0;
+    return LVBGPU_OK;
+}
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_walk_timing(lvbgpu_ctx *ctx, int enable)
+{
+    if (!ctx)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (enable)
+    {
+        for (hipEvent_t &ev : ctx->wt_ev)
+            if (!ev)
+                HIPCHK(ctx, hipEventCreate(&ev));
+        ctx->wt_pending = 0;
+        ctx->wt_ms = 0.0;
+        ctx->wt_launches = 0;
+        ctx->walk_timing = true;
+        return LVBGPU_OK;
+    }
+    const int rc = ctx->walk_timing ? walk_timing_drain(ctx) : LVBGPU_OK;
+    ctx->walk_timing = false;
+    return rc;
+}
+
+extern "C" int lvbgpu_walk_timing_read(lvbgpu_ctx *ctx, double *total_ms, int64_t *launches)
+{
+    if (!ctx || !total_ms || !launches)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = walk_timing_drain(ctx);
+    if (rc != LVBGPU_OK)
+        return rc;
+    *total_ms = ctx->wt_ms;
+    *launches = ctx->wt_launches;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave, int32_t reps, double *gb_per_s)
+{
+    if (!ctx || !gb_per_s || B < 1 || rows_per_wave < 8 || reps < 1 || (uint64_t)B * ctx->ntiles >= (1ull << 31))
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->d_probe_sink.reserve(64));
+    const uint32_t ngroups = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
+    double best = 0.0;
+    for (int ring : {4, 8})
+    {
+        uint64_t loads = 0;
+        for (int i = 0; i < 3; i++) // warm the caches and the clocks
+            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, (uint32_t)ctx->nb, ctx->ntiles, ngroups,
+                                        (uint32_t)B, (uint32_t)rows_per_wave, ring, (uint4 *)ctx->d_probe_sink.p, &loads,
+                                        ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int i = 0; i < reps; i++)
+            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, (uint32_t)ctx->nb, ctx->ntiles, ngroups,
+                                        (uint32_t)B, (uint32_t)rows_per_wave, ring, (uint4 *)ctx->d_probe_sink.p, &loads,
+                                        ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        if (ms > 0.f)
+            best = std::max(best, (double)loads * 1024.0 * reps / (ms * 1e-3) / 1e9);
+    }
+    *gb_per_s = best;
     return LVBGPU_OK;
 }
 

@@ -282,3 +282,32 @@ extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *ed
     return LVBGPU_OK;
 }
 
+
+// what the last device-built batch cost (the counts lvbgpu_batch_get_stats gives for host-built ones): the
+// candidates' descriptors are read back and summed - for the measurement line, not for the search
+extern "C" int lvbgpu_proposal_stats(lvbgpu_ctx *ctx, lvbgpu_batch_stats *out)
+{
+    if (!ctx || !out)
+        return LVBGPU_E_ARG;
+    if (ctx->p_B <= 0 || !ctx->prop_batch)
+        return ctx->fail(LVBGPU_E_STATE, "no device batch: call lvbgpu_propose_score first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<ProposalInfo> info((size_t)ctx->p_B);
+    HIPCHK(ctx, hipMemcpyAsync(info.data(), ctx->d_pinfo.p, info.size() * sizeof(ProposalInfo), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    lvbgpu_batch_stats st{};
+    st.max_stack = 1;
+    for (const ProposalInfo &pi : info)
+    {
+        if (pi.overflow)
+            continue;
+        st.candidates++;
+        st.combines += pi.ncomb;       // D + 2
+        st.rows_read += pi.ncomb + 1;  // D + 3 clean rows
+        st.dirty_nodes += pi.ncomb - 2;
+    }
+    st.algorithmic_bytes = st.rows_read * ctx->nwords * 8;
+    *out = st;
+    return LVBGPU_OK;
+}

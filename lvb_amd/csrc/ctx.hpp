@@ -190,6 +190,19 @@ struct lvbgpu_ctx
     int comm_rank = 0, comm_size = 1;
     DevBuf d_comm;
 
+    // batches the caller holds (lvbgpu_batch_build): lvbgpu_destroy detaches them, so that a batch freed
+    // after its context touches nothing of it
+    std::vector<lvbgpu_batch *> held;
+
+    // lvbgpu_walk_timing: HIP events around every scoring walk, on the stream it is launched on
+    static constexpr int WT_RING = 32;
+    bool walk_timing = false;
+    hipEvent_t wt_ev[2 * WT_RING] = {};
+    int wt_pending = 0;
+    double wt_ms = 0.0;
+    int64_t wt_launches = 0;
+    DevBuf d_probe_sink;
+
     std::string last_error;
 
     int fail_hip(hipError_t e, const char *what)
@@ -224,6 +237,7 @@ struct lvbgpu_batch
     bool len_zeroed = false; // d_len was cleared after the previous read-back
     bool direct = false;     // this step's lengths come back through the walk's last wave (no copy, no stream wait)
     bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
+    bool launched = false;   // lengths exist (or are on their way)
     std::vector<int32_t> slot_of; // big batches: candidate b sits at position slot_of[b] (longest program first)
 };
 
@@ -285,6 +299,7 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const void *prog, size_t off_toks, size_
 int check_depth(lvbgpu_ctx *ctx, int32_t max_stack);
 int read_current_length(lvbgpu_ctx *ctx);
 int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool readback);
+int walk_timing_drain(lvbgpu_ctx *ctx);
 } // namespace lvbgpu_detail
 
 using namespace lvbgpu_detail;

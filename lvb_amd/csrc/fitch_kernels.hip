@@ -647,6 +647,86 @@ __global__ void encode_text_kernel(const uint8_t *text, uint32_t n, uint64_t m, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Ceiling probe of the walk's memory path (lvbgpu_probe_l2): the walk's launch geometry and access pattern -
+// one wave per (tile group, candidate), XCD-aware item order, `ntok` pseudo-random rows of the resident block
+// per tile, RING row loads (1 KiB each) in flight - with the arithmetic replaced by one XOR per 16 bytes.
+// What it reads per second is what the L2 -> CU path delivers to this pattern on this chip, measured in the
+// run that quotes it.
+template <int RING>
+__global__ __launch_bounds__(WALK_THREADS) void l2_probe_kernel(const uint4 *rows, uint32_t stride4, uint32_t nrows,
+                                                                uint32_t ntiles, uint32_t ngroups, uint32_t B,
+                                                                uint32_t ntok, uint4 *sink)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nblk = gridDim.x;
+    const uint32_t pos = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const uint32_t item = pos * WALK_WAVES + wave;
+    if (item >= B * ngroups)
+        return;
+    const uint32_t group = item / B, cand = item - group * B;
+    const uint32_t t0 = (uint32_t)((uint64_t)group * ntiles / ngroups), t1 = (uint32_t)((uint64_t)(group + 1) * ntiles / ngroups);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    const uint32_t seed = cand * 2654435761u + 12345u;
+    for (uint32_t t = t0; t < t1; t++)
+    {
+        const uint4 *base = rows + (size_t)t * 64u + lane;
+        uint32_t s = seed;
+        uint4 ring[RING];
+#pragma unroll
+        for (int q = 0; q < RING; q++)
+        {
+            s = s * 1664525u + 1013904223u;
+            ring[q] = base[(size_t)((s >> 8) % nrows) * stride4];
+        }
+        for (uint32_t j = 0; j + RING <= ntok; j += RING)
+        {
+#pragma unroll
+            for (int q = 0; q < RING; q++)
+            {
+                acc.x ^= ring[q].x;
+                acc.y ^= ring[q].y;
+                acc.z ^= ring[q].z;
+                acc.w ^= ring[q].w;
+                s = s * 1664525u + 1013904223u;
+                ring[q] = base[(size_t)((s >> 8) % nrows) * stride4];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RING; q++)
+        {
+            acc.x ^= ring[q].x;
+            acc.y ^= ring[q].y;
+            acc.z ^= ring[q].z;
+            acc.w ^= ring[q].w;
+        }
+    }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u && acc.z == 0x0fedcba9u) // never: keeps the loads alive
+        sink[0] = acc;
+}
+
+hipError_t launch_l2_probe(const uint4 *rows, uint32_t stride4, uint32_t nrows, uint32_t ntiles, uint32_t ngroups,
+                           uint32_t B, uint32_t ntok, int ring, uint4 *sink, uint64_t *loads_out, hipStream_t stream)
+{
+    if (B == 0 || ngroups == 0 || ngroups > ntiles || nrows == 0 || (uint64_t)B * ngroups >= (1ull << 31))
+        return hipErrorInvalidValue;
+    uint32_t nblk = (B * ngroups + WALK_WAVES - 1) / WALK_WAVES;
+    nblk = (nblk + 7u) & ~7u;
+    const dim3 grid(nblk), block(WALK_THREADS);
+    if (ring == 8)
+        hipLaunchKernelGGL(l2_probe_kernel<8>, grid, block, 0, stream, rows, stride4, nrows, ntiles, ngroups, B, ntok, sink);
+    else
+    {
+        ring = 4;
+        hipLaunchKernelGGL(l2_probe_kernel<4>, grid, block, 0, stream, rows, stride4, nrows, ntiles, ngroups, B, ntok, sink);
+    }
+    if (loads_out) // row loads (1 KiB each) one launch issues
+        *loads_out = (uint64_t)B * ntiles * ((uint64_t)(ntok / (uint32_t)ring) * (uint32_t)ring + (uint32_t)ring);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (kernels.hpp)
 

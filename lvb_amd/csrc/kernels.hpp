@@ -130,6 +130,9 @@ hipError_t launch_fill_pad(uint64_t *rows, uint32_t nrows, uint32_t nwords, uint
 hipError_t launch_relayout(uint4 *rows, uint32_t nrows, uint32_t stride4, bool to_planes, hipStream_t stream);
 // one bit-plane row -> nibble layout in `out`
 hipError_t launch_export_row(const uint4 *row, uint4 *out, uint32_t stride4, hipStream_t stream);
+// ceiling probe of the walk's memory path: one launch; *loads_out = 1 KiB row loads it issues
+hipError_t launch_l2_probe(const uint4 *rows, uint32_t stride4, uint32_t nrows, uint32_t ntiles, uint32_t ngroups,
+                           uint32_t B, uint32_t ntok, int ring, uint4 *sink, uint64_t *loads_out, hipStream_t stream);
 hipError_t launch_encode_text(const uint8_t *text, uint32_t n, uint64_t m, uint32_t nwords, uint32_t stride_words,
                               uint64_t *rows, unsigned long long *bad, hipStream_t stream);
 

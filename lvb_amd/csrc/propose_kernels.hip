@@ -588,14 +588,27 @@ hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t
                           bool *paths_capped, hipStream_t stream)
 {
     const int32_t nb = 2 * n - 3;
-    static const hipError_t raised = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return e;
-    }();
+    // the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raise it once for each device a
+    // context of this process launches on (the walk does the same per context, raise_lds_limit)
+    static hipError_t raised_on[64];
+    static bool asked_on[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t raised = hipErrorInvalidDevice;
+    if (dev >= 0 && dev < 64)
+    {
+        if (!asked_on[dev])
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised_on[dev] = e;
+            asked_on[dev] = true;
+        }
+        raised = raised_on[dev];
+    }
     const size_t lds_max = raised == hipSuccess ? 160u * 1024u : 64u * 1024u;
     // the topology in LDS when it fits (16 bytes per node; 160 KB of LDS per CU): up to ~5000 taxa
     size_t lds = (size_t)nb * 16u;

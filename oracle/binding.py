@@ -235,6 +235,8 @@ def load_ref():
     lib.refh_uni.argtypes = []
     lib.refh_randpint.restype = C.c_long
     lib.refh_randpint.argtypes = [C.c_long]
+    if hasattr(lib, "refh_set_topology"):
+        lib.refh_set_topology.argtypes = [vp, C.c_int, _longp, _longp, _longp, C.c_long]
     lib.refh_root.restype = C.c_long
     lib.refh_root.argtypes = [vp, C.c_int]
     lib.refh_getplen.restype = C.c_long
@@ -340,6 +342,11 @@ class RefRun:
 
     def randpint(self, upper: int) -> int:
         return int(self.lib.refh_randpint(int(upper)))
+
+    def set_topology(self, parent, left, right, root: int, which: int = 0) -> None:
+        """Tree `which` := the given arrays (all internal nodes dirty: the next getplen is a full evaluation)."""
+        p, l, r = (np.ascontiguousarray(a, dtype=np.int64) for a in (parent, left, right))
+        self.lib.refh_set_topology(self.h, which, p, l, r, int(root))
 
     def root(self, which: int = 0) -> int:
         return int(self.lib.refh_root(self.h, which))

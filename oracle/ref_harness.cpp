@@ -184,6 +184,25 @@ void refh_random_tree(void *vh)
     h->root[0] = 0;
 }
 
+/* make tree `which` the topology given by the arrays (the node numbering is the caller's), rooted at leaf
+ * `root`: only the records' scalars are written here; every internal node is marked dirty the way the
+ * reference does it (sitestate[0] = 0, TreeOperations.c:49-59), the leaves' sets are re-initialised by the
+ * reference's ss_init, and the caller's next refh_getplen is the reference's full evaluation */
+void refh_set_topology(void *vh, int which, const long *parent, const long *left, const long *right, long root)
+{
+    RefHandle *h = (RefHandle *)vh;
+    TREESTACK_TREE_NODES *t = h->tree[which];
+    for (long i = 0; i < h->msa.numberofpossiblebranches; i++)
+    {
+        t[i].parent = parent[i];
+        t[i].left = left[i];
+        t[i].right = right[i];
+        t[i].changes = 0;
+    }
+    ss_init(&h->msa, t, h->enc);
+    h->root[which] = root;
+}
+
 long refh_root(void *vh, int which) { return ((RefHandle *)vh)->root[which]; }
 
 long refh_getplen(void *vh, int which)

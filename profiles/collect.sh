@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 40 --warmup 5 --no-cpu-baseline --anneal-seconds 0 $*"
+ARGS="--steps 40 --warmup 5 --headline-only $*"
 # pass 1: kernel trace + stats (durations)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"

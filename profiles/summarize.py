@@ -19,7 +19,7 @@ ROOT = Path(__file__).resolve().parent.parent
 KERNEL = "fitch_walk<false,"  # <COMMIT=false, WIDE=...>
 
 
-def main(tag: str) -> None:
+def main(tag: str, mixed: bool = False, extra=()) -> None:
     src = ROOT / "gpurun_out" / f"prof_{tag}"
     stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))
     if stats:
@@ -51,17 +51,23 @@ def main(tag: str) -> None:
                                          ("wait_issue(SQ_WAIT_INST_ANY)", "SQ_WAIT_INST_ANY"),
                                          ("active(SQ_ACTIVE_INST_ANY)", "SQ_ACTIVE_INST_ANY")) if mean(c) is not None}
     doc = {"command": f"rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 40 --warmup 5 "
-                      f"--no-cpu-baseline --anneal-seconds 0   (one pass per counter set, profiles/collect.sh {tag})",
+                      f"--headline-only {' '.join(extra)}  (one pass per counter set, profiles/collect.sh {tag})",
            "kernel": f"lvbgpu::{KERNEL}", "counters": summary, "derived": derived}
     (ROOT / "profiles" / f"{tag}_pmc_summary.json").write_text(json.dumps(doc, indent=1) + "\n")
     if "hbm_read_bytes_per_launch_corrected" in derived:
-        traffic = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-        traffic["hbm_bytes_per_launch"] = derived["hbm_read_bytes_per_launch_corrected"] + derived.get(
-            "hbm_write_bytes_per_launch", 0.0)
-        traffic["source"] = f"profiles/{tag}_pmc_summary.json"
-        (ROOT / "profiles" / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+        # traffic.json: one entry per measured workload (bench.py picks the one that matches its arguments)
+        tf = ROOT / "profiles" / "traffic.json"
+        entries = json.loads(tf.read_text()) if tf.exists() else []
+        if isinstance(entries, dict):
+            entries = [entries]
+        key = dict(taxa=500, sites=50000, batch=4096, move="spr", mixed_walk=mixed)
+        entries = [e for e in entries if any(e.get(k, False if k == "mixed_walk" else None) != v for k, v in key.items())]
+        entries.append(dict(key, hbm_bytes_per_launch=derived["hbm_read_bytes_per_launch_corrected"] + derived.get(
+            "hbm_write_bytes_per_launch", 0.0), source=f"profiles/{tag}_pmc_summary.json"))
+        tf.write_text(json.dumps(entries, indent=1) + "\n")
     print(json.dumps(derived, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01e")
+    # python profiles/summarize.py <tag> [mixed] [bench args the profile was taken with ...]
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02a", "mixed" in sys.argv[2:3], [a for a in sys.argv[2:] if a != "mixed"])
