@@ -198,11 +198,12 @@ int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms); /* synchronises */
 int lvbgpu_synchronize(lvbgpu_ctx *ctx);
 void *lvbgpu_stream(lvbgpu_ctx *ctx); /* hipStream_t, for interop */
 
-/* per-kernel timing for the roofline line: while enabled, every scoring walk the library launches (batch
- * launches, lvbgpu_score_batch, lvbgpu_propose_score*, lvbgpu_score_moves) is bracketed by HIP events on
- * the context's stream; _read waits for the walks in flight and returns the sum of their durations and
- * their number since timing was enabled.  Commit walks are not counted. */
-int lvbgpu_walk_timing(lvbgpu_ctx *ctx, int enable);
+/* per-kernel timing for the roofline line: while enabled (every > 0), every `every`-th scoring walk the
+ * library launches (batch launches, lvbgpu_score_batch, lvbgpu_propose_score*, lvbgpu_score_moves) is
+ * bracketed by HIP events on the context's stream - sampled, because a pair of events between launches
+ * costs the step ~20 us; _read waits for the walks in flight and returns the sum of the timed walks' durations
+ * and their number since timing was enabled.  every = 0 turns it off.  Commit walks are not counted. */
+int lvbgpu_walk_timing(lvbgpu_ctx *ctx, int every);
 int lvbgpu_walk_timing_read(lvbgpu_ctx *ctx, double *total_ms, int64_t *launches);
 /* what the memory path the walk is bound by delivers on this device, measured now: a pure-load kernel with
  * the walk's launch geometry and access pattern (one wave per (tile, candidate), XCD-aware order,

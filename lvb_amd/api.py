@@ -339,8 +339,9 @@ class FitchContext:
     def synchronize(self) -> None:
         self._chk(self.lib.lvbgpu_synchronize(self.h))
 
-    def walk_timing(self, enable: bool) -> None:
-        self._chk(self.lib.lvbgpu_walk_timing(self.h, 1 if enable else 0))
+    def walk_timing(self, every: int | bool) -> None:
+        """Time every `every`-th scoring walk with HIP events (True = all, 0/False = off)."""
+        self._chk(self.lib.lvbgpu_walk_timing(self.h, int(every)))
 
     def walk_timing_read(self) -> tuple[float, int]:
         """(sum of the scoring walks' durations in ms, their number) since walk_timing(True)."""

@@ -324,7 +324,8 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         a.host_flag = (uint32_t *)ctx->h_step.p;
         a.step_seq = ++ctx->step_seq;
     }
-    if (ctx->walk_timing)
+    const bool timed = ctx->walk_timing && (ctx->wt_seen++ % ctx->wt_every) == 0;
+    if (timed)
     {
         if (ctx->wt_pending == lvbgpu_ctx::WT_RING)
         {
@@ -335,7 +336,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         HIPCHK(ctx, hipEventRecord(ctx->wt_ev[2 * ctx->wt_pending], ctx->stream));
     }
     HIPCHK(ctx, launch_walk(a, false, ctx->stream));
-    if (ctx->walk_timing)
+    if (timed)
     {
         HIPCHK(ctx, hipEventRecord(ctx->wt_ev[2 * ctx->wt_pending + 1], ctx->stream));
         ctx->wt_pending++;

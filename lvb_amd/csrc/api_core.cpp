@@ -259,6 +259,7 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->d_pedits.release();
     ctx->d_pinfo.release();
     ctx->h_pinfo.release();
+    ctx->h_topo.release();
     ctx->d_moves.release();
     ctx->h_moves.release();
     ctx->h_step.release();
@@ -616,7 +617,7 @@ int walk_timing_drain(lvbgpu_ctx *ctx)
 
 extern "C" int lvbgpu_walk_timing(lvbgpu_ctx *ctx, int enable)
 {
-    if (!ctx)
+    if (!ctx || enable < 0)
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (enable)
@@ -627,6 +628,8 @@ extern "C" int lvbgpu_walk_timing(lvbgpu_ctx *ctx, int enable)
         ctx->wt_pending = 0;
         ctx->wt_ms = 0.0;
         ctx->wt_launches = 0;
+        ctx->wt_every = (uint32_t)enable;
+        ctx->wt_seen = 0;
         ctx->walk_timing = true;
         return LVBGPU_OK;
     }

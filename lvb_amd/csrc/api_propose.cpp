@@ -5,22 +5,51 @@
 
 namespace lvbgpu_detail
 {
-// parent | left | right | number of leaves below, for propose_kernel
+// the generator's tables of the resident topology (layout: GenArgs in kernels.hpp)
+template <typename IdxT>
+static void fill_tables(const Topology &t, int32_t K, const std::vector<int32_t> &order, const std::vector<int32_t> &depth,
+                        const std::vector<int32_t> &nleaf, std::vector<IdxT> &out)
+{
+    const size_t nb = (size_t)t.nb;
+    const size_t nlo = (size_t)t.n; // leaf_order: n - 1 used
+    out.assign((7 + (size_t)K) * nb + nlo + 8, (IdxT)0);
+    IdxT *parent = out.data(), *left = parent + nb, *right = left + nb, *nl = right + nb, *dep = nl + nb, *tin = dep + nb,
+         *first = tin + nb, *lo = first + nb, *up = lo + nlo;
+    size_t nleaves = 0;
+    for (size_t i = 0; i < order.size(); i++)
+    {
+        const int32_t v = order[i];
+        tin[v] = (IdxT)i;
+        first[v] = (IdxT)nleaves;
+        if (t.left[v] < 0)
+            lo[nleaves++] = (IdxT)v;
+    }
+    for (size_t v = 0; v < nb; v++)
+    {
+        parent[v] = (IdxT)((int32_t)v == t.root ? t.root : t.parent[v]);
+        left[v] = (IdxT)(t.left[v] < 0 ? 0 : t.left[v]);
+        right[v] = (IdxT)(t.right[v] < 0 ? 0 : t.right[v]);
+        nl[v] = (IdxT)nleaf[v];
+        dep[v] = (IdxT)depth[v];
+        up[v] = parent[v];
+    }
+    for (int32_t k = 1; k < K; k++)
+        for (size_t v = 0; v < nb; v++)
+            up[(size_t)k * nb + v] = up[(size_t)(k - 1) * nb + (size_t)up[(size_t)(k - 1) * nb + v]];
+}
+
 int sync_device_topology(lvbgpu_ctx *ctx)
 {
     if (ctx->d_topo_version == ctx->topo_version)
         return LVBGPU_OK;
     const int32_t nb = ctx->nb;
     const Topology &t = ctx->topo;
-    std::vector<int32_t> host((size_t)4 * nb);
-    memcpy(host.data(), t.parent.data(), (size_t)nb * 4);
-    memcpy(host.data() + nb, t.left.data(), (size_t)nb * 4);
-    memcpy(host.data() + 2 * (size_t)nb, t.right.data(), (size_t)nb * 4);
-    int32_t *leaves = host.data() + 3 * (size_t)nb;
-    // leaves below each node: children before parents via an explicit preorder
+    // preorder from the root leaf; children before parents when read backwards
     std::vector<int32_t> order;
     order.reserve(nb);
+    std::vector<int32_t> depth((size_t)nb, 0), nleaf((size_t)nb, 1);
     std::vector<int32_t> st{t.root};
+    int32_t maxdepth = 1;
     while (!st.empty())
     {
         const int32_t v = st.back();
@@ -28,18 +57,42 @@ int sync_device_topology(lvbgpu_ctx *ctx)
         order.push_back(v);
         if (t.left[v] >= 0)
         {
-            st.push_back(t.left[v]);
+            depth[t.left[v]] = depth[t.right[v]] = depth[v] + 1;
+            maxdepth = std::max(maxdepth, depth[v] + 1);
             st.push_back(t.right[v]);
+            st.push_back(t.left[v]);
         }
     }
     for (auto it = order.rbegin(); it != order.rend(); ++it)
+        if (t.left[*it] >= 0)
+            nleaf[*it] = nleaf[t.left[*it]] + nleaf[t.right[*it]];
+    int32_t K = 1;
+    while ((1 << K) <= maxdepth)
+        K++;
+    size_t bytes;
+    const void *src;
+    if (nb <= 65535)
     {
-        const int32_t v = *it;
-        leaves[v] = (t.left[v] < 0 || v == t.root) ? 1 : leaves[t.left[v]] + leaves[t.right[v]];
+        fill_tables<uint16_t>(t, K, order, depth, nleaf, ctx->gen_tab16);
+        bytes = ctx->gen_tab16.size() * 2;
+        src = ctx->gen_tab16.data();
+        ctx->gen_idx_bytes = 2;
     }
-    HIPCHK(ctx, ctx->d_topo4.reserve(host.size() * 4));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_topo4.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // `host` goes out of scope
+    else
+    {
+        fill_tables<int32_t>(t, K, order, depth, nleaf, ctx->gen_tab32);
+        bytes = ctx->gen_tab32.size() * 4;
+        src = ctx->gen_tab32.data();
+        ctx->gen_idx_bytes = 4;
+    }
+    bytes &= ~(size_t)15; // whole 16-byte pieces (the arrays end 8 elements before the vector does)
+    HIPCHK(ctx, ctx->d_topo4.reserve(bytes));
+    HIPCHK(ctx, ctx->h_topo.reserve(bytes));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // an upload still reading the staging buffer
+    memcpy(ctx->h_topo.p, src, bytes);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_topo4.p, ctx->h_topo.p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->gen_table_bytes = (uint32_t)bytes;
+    ctx->gen_K = K;
     ctx->d_topo_version = ctx->topo_version;
     return LVBGPU_OK;
 }
@@ -180,42 +233,50 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
             d_moves = (const lvbgpu_move_dev *)ctx->d_moves.p;
         }
     }
-    // the generator keeps its root-ward paths in LDS; when LDS is too small for the deepest possible path and a
-    // candidate does overflow, the batch is generated once more with the paths in scratch memory
-    for (int attempt = 0; attempt < 2; attempt++)
+    GenArgs ga{};
+    ga.tables = ctx->d_topo4.p;
+    ga.table_bytes = ctx->gen_table_bytes;
+    ga.idx_bytes = ctx->gen_idx_bytes;
+    ga.n = (int32_t)ctx->n;
+    ga.nb = ctx->nb;
+    ga.root = ctx->topo.root;
+    ga.K = ctx->gen_K;
+    ga.leaf_order_len = (uint32_t)ctx->n;
+    ga.kind_all = kind;
+    ga.mix_a = mix_a;
+    ga.mix_b = mix_b;
+    ga.seed = seed;
+    ga.B = (uint32_t)B;
+    ga.stride_t = stride_t;
+    ga.stride_e = stride_e;
+    ga.toks = (uint32_t *)((char *)bt->d_prog.p + o_t);
+    ga.dsts = (int32_t *)((char *)bt->d_prog.p + o_d);
+    ga.edits = (lvbgpu_edit_dev *)ctx->d_pedits.p;
+    ga.cands = (CandDesc *)bt->d_prog.p;
+    ga.info = (ProposalInfo *)ctx->d_pinfo.p;
+    ga.len_out = (unsigned long long *)bt->d_len.p;
+    ga.moves = d_moves;
+    HIPCHK(ctx, launch_propose(ga, ctx->stream));
+    bt->len_zeroed = true; // by the generator
+    rc = lvbgpu_batch_launch(ctx, bt);
+    if (rc != LVBGPU_OK)
+        return rc;
+    // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
+    // when) the caller wants that candidate (lvbgpu_proposal_edits)
+    HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, wait_for_step(ctx, B));
+    const int64_t *len = (const int64_t *)bt->h_len.p;
+    for (int32_t b = 0; b < B; b++)
     {
-        bool paths_capped = false;
-        HIPCHK(ctx, launch_propose((const int32_t *)ctx->d_topo4.p, (int32_t)ctx->n, ctx->topo.root, kind, mix_a, mix_b, seed,
-                                   (uint32_t)B, stride_t, stride_e, (uint32_t *)((char *)bt->d_prog.p + o_t),
-                                   (int32_t *)((char *)bt->d_prog.p + o_d), (lvbgpu_edit_dev *)ctx->d_pedits.p,
-                                   (CandDesc *)bt->d_prog.p, (ProposalInfo *)ctx->d_pinfo.p, d_moves, attempt > 0,
-                                   &paths_capped, ctx->stream));
-        rc = lvbgpu_batch_launch(ctx, bt);
-        if (rc != LVBGPU_OK)
-            return rc;
-        // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
-        // when) the caller wants that candidate (lvbgpu_proposal_edits)
-        HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, wait_for_step(ctx, B));
-        HIPCHK(ctx, hipMemsetAsync(bt->d_len.p, 0, bt->d_len.cap, ctx->stream)); // for the next step, off its critical path
-        bt->len_zeroed = true;
-        const int64_t *len = (const int64_t *)bt->h_len.p;
-        bool overflowed = false;
-        for (int32_t b = 0; b < B; b++)
+        if (len[b] >= PROPOSAL_OVERFLOW_LENGTH)
         {
-            if (len[b] >= PROPOSAL_OVERFLOW_LENGTH)
-            {
-                lengths_out[b] = INT64_MAX;
-                overflowed = true;
-                continue;
-            }
-            lengths_out[b] = len[b];
-            if (len[b] <= 0)
-                return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (device-built candidate " + std::to_string(b) +
-                                                       " of " + std::to_string(B) + " scored " + std::to_string(len[b]) + ")");
+            lengths_out[b] = INT64_MAX;
+            continue;
         }
-        if (!(overflowed && paths_capped))
-            break;
+        lengths_out[b] = len[b];
+        if (len[b] <= 0)
+            return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (device-built candidate " + std::to_string(b) +
+                                                   " of " + std::to_string(B) + " scored " + std::to_string(len[b]) + ")");
     }
     ctx->p_B = B;
     return LVBGPU_OK;

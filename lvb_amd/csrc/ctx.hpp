@@ -164,8 +164,12 @@ struct lvbgpu_ctx
     lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
     // device-side proposals (lvbgpu_propose_score)
     lvbgpu_batch *prop_batch = nullptr;
-    DevBuf d_topo4, d_pedits, d_pinfo;
-    PinBuf h_pinfo;
+    DevBuf d_topo4, d_pedits, d_pinfo; // d_topo4: the generator's tables of the resident topology (GenArgs)
+    PinBuf h_pinfo, h_topo;
+    std::vector<uint16_t> gen_tab16;
+    std::vector<int32_t> gen_tab32;
+    uint32_t gen_table_bytes = 0, gen_idx_bytes = 2;
+    int32_t gen_K = 1;
     DevBuf d_moves; // moves named by the host (lvbgpu_score_moves)
     PinBuf h_moves;
     uint64_t d_topo_version = ~0ull;
@@ -197,6 +201,8 @@ struct lvbgpu_ctx
     // lvbgpu_walk_timing: HIP events around every scoring walk, on the stream it is launched on
     static constexpr int WT_RING = 32;
     bool walk_timing = false;
+    uint32_t wt_every = 1;  // every wt_every-th walk is timed (events between launches cost ~10 us each)
+    uint64_t wt_seen = 0;
     hipEvent_t wt_ev[2 * WT_RING] = {};
     int wt_pending = 0;
     double wt_ms = 0.0;

@@ -109,12 +109,34 @@ struct ProposalInfo
     int32_t overflow; // the move did not fit the fixed strides: its length is meaningless, never accept it
     int32_t ncomb;    // combines of its program (D + 2)
 };
-// topo4 = [parent | left | right | leaves-below] each 2n-3 int32
-hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
-                          uint64_t seed, uint32_t B,
-                          uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves, bool scratch_paths,
-                          bool *paths_capped, hipStream_t stream);
+// What the generator reads of one topology: one blob of IdxT (uint16_t while 2n-3 <= 65535, else int32_t)
+//   parent[nb] left[nb] right[nb] nleaf[nb] depth[nb] tin[nb] first_leaf[nb] leaf_order[leaf_order_len] up[K][nb]
+// nleaf = leaves below (1 for a leaf); depth = edges to the root leaf (0 for it); tin = preorder number (root 0,
+// a subtree is the interval [tin, tin + 2 nleaf - 1)); leaf_order = the non-root leaves in preorder and
+// first_leaf[v] the position of v's first one; up[k][v] = the 2^k-th ancestor of v, the root beyond it.
+// Built by the host when the resident topology changes (api_propose.cpp), padded to 16 bytes.
+constexpr uint32_t GEN_WAVES = 4;
+constexpr uint32_t GEN_THREADS = 64 * GEN_WAVES;
+struct GenArgs
+{
+    const void *tables;
+    uint32_t table_bytes, idx_bytes;
+    int32_t n, nb, root, K;
+    uint32_t leaf_order_len;
+    int32_t kind_all;
+    uint32_t mix_a, mix_b;
+    uint64_t seed;
+    uint32_t B, stride_t, stride_e;
+    uint32_t *toks;
+    int32_t *dsts;
+    lvbgpu_edit_dev *edits;
+    CandDesc *cands;
+    ProposalInfo *info;
+    unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
+    const lvbgpu_move_dev *moves;
+    int32_t use_lds; // filled by launch_propose
+};
+hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
 
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();

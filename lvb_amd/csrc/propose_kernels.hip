@@ -2,17 +2,30 @@
 // device (SURVEY.md 8f "next" row 1: once scoring is fast, building candidates on the host and
 // shipping them over PCIe is the limiter).
 //
-// One thread = one candidate.  It draws a move with the reference's rules
+// One WAVEFRONT = one candidate.  The wave draws a move with the reference's rules
 //   mutate_nni TreeOperations.c:160-209, mutate_spr :236-335, mutate_tbr :337-541
-// (same eligibility/rejection loops, same re-use of the pruned parent as graft node; the random
-// stream is a counter-based splitmix64, not the reference's generator), and writes
+// (same admissible sets, uniform over them as the reference's rejection loops are, same re-use of the
+// pruned parent as graft node; the random stream is a counter-based splitmix64, not the reference's
+// generator), and writes
 //   - the move as child-pair rewrites (edits) - what the host applies if the candidate is accepted,
 //   - the token program fitch_walk will run (program.hpp's format), and its CandDesc.
 //
-// The dirty set of any of these moves is a union of at most two root-ward paths in the NEW
-// topology (the reference's make_dirty_below calls), so the program is one or two chains, one
-// merge, and the common path to the root; no general postorder is needed here (the general builder
-// stays on the host: program.cpp).
+// Why a wave and not a thread.  The dirty set of these moves is a union of at most two root-ward paths
+// in the NEW topology (the reference's make_dirty_below calls), so the program is one or two chains,
+// one merge, and the common path to the root.  A thread walking those paths is ~5000 dependent
+// instructions (46 us for any batch size, and milliseconds on a tree whose top is a caterpillar: the
+// "is dest inside the pruned subtree" test walked to the root for every rejected draw).  Here nothing
+// is walked.  With the topology the host uploads, per node, its depth, its preorder number, the leaves
+// below it and its 2^k-th ancestors (binary lifting); then
+//   * "v lies in the subtree of a" is one interval test on preorder numbers,
+//   * the node at position j of a root-ward path is the j-th ancestor: lane j computes it in <= K table
+//     reads, all positions at once,
+//   * the clean sibling that position feeds on is "the child of that node whose subtree does not
+//     hold the path's start": another interval test,
+//   * rejection sampling draws 64 candidates at a time, one per lane, and takes the first admissible
+//     one in draw order (a ballot),
+// so a program is a handful of wave-wide pieces, and tokens, destinations and rewrites leave as coalesced
+// stores.  The tables live in LDS (copied once per workgroup, ~32 KB at 500 taxa).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,568 +39,552 @@ namespace lvbgpu
 namespace
 {
 
+// counter-based random numbers: draw `idx` of stream `stream` of candidate `key` (splitmix64 finaliser)
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 struct DevRng
 {
-    uint64_t s;
-    __device__ uint64_t next()
+    uint64_t key;
+    __device__ uint64_t draw(uint32_t stream, uint32_t idx) const
     {
-        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
+        return mix64(key + 0x9E3779B97F4A7C15ull * ((uint64_t)stream << 32 | (uint64_t)(idx + 1u)));
     }
-    __device__ uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+    // uniform integer in [0, n)
+    __device__ uint32_t below(uint32_t stream, uint32_t idx, uint32_t n) const
+    {
+        return (uint32_t)(((draw(stream, idx) >> 32) * (uint64_t)n) >> 32);
+    }
 };
 
-// the emitting side of one candidate
-struct Emit
+// the tables of one topology (GenTables in kernels.hpp gives the layout), in LDS or in global memory
+template <typename IdxT>
+struct Tab
+{
+    const IdxT *parent, *left, *right, *nleaf, *depth, *tin, *first_leaf, *leaf_order, *up;
+    int32_t n, nb, root, K;
+
+    __device__ int32_t par(int32_t v) const { return (int32_t)parent[v]; }
+    __device__ int32_t dep(int32_t v) const { return (int32_t)depth[v]; }
+    // v in the subtree of a (a itself included); a is not the root
+    __device__ bool inside(int32_t v, int32_t a) const
+    {
+        return (uint32_t)tin[v] - (uint32_t)tin[a] < 2u * (uint32_t)nleaf[a] - 1u;
+    }
+    __device__ int32_t other(int32_t v, int32_t c) const
+    {
+        const int32_t l = (int32_t)left[v];
+        return l == c ? (int32_t)right[v] : l;
+    }
+    __device__ int32_t sister(int32_t v) const { return other(par(v), v); }
+    // the child of v whose subtree does NOT hold y (y lies strictly below v)
+    __device__ int32_t away(int32_t v, int32_t y) const
+    {
+        const int32_t l = (int32_t)left[v];
+        return inside(y, l) ? (int32_t)right[v] : l;
+    }
+    // the child of v whose subtree holds y
+    __device__ int32_t toward(int32_t v, int32_t y) const
+    {
+        const int32_t l = (int32_t)left[v];
+        return inside(y, l) ? l : (int32_t)right[v];
+    }
+    // k-th ancestor (saturates at the root)
+    __device__ int32_t anc(int32_t v, uint32_t k) const
+    {
+        for (int32_t i = 0; k != 0u && i < K; i++, k >>= 1)
+            if (k & 1u)
+                v = (int32_t)up[(size_t)i * nb + v];
+        return k != 0u ? root : v;
+    }
+    // lowest common ancestor of two nodes below the root (may be the root)
+    __device__ int32_t lca(int32_t a, int32_t b) const
+    {
+        int32_t da = dep(a), db = dep(b);
+        if (da < db)
+        {
+            const int32_t s = a;
+            a = b;
+            b = s;
+            const int32_t sd = da;
+            da = db;
+            db = sd;
+        }
+        a = anc(a, (uint32_t)(da - db));
+        if (a == b)
+            return a;
+        for (int32_t i = K - 1; i >= 0; i--)
+        {
+            const int32_t ua = (int32_t)up[(size_t)i * nb + a], ub = (int32_t)up[(size_t)i * nb + b];
+            if (ua != ub)
+            {
+                a = ua;
+                b = ub;
+            }
+        }
+        return par(a);
+    }
+};
+
+struct GenOut
 {
     uint32_t *toks;
     int32_t *dsts;
     lvbgpu_edit_dev *edits;
-    uint32_t ntok = 0, ndst = 0, nedit = 0, nfresh = 0, cap_t, cap_e;
-    bool overflow = false;
+    uint32_t ntok, ndst, nedit, nfresh, cap_e;
+};
 
-    __device__ void tok(int32_t row, uint32_t flags)
+template <typename IdxT>
+struct Gen
+{
+    const Tab<IdxT> &t;
+    GenOut o;
+    uint32_t lane;
+
+    // ---- pieces of a program (all arguments wave-uniform)
+    // chain head with two clean children
+    __device__ void head2(int32_t row_a, uint32_t flags_a, int32_t row_b, int32_t dst, bool merge_after)
     {
-        if (ntok < cap_t)
-            toks[ntok] = (uint32_t)row | flags;
-        else
-            overflow = true;
-        ntok++;
-        if (flags & TOK_FRESH)
-            nfresh++;
+        if (lane == 0)
+        {
+            o.toks[o.ntok] = (uint32_t)row_a | TOK_FRESH | flags_a;
+            o.toks[o.ntok + 1] = (uint32_t)row_b | (merge_after ? 1u << TOK_MERGE_SHIFT : 0u);
+            o.dsts[o.ndst] = dst;
+        }
+        o.ntok += 2;
+        o.ndst += 1;
+        o.nfresh += 1;
     }
-    __device__ void dst(int32_t d)
+    // one node fed by the running set and one clean row
+    __device__ void one(int32_t row, int32_t dst, bool merge_after = false)
     {
-        if (ndst < cap_t)
-            dsts[ndst] = d;
-        else
-            overflow = true;
-        ndst++;
+        if (lane == 0)
+        {
+            o.toks[o.ntok] = (uint32_t)row | (merge_after ? 1u << TOK_MERGE_SHIFT : 0u);
+            o.dsts[o.ndst] = dst;
+        }
+        o.ntok += 1;
+        o.ndst += 1;
     }
-    __device__ void merge(int32_t d)
+    // the destination of a merge (its count rides on the token emitted just before: merge_after / merge_last)
+    __device__ void merge_dst(int32_t dst)
     {
-        if (ntok > 0 && ntok <= cap_t)
-            toks[ntok - 1] += 1u << TOK_MERGE_SHIFT;
-        dst(d);
+        if (lane == 0)
+            o.dsts[o.ndst] = dst;
+        o.ndst += 1;
+    }
+    // `count` consecutive nodes of the OLD root-ward path of y, from its j0-th ancestor on, each fed by the
+    // running set from below and by its clean child: the one given for position 0 of the path (row0, y's own
+    // clean child in the new topology), otherwise the child that does not hold y - where a child that is the
+    // pruned parent's old place (fix_from) now holds its sister (fix_to).  Lane-parallel, 64 nodes per trip.
+    __device__ void run(int32_t y, uint32_t j0, uint32_t count, int32_t row0, int32_t fix_from, int32_t fix_to, bool merge_last)
+    {
+        for (uint32_t base = 0; base < count; base += 64u)
+        {
+            const uint32_t idx = base + lane;
+            if (idx < count)
+            {
+                const uint32_t j = j0 + idx;
+                const int32_t v = t.anc(y, j);
+                int32_t row = j == 0u ? row0 : t.away(v, y);
+                if (row == fix_from)
+                    row = fix_to;
+                o.toks[o.ntok + idx] = (uint32_t)row | ((merge_last && idx == count - 1u) ? 1u << TOK_MERGE_SHIFT : 0u);
+                o.dsts[o.ndst + idx] = v;
+            }
+        }
+        o.ntok += count;
+        o.ndst += count;
     }
     __device__ void edit(int32_t node, int32_t l, int32_t r)
     {
-        if (nedit < cap_e)
-            edits[nedit] = {node, l, r};
-        else
-            overflow = true;
-        nedit++;
+        if (lane == 0 && o.nedit < o.cap_e)
+            o.edits[o.nedit] = {node, l, r};
+        o.nedit += 1;
     }
-};
-
-struct Topo
-{
-    const int32_t *parent, *left, *right, *leaves;
-    int32_t n, nb, root;
-    __device__ int32_t sister(int32_t v) const
+    // the root's two combines: its clean child (new topology), then the root leaf's own row
+    __device__ void finish(int32_t root_clean_child)
     {
-        const int32_t p = parent[v];
-        return left[p] == v ? right[p] : left[p];
+        if (root_clean_child >= 0)
+            one(root_clean_child, -1);
+        one(t.root, -1);
     }
 };
-
-// children of v in the topology after an SPR-shaped move: pp lost sp for ss, dp lost dest for sp,
-// sp holds (dest, top)
-struct SprView
-{
-    const Topo &t;
-    int32_t sp, ss, pp, dp, dest, top;
-    __device__ void children(int32_t v, int32_t &l, int32_t &r) const
-    {
-        if (v == sp)
-        {
-            l = dest;
-            r = top;
-            return;
-        }
-        l = t.left[v];
-        r = t.right[v];
-        if (v == pp)
-        {
-            if (l == sp)
-                l = ss;
-            else
-                r = ss;
-        }
-        if (v == dp)
-        {
-            if (l == dest)
-                l = sp;
-            else if (r == dest)
-                r = sp;
-        }
-    }
-    __device__ int32_t parent(int32_t v) const
-    {
-        if (v == sp)
-            return dp;
-        if (v == ss)
-            return pp;
-        if (v == dest || v == top)
-            return sp;
-        return t.parent[v];
-    }
-    __device__ int32_t other_child(int32_t v, int32_t d) const
-    {
-        int32_t l, r;
-        children(v, l, r);
-        return l == d ? r : l;
-    }
-};
-
-constexpr int MAX_PATH = 768; // nodes of one root-ward path kept per thread; longer -> overflow flag
-
-// One root-ward path of a thread.  In LDS (16-bit node numbers, element i of thread t at [i * 64 + t]: conflict-free)
-// when the block's LDS holds it next to the topology, else in thread-private scratch memory, where every access is
-// a trip to the cache hierarchy - the generator is a chain of dependent accesses and nothing else.
-template <bool IN_LDS>
-struct PathStore;
-template <>
-struct PathStore<true>
-{
-    uint16_t *p;
-    int cap;
-    __device__ int32_t get(int i) const { return (int32_t)p[(size_t)i * 64u]; }
-    __device__ void set(int i, int32_t v) { p[(size_t)i * 64u] = (uint16_t)v; }
-};
-template <>
-struct PathStore<false>
-{
-    int32_t buf[MAX_PATH];
-    static constexpr int cap = MAX_PATH;
-    __device__ int32_t get(int i) const { return buf[i]; }
-    __device__ void set(int i, int32_t v) { buf[i] = v; }
-};
-
-} // namespace
 
 // kind_all: 0 NNI, 1 SPR, 2 TBR; -1: candidate b gets kind b % 3; -2: NNI/SPR alternate by the
 // parity of (mix_a + b) (reference -a 0, Solve.c:288-297); -3: drawn per candidate, NNI below
 // threshold mix_a, SPR below mix_b, else TBR, both scaled to 2^32 (reference -a 1, Solve.c:262-283)
-template <bool LDS_PATHS>
-__global__ void propose_kernel(const int32_t *parent, const int32_t *left, const int32_t *right, const int32_t *leaves,
-                               int32_t n, int32_t root, int32_t kind_all, uint32_t mix_a, uint32_t mix_b,
-                               uint64_t seed, uint32_t B, uint32_t stride_t,
-                               uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                               CandDesc *cands, ProposalInfo *info, int32_t use_lds, const lvbgpu_move_dev *moves,
-                               int32_t path_cap)
+template <typename IdxT>
+__device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const uint32_t b, const uint32_t lane)
 {
-    // The walk below is pointer chasing (two root-ward paths, a random descent for TBR): from global
-    // memory every step is an L2 round trip.  When the four arrays fit, the block first copies them
-    // into LDS (coalesced) and chases there.
-    extern __shared__ __attribute__((aligned(16))) int32_t lds_topo[];
-    const int32_t nb_all = 2 * n - 3;
-    if (use_lds)
-    {
-        // parent | left | right | leaves are contiguous and 16-byte aligned (launch_propose): 4 * nb ints = nb
-        // 16-byte pieces.  Eight loads in flight per thread: one wave copies 16 KB, and a loop of single dwords
-        // (62 dependent-looking round trips) was most of this kernel's time on small batches.
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(parent);
-        uint4 *dst4 = reinterpret_cast<uint4 *>(lds_topo);
-        for (int32_t i0 = 0; i0 < nb_all; i0 += 8 * (int32_t)blockDim.x)
-        {
-            uint4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-            {
-                const int32_t i = i0 + u * (int32_t)blockDim.x + (int32_t)threadIdx.x;
-                if (i < nb_all)
-                    v[u] = src4[i];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-            {
-                const int32_t i = i0 + u * (int32_t)blockDim.x + (int32_t)threadIdx.x;
-                if (i < nb_all)
-                    dst4[i] = v[u];
-            }
-        }
-        __syncthreads();
-        parent = lds_topo;
-        left = lds_topo + nb_all;
-        right = lds_topo + 2 * nb_all;
-        leaves = lds_topo + 3 * nb_all;
-    }
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B)
-        return;
-    const Topo t{parent, left, right, leaves, n, 2 * n - 3, root};
-    DevRng rng{seed ^ ((uint64_t)(b + 1) * 0xD1B54A32D192ED03ull)};
-    Emit e;
-    e.toks = toks + (size_t)b * stride_t;
-    e.dsts = dsts + (size_t)b * stride_t;
-    e.edits = edits + (size_t)b * stride_e;
-    e.cap_t = stride_t;
-    e.cap_e = stride_e;
-    int32_t kind = kind_all;
-    if (kind_all == -1)
+    const int32_t n = t.n, nb = t.nb, root = t.root;
+    const DevRng rng{g.seed ^ ((uint64_t)(b + 1u) * 0xD1B54A32D192ED03ull)};
+    Gen<IdxT> e{t, GenOut{g.toks + (size_t)b * g.stride_t, g.dsts + (size_t)b * g.stride_t, g.edits + (size_t)b * g.stride_e, 0, 0,
+                          0, 0, g.stride_e},
+                lane};
+    int32_t kind = g.kind_all;
+    if (g.kind_all == -1)
         kind = (int32_t)(b % 3u);
-    else if (kind_all == -2)
-        kind = ((mix_a + b) & 1u) ? 1 : 0;
-    else if (kind_all == -3)
+    else if (g.kind_all == -2)
+        kind = ((g.mix_a + b) & 1u) ? 1 : 0;
+    else if (g.kind_all == -3)
     {
-        const uint32_t r = (uint32_t)(rng.next() >> 32);
-        kind = r < mix_a ? 0 : (r < mix_b ? 1 : 2);
+        const uint32_t r = (uint32_t)(rng.draw(0, 0) >> 32);
+        kind = r < g.mix_a ? 0 : (r < g.mix_b ? 1 : 2);
     }
     // moves != nullptr: nothing is drawn, candidate b IS moves[b] (validated by the host side of
     // lvbgpu_score_moves); everything after the draws is shared
     lvbgpu_move_dev given{0, -1, -1, -1};
-    if (moves)
+    if (g.moves)
     {
-        given = moves[b];
+        given = g.moves[b];
         kind = given.kind;
     }
     ProposalInfo pi{kind, -1, -1, -1, 0, 0, 0, 0};
-
-    int32_t last = -1; // top node of the chain that reaches the root
+    bool unusable = false;
 
     if (kind == 0)
     {
         // ---- NNI: u any internal node, v its parent, swap one child of u with u's sister
-        const int32_t u = moves ? given.a : n + (int32_t)rng.below((uint32_t)(t.nb - n));
-        const bool swap_right = moves ? given.b != 0 : (rng.next() >> 63) != 0;
-        const int32_t v = t.parent[u], a = t.left[u], bb = t.right[u], c = t.sister(u);
+        const int32_t u = g.moves ? given.a : n + (int32_t)rng.below(1, 0, (uint32_t)(nb - n));
+        const bool swap_right = g.moves ? given.b != 0 : (rng.draw(1, 1) >> 63) != 0;
+        const int32_t v = t.par(u), a = (int32_t)t.left[u], bb = (int32_t)t.right[u], c = t.sister(u);
         const int32_t keep = swap_right ? a : bb, moved = swap_right ? bb : a;
         pi.a = u;
         pi.flag = swap_right ? 1 : 0;
-        // edits: v trades c for `moved`, u holds (keep, c)
-        e.edit(v, t.left[v] == c ? moved : t.left[v], t.left[v] == c ? t.right[v] : moved);
-        e.edit(u, keep, c);
+        // edits: v trades c for `moved` (same side), u holds (keep, c)
+        {
+            const int32_t vl = (int32_t)t.left[v], vr = (int32_t)t.right[v];
+            e.edit(v, vl == c ? moved : vl, vl == c ? vr : moved);
+            e.edit(u, keep, c);
+        }
         // chain: u (keep, c), then v with `moved` as its clean child, then the old path above v
-        e.tok(keep, TOK_FRESH);
-        e.tok(c, 0);
-        e.dst(u);
-        last = u;
+        e.head2(keep, 0u, c, u, false);
         if (v != root)
         {
-            e.tok(moved, 0);
-            e.dst(v);
-            last = v;
-            for (int32_t w = t.parent[v]; w != root; w = t.parent[w])
-            {
-                e.tok(t.left[w] == last ? t.right[w] : t.left[w], 0);
-                e.dst(w);
-                last = w;
-            }
-            e.tok(t.left[root] == last ? t.right[root] : t.left[root], 0);
+            const uint32_t dv = (uint32_t)t.dep(v);
+            e.run(v, 0u, dv, moved, -1, -1, false);
+            e.finish(t.away(root, v));
         }
         else
-            e.tok(moved, 0); // the root's other child is now `moved`
-        e.dst(-1);
-        e.tok(root, 0);
-        e.dst(-1);
+            e.finish(moved); // the root's other child is now `moved`
     }
     else
     {
         // ---- SPR / TBR: prune src (with its parent sp), graft on the edge above dest
-        // every draw loop is bounded: a tree with no admissible move must not hang the GPU
         int32_t src = given.a, dest = given.b;
-        int tries = 0;
-        if (!moves)
+        if (!g.moves)
         {
-            do
-                src = (int32_t)rng.below((uint32_t)t.nb);
-            while ((src == root || src == t.left[root] || src == t.right[root]) && ++tries < 4096);
-            if (tries >= 4096)
+            // src: any node but the root and its two children (TreeOperations.c:256-259)
+            const int32_t r1 = (int32_t)t.left[root], r2 = (int32_t)t.right[root];
+            src = -1;
+            for (uint32_t round = 0; round < 16u && src < 0; round++)
             {
-                e.overflow = true;
-                src = t.left[t.left[root] >= n ? t.left[root] : t.right[root]];
+                const int32_t cand = (int32_t)rng.below(2, round * 64u + lane, (uint32_t)nb);
+                const uint64_t ok = __builtin_amdgcn_ballot_w64(cand != root && cand != r1 && cand != r2);
+                if (ok)
+                    src = __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(ok));
             }
         }
-        const int32_t sp = t.parent[src], ss = t.sister(src), pp = t.parent[sp];
-        for (tries = moves ? 65536 : 0; tries < 65536; tries++)
+        int32_t sp = -1, ss = -1, pp = -1;
+        if (src >= 0)
         {
-            dest = (int32_t)rng.below((uint32_t)t.nb);
-            if (dest == src || dest == sp || dest == ss || dest == root)
-                continue;
-            bool below = false; // dest inside src's subtree?
-            for (int32_t p = t.parent[dest]; p != UNSET; p = t.parent[p])
-                if (p == src)
-                {
-                    below = true;
-                    break;
-                }
-            if (!below)
-                break;
+            sp = t.par(src);
+            ss = t.other(sp, src);
+            pp = t.par(sp);
         }
-        if (!moves && tries >= 65536)
+        if (!g.moves && src >= 0)
         {
-            // no admissible destination found: emit nothing usable
-            CandDesc none{};
-            none.tok_off = b * stride_t;
-            none.dst_off = b * stride_t;
-            none.base = PROPOSAL_OVERFLOW_LENGTH;
-            cands[b] = none;
-            pi.overflow = 1;
-            info[b] = pi;
-            return;
+            // dest: any node but src, its parent, its sister, the root, and src's own subtree (268-271 and the
+            // descendant test); 64 draws per round, the first admissible one in draw order wins
+            dest = -1;
+            for (uint32_t round = 0; round < 1024u && dest < 0; round++)
+            {
+                const int32_t cand = (int32_t)rng.below(3, round * 64u + lane, (uint32_t)nb);
+                const bool good = cand != sp && cand != ss && cand != root && !t.inside(cand, src);
+                const uint64_t ok = __builtin_amdgcn_ballot_w64(good);
+                if (ok)
+                    dest = __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(ok));
+            }
         }
-        const int32_t dp = t.parent[dest];
-        pi.a = src;
-        pi.b = dest;
+        if (src < 0 || dest < 0)
+            unusable = true; // no admissible move found: emit nothing usable
+        else
+        {
+            const int32_t dp = t.par(dest);
+            pi.a = src;
+            pi.b = dest;
 
-        PathStore<LDS_PATHS> buf1, buf2; // root-ward paths
-        if constexpr (LDS_PATHS)
-        {
-            // behind the topology copy: [2][path_cap][64 threads] node numbers
-            uint16_t *paths = reinterpret_cast<uint16_t *>(lds_topo + 4 * nb_all);
-            buf1.p = paths + threadIdx.x;
-            buf1.cap = path_cap;
-            buf2.p = paths + (size_t)path_cap * 64u + threadIdx.x;
-            buf2.cap = path_cap;
-        }
-        const int cap = buf1.cap;
-        int32_t top = src;   // what hangs under sp next to dest
-        bool have_acc = false; // a chain inside the moved subtree already feeds sp
-        if (kind == 2 && t.leaves[src] > 2 && !(moves && given.c < 0))
-        {
-            // TBR: re-root the moved subtree on the edge above a random leaf x (not a child of src)
-            int32_t x = given.c;
-            int xt = 0;
-            if (!moves)
+            int32_t top = src;     // what hangs under sp next to dest
+            bool have_acc = false; // a chain inside the moved subtree already feeds sp
+            if (kind == 2 && (int32_t)t.nleaf[src] > 2 && !(g.moves && given.c < 0))
             {
-                do
+                // TBR: re-root the moved subtree on the edge above a random leaf x (not a child of src)
+                int32_t x = given.c;
+                if (!g.moves)
                 {
-                    x = src;
-                    while (t.left[x] >= 0)
+                    const int32_t c1 = (int32_t)t.left[src], c2 = (int32_t)t.right[src];
+                    const uint32_t first = (uint32_t)t.first_leaf[src], cnt = (uint32_t)t.nleaf[src];
+                    x = -1;
+                    for (uint32_t round = 0; round < 64u && x < 0; round++)
                     {
-                        const int32_t l = t.left[x];
-                        x = rng.below((uint32_t)t.leaves[x]) < (uint32_t)t.leaves[l] ? l : t.right[x];
+                        const int32_t cand = (int32_t)t.leaf_order[first + rng.below(4, round * 64u + lane, cnt)];
+                        const uint64_t ok = __builtin_amdgcn_ballot_w64(cand != c1 && cand != c2);
+                        if (ok)
+                            x = __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(ok));
                     }
-                } while ((x == t.left[src] || x == t.right[src]) && ++xt < 4096);
+                }
+                if (x < 0)
+                    unusable = true;
+                else
+                {
+                    pi.c = x;
+                    // path P0 = parent(x) .. Pk = src (P_i = the (i+1)-th ancestor of x); k >= 1
+                    const uint32_t k = (uint32_t)(t.dep(x) - t.dep(src)) - 1u;
+                    const int32_t p0 = t.par(x), sis_x = t.other(p0, x);
+                    const int32_t below_src = t.toward(src, x); // P(k-1)
+                    const int32_t displaced_k = k == 1u ? sis_x : t.away(below_src, x);
+                    // rewrites: P0 = (P1, x); P_i = (P_(i+1), displaced_i), displaced_1 = sister(x), displaced_i = the
+                    // child of P_(i-1) off the path; src trades P(k-1) for the last displaced one (same side)
+                    if (lane == 0 && e.o.nedit < e.o.cap_e)
+                        e.o.edits[e.o.nedit] = {p0, t.par(p0), x};
+                    for (uint32_t base = 1; base < k; base += 64u)
+                    {
+                        const uint32_t i = base + lane;
+                        if (i < k && e.o.nedit + i < e.o.cap_e)
+                        {
+                            const int32_t node = t.anc(x, i + 1u);
+                            const int32_t disp = i == 1u ? sis_x : t.away(t.toward(node, x) /* P(i-1) */, x);
+                            e.o.edits[e.o.nedit + i] = {node, t.par(node), disp};
+                        }
+                    }
+                    e.o.nedit += k;
+                    {
+                        const int32_t l = (int32_t)t.left[src], r = (int32_t)t.right[src];
+                        e.edit(src, l == below_src ? displaced_k : l, l == below_src ? r : displaced_k);
+                        // chain bottom: src's two (clean) children in the new topology
+                        e.head2(l == below_src ? r : l, 0u, displaced_k, src, false);
+                    }
+                    // upwards in the NEW subtree: P(k-1) .. P1, each fed by the sister displaced from the node below it
+                    for (uint32_t base = 0; base + 1u < k; base += 64u)
+                    {
+                        const uint32_t q = base + lane;
+                        if (q + 1u < k)
+                        {
+                            const uint32_t i = k - 1u - q; // P_i, i = k-1 .. 1
+                            const int32_t node = t.anc(x, i + 1u);
+                            const int32_t dis = i == 1u ? sis_x : t.away(t.toward(node, x), x);
+                            e.o.toks[e.o.ntok + q] = (uint32_t)dis;
+                            e.o.dsts[e.o.ndst + q] = node;
+                        }
+                    }
+                    e.o.ntok += k - 1u;
+                    e.o.ndst += k - 1u;
+                    e.one(x, p0);
+                    top = p0;
+                    have_acc = true;
+                }
             }
-            if (xt >= 4096)
-                e.overflow = true;
-            pi.c = x;
-            // path P0 = parent(x) .. Pk = src; walk it from the bottom to emit edits, then emit the
-            // chain from Pk upwards: Pk (other child, displaced(k-1)), Pi (displaced(i-1)), P0 (x)
-            PathStore<LDS_PATHS> &path = buf1;
-            int k = 0;
-            for (int32_t p = t.parent[x]; p != src && k < cap - 1; p = t.parent[p])
-                path.set(k++, p);
-            if (k >= cap - 1)
-                e.overflow = true;
-            path.set(k, src);
-            // displaced[i] = the child of Pi that is not P(i-1) (for i = 0: the sister of x)
-            // edits
-            int32_t displaced = t.sister(x);
-            e.edit(path.get(0), path.get(1), x);
-            for (int i = 1; i < k; i++)
+            if (!unusable)
             {
-                const int32_t pi_ = path.get(i);
-                const int32_t other = (t.left[pi_] == path.get(i - 1)) ? t.right[pi_] : t.left[pi_];
-                e.edit(pi_, path.get(i + 1), displaced);
-                displaced = other;
+                // rewrites of the prune-and-graft (pp and dp may be the same node): pp trades sp for ss, dp trades dest
+                // for sp, each on the side it was; sp holds (dest, top)
+                {
+                    int32_t l = (int32_t)t.left[pp], r = (int32_t)t.right[pp];
+                    if (l == sp)
+                        l = ss;
+                    else
+                        r = ss;
+                    if (pp == dp)
+                    {
+                        if (l == dest)
+                            l = sp;
+                        else if (r == dest)
+                            r = sp;
+                        e.edit(pp, l, r);
+                    }
+                    else
+                    {
+                        e.edit(pp, l, r);
+                        l = (int32_t)t.left[dp];
+                        r = (int32_t)t.right[dp];
+                        if (l == dest)
+                            l = sp;
+                        else
+                            r = sp;
+                        e.edit(dp, l, r);
+                    }
+                    e.edit(sp, dest, top);
+                }
+                // ---- the program.  d(v) = depth below the root; a root-ward path of y has d(y) nodes (the root is
+                // not one of them).  Three shapes (TreeOperations.c:302, 330-334: both root-ward paths are dirty):
+                const int32_t oc_dp = dp == root ? -1 : t.other(dp, dest); // dp's clean child once sp has taken dest's place
+                const int32_t oc_pp = t.other(pp, sp);                     // pp's other child (pp keeps it; sp's place goes to ss)
+                auto head_sp = [&](bool merge_after) {
+                    if (have_acc)
+                        e.one(dest, sp, merge_after);
+                    else
+                        e.head2(dest, 0u, top, sp, merge_after);
+                };
+                if (dest != ss && t.inside(dest, ss))
+                {
+                    // (1) dest below the sister: one chain sp, dp .. ss, then pp .. (sp's old place is skipped)
+                    head_sp(false);
+                    e.run(dp, 0u, (uint32_t)(t.dep(dp) - t.dep(ss)) + 1u, oc_dp, -1, -1, false);
+                    if (pp != root)
+                    {
+                        e.run(pp, 0u, (uint32_t)t.dep(pp), oc_pp, -1, -1, false);
+                        e.finish(t.away(root, pp));
+                    }
+                    else
+                        e.finish(oc_pp);
+                }
+                else if (pp != root && t.inside(pp, dest))
+                {
+                    // (2) dest is pp or above it: one chain from pp through dest, sp (new place), dp ..
+                    const uint32_t up_to_dest = (uint32_t)(t.dep(pp) - t.dep(dest)); // nodes above pp up to dest
+                    e.head2(ss, have_acc ? TOK_PUSH : 0u, oc_pp, pp, have_acc && up_to_dest == 0u);
+                    e.run(pp, 1u, up_to_dest, -1, -1, -1, have_acc);
+                    if (have_acc)
+                        e.merge_dst(sp); // both children of sp are dirty: the subtree chain waited on the stack
+                    else
+                        e.one(top, sp);
+                    if (dp != root)
+                    {
+                        e.run(dp, 0u, (uint32_t)t.dep(dp), oc_dp, -1, -1, false);
+                        e.finish(t.away(root, dp));
+                    }
+                    else
+                        e.finish(t.other(root, dest));
+                }
+                else
+                {
+                    // (3) dest elsewhere: paths from sp (through dp) and from pp, meeting at M (possibly only at the root)
+                    const int32_t m = (pp == root || dp == root) ? root : t.lca(dp, pp);
+                    if (pp == root || m == pp)
+                    {
+                        // pp is the root or lies on the path from dp: one chain; where it passes pp, sp's place holds ss
+                        head_sp(false);
+                        if (dp != root)
+                        {
+                            e.run(dp, 0u, (uint32_t)t.dep(dp), oc_dp, sp, ss, false);
+                            e.finish(pp == root ? ss : t.away(root, dp));
+                        }
+                        else
+                            e.finish(ss); // root = (ss, sp) now
+                    }
+                    else
+                    {
+                        const uint32_t dm = m == root ? 0u : (uint32_t)t.dep(m);
+                        const uint32_t len_a = dp == root ? 0u : (uint32_t)t.dep(dp) - dm; // dp .. below M (0: M is dp)
+                        const uint32_t len_b = (uint32_t)t.dep(pp) - dm;                     // pp .. below M (>= 1)
+                        head_sp(false);
+                        e.run(dp, 0u, len_a, oc_dp, -1, -1, false);
+                        e.head2(ss, TOK_PUSH, oc_pp, pp, len_b == 1u);
+                        e.run(pp, 1u, len_b - 1u, -1, -1, -1, true);
+                        e.merge_dst(m == root ? -1 : m); // both children of M are dirty
+                        if (m != root)
+                        {
+                            e.run(m, 1u, dm - 1u, -1, -1, -1, false);
+                            e.finish(t.away(root, m));
+                        }
+                        else
+                            e.finish(-1); // the chains met at the root: its children combine was the merge
+                    }
+                }
             }
-            {
-                const int32_t l = t.left[src], r = t.right[src];
-                const int32_t below_src = path.get(k - 1);
-                e.edit(src, l == below_src ? displaced : l, l == below_src ? r : displaced);
-                // chain bottom: src's two (clean) children in the new topology
-                e.tok(l == below_src ? r : l, TOK_FRESH);
-                e.tok(displaced, 0);
-                e.dst(src);
-            }
-            // upwards: P(k-1) .. P1 each take the sister displaced from the node below them
-            for (int i = k - 1; i >= 1; i--)
-            {
-                // clean child of Pi in the new topology = displaced(i-1) = child of P(i-1) not on the path
-                const int32_t below_node = path.get(i - 1);
-                const int32_t dis = (i - 1 == 0) ? t.sister(x)
-                                                 : ((t.left[below_node] == path.get(i - 2)) ? t.right[below_node]
-                                                                                            : t.left[below_node]);
-                e.tok(dis, 0);
-                e.dst(path.get(i));
-            }
-            e.tok(x, 0);
-            e.dst(path.get(0));
-            top = path.get(0);
-            have_acc = true;
         }
-        const SprView nv{t, sp, ss, pp, dp, dest, top};
-        // edits of the prune-and-graft (pp and dp may be the same node)
+    }
+
+    const bool overflow = unusable || e.o.nedit > e.o.cap_e;
+    if (lane == 0)
+    {
+        CandDesc cd{};
+        cd.tok_off = b * g.stride_t;
+        cd.dst_off = b * g.stride_t;
+        if (overflow)
         {
-            int32_t l, r;
-            if (pp == dp)
-            {
-                nv.children(pp, l, r);
-                e.edit(pp, l, r);
-            }
-            else
-            {
-                nv.children(pp, l, r);
-                e.edit(pp, l, r);
-                nv.children(dp, l, r);
-                e.edit(dp, l, r);
-            }
-            e.edit(sp, dest, top);
-        }
-        // path A: sp upwards in the new topology (excluding the root)
-        PathStore<LDS_PATHS> &pa = buf1; // the TBR path above is no longer needed (top is saved)
-        int na = 0;
-        for (int32_t v = sp; v != root && na < cap; v = nv.parent(v))
-            pa.set(na++, v);
-        if (na >= cap)
-            e.overflow = true;
-        // path B: pp upwards until it meets A or the root.  Both paths end just below the root, so
-        // what they share is a common suffix: walk B to the top, then strip the suffix (linear,
-        // instead of searching A for every node of B)
-        PathStore<LDS_PATHS> &pb = buf2;
-        int nbp = 0, meet_a = -1;
-        if (pp != root)
-        {
-            for (int32_t v = pp; v != root && nbp < cap; v = nv.parent(v))
-                pb.set(nbp++, v);
-            if (nbp >= cap)
-                e.overflow = true;
-            int common = 0;
-            while (common < na && common < nbp && pa.get(na - 1 - common) == pb.get(nbp - 1 - common))
-                common++;
-            if (common > 0)
-            {
-                meet_a = na - common; // first node of A that B runs into
-                nbp -= common;
-            }
-        }
-        // chain below sp -> sp: sp's clean child is dest (its other child is `top`: clean for SPR,
-        // the accumulated chain for TBR)
-        auto chain_from_sp = [&](int upto) { // emits pa[0 .. upto)
-            if (upto <= 0)
-                return;
-            if (have_acc)
-                e.tok(dest, 0);
-            else
-            {
-                e.tok(dest, TOK_FRESH);
-                e.tok(top, 0);
-            }
-            e.dst(sp);
-            for (int i = 1; i < upto; i++)
-            {
-                e.tok(nv.other_child(pa.get(i), pa.get(i - 1)), 0);
-                e.dst(pa.get(i));
-            }
-        };
-        if (nbp == 0)
-        {
-            // pp is the root, or pp already lies on A: one chain
-            chain_from_sp(na);
-            last = pa.get(na - 1);
+            // cannot be represented (no admissible move, or a TBR path longer than the rewrite stride): its
+            // "length" tells the host never to accept it
+            cd.base = PROPOSAL_OVERFLOW_LENGTH;
         }
         else
         {
-            // does B pass through sp (dest is pp or above it)?  then B continues as A: one chain from pp
-            bool b_has_sp = (meet_a == 0);
-            if (b_has_sp)
-            {
-                // B: pp (ss, other) ... up to the node below sp, then all of A with the chain as dirty child
-                int32_t l, r;
-                nv.children(pb.get(0), l, r);
-                uint32_t push = have_acc ? TOK_PUSH : 0u;
-                e.tok(l, TOK_FRESH | push);
-                e.tok(r, 0);
-                e.dst(pb.get(0));
-                for (int i = 1; i < nbp; i++)
-                {
-                    e.tok(nv.other_child(pb.get(i), pb.get(i - 1)), 0);
-                    e.dst(pb.get(i));
-                }
-                // sp: children (dest = top of B chain [dirty], top)
-                if (have_acc)
-                    e.merge(sp); // both children of sp are dirty: the subtree chain waits on the stack
-                else
-                {
-                    e.tok(top, 0);
-                    e.dst(sp);
-                }
-                for (int i = 1; i < na; i++)
-                {
-                    e.tok(nv.other_child(pa.get(i), pa.get(i - 1)), 0);
-                    e.dst(pa.get(i));
-                }
-                last = pa.get(na - 1);
-            }
-            else
-            {
-                // two chains: A below the meeting node (or all of A if they only meet at the root), then B
-                const int a_len = meet_a >= 0 ? meet_a : na;
-                chain_from_sp(a_len);
-                int32_t l, r;
-                nv.children(pb.get(0), l, r);
-                e.tok(l, TOK_FRESH | TOK_PUSH);
-                e.tok(r, 0);
-                e.dst(pb.get(0));
-                for (int i = 1; i < nbp; i++)
-                {
-                    e.tok(nv.other_child(pb.get(i), pb.get(i - 1)), 0);
-                    e.dst(pb.get(i));
-                }
-                if (meet_a >= 0)
-                {
-                    e.merge(pa.get(meet_a)); // both children of the meeting node are dirty
-                    for (int i = meet_a + 1; i < na; i++)
-                    {
-                        e.tok(nv.other_child(pa.get(i), pa.get(i - 1)), 0);
-                        e.dst(pa.get(i));
-                    }
-                    last = pa.get(na - 1);
-                }
-                else
-                {
-                    // the chains meet only at the root: its two children are both dirty
-                    e.merge(-1);
-                    last = -2; // root combine already emitted
-                }
-            }
+            cd.ntok = e.o.ntok;
+            cd.ncomb = e.o.ndst;
+            cd.flags = CAND_RESIDENT_BASE;
+            cd.nfresh = e.o.nfresh;
         }
-        if (last != -2)
-        {
-            e.tok(nv.other_child(root, last), 0);
-            e.dst(-1);
-        }
-        e.tok(root, 0);
-        e.dst(-1);
+        g.cands[b] = cd;
+        g.len_out[b] = 0ull; // the walk accumulates into it: cleared here, so a step needs no clearing pass of its own
+        pi.n_edits = (int32_t)e.o.nedit;
+        pi.overflow = overflow ? 1 : 0;
+        pi.ncomb = (int32_t)e.o.ndst;
+        g.info[b] = pi;
     }
-
-    CandDesc cd{};
-    cd.tok_off = b * stride_t;
-    cd.ntok = e.ntok;
-    cd.dst_off = b * stride_t;
-    cd.ncomb = e.ndst;
-    cd.base = 0;
-    cd.flags = CAND_RESIDENT_BASE;
-    cd.nfresh = e.nfresh;
-    if (e.overflow)
-    {
-        // cannot be represented in the fixed strides: score it as the unchanged tree's root
-        // combine only and flag it, so the host never accepts it
-        cd.ntok = 0;
-        cd.ncomb = 0;
-        cd.nfresh = 0;
-        cd.flags = 0;
-        cd.base = PROPOSAL_OVERFLOW_LENGTH; // its "length": the host reads that as unusable
-    }
-    cands[b] = cd;
-    pi.n_edits = (int32_t)e.nedit;
-    pi.overflow = e.overflow ? 1 : 0;
-    pi.ncomb = (int32_t)e.ndst;
-    info[b] = pi;
 }
 
-hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t kind, uint32_t mix_a, uint32_t mix_b,
-                          uint64_t seed, uint32_t B,
-                          uint32_t stride_t, uint32_t stride_e, uint32_t *toks, int32_t *dsts, lvbgpu_edit_dev *edits,
-                          CandDesc *cands, ProposalInfo *info, const lvbgpu_move_dev *moves, bool scratch_paths,
-                          bool *paths_capped, hipStream_t stream)
+} // namespace
+
+template <typename IdxT>
+__global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 {
-    const int32_t nb = 2 * n - 3;
+    extern __shared__ uint4 lds_tables[];
+    const IdxT *tab = reinterpret_cast<const IdxT *>(g.tables);
+    if (g.use_lds)
+    {
+        // one coalesced copy per workgroup; everything after it is LDS latency instead of L2 latency
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(g.tables);
+        const uint32_t n16 = g.table_bytes / 16u;
+        for (uint32_t i0 = 0; i0 < n16; i0 += 4u * GEN_THREADS)
+        {
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++)
+            {
+                const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
+                if (i < n16)
+                    v[u] = src4[i];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++)
+            {
+                const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
+                if (i < n16)
+                    lds_tables[i] = v[u];
+            }
+        }
+        __syncthreads();
+        tab = reinterpret_cast<const IdxT *>(lds_tables);
+    }
+    const size_t nb = (size_t)g.nb;
+    Tab<IdxT> t;
+    t.parent = tab;
+    t.left = tab + nb;
+    t.right = tab + 2 * nb;
+    t.nleaf = tab + 3 * nb;
+    t.depth = tab + 4 * nb;
+    t.tin = tab + 5 * nb;
+    t.first_leaf = tab + 6 * nb;
+    t.leaf_order = tab + 7 * nb;
+    t.up = tab + 7 * nb + (size_t)g.leaf_order_len;
+    t.n = g.n;
+    t.nb = g.nb;
+    t.root = g.root;
+    t.K = g.K;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t b = blockIdx.x * GEN_WAVES + wave; b < g.B; b += gridDim.x * GEN_WAVES)
+        generate_one(t, g, b, lane);
+}
+
+hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
+{
+    if (args.B == 0)
+        return hipSuccess;
     // the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raise it once for each device a
     // context of this process launches on (the walk does the same per context, raise_lds_limit)
     static hipError_t raised_on[64];
@@ -599,48 +596,29 @@ hipError_t launch_propose(const int32_t *topo4, int32_t n, int32_t root, int32_t
     {
         if (!asked_on[dev])
         {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<uint16_t>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<int32_t>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
             raised_on[dev] = e;
             asked_on[dev] = true;
         }
         raised = raised_on[dev];
     }
-    const size_t lds_max = raised == hipSuccess ? 160u * 1024u : 64u * 1024u;
-    // the topology in LDS when it fits (16 bytes per node; 160 KB of LDS per CU): up to ~5000 taxa
-    size_t lds = (size_t)nb * 16u;
-    int32_t use_lds = 1;
-    if (lds > lds_max)
-    {
-        lds = 0;
-        use_lds = 0;
-    }
-    // ... and behind it the threads' two root-ward paths: 256 bytes per path element and block.  No path has
-    // more than n - 2 nodes; with less room than that a deep tree can overflow a candidate, which the caller
-    // answers by running the batch again with the paths in scratch memory (*paths_capped says it may help)
-    int32_t path_cap = 0;
-    if (use_lds && !scratch_paths && nb <= 65535)
-    {
-        const size_t room = (lds_max - lds) / 256u;
-        const size_t want = (size_t)std::min(n, MAX_PATH);
-        path_cap = (int32_t)std::min(room, want);
-        if (path_cap < 64 && path_cap < n - 1)
-            path_cap = 0; // too little to be worth a second launch now and then
-    }
-    if (paths_capped)
-        *paths_capped = path_cap > 0 && path_cap < std::min(n - 1, MAX_PATH);
-    const dim3 grid((B + 63) / 64), block(64);
-    if (path_cap > 0)
-        hipLaunchKernelGGL(propose_kernel<true>, grid, block, lds + (size_t)path_cap * 256u, stream, topo4, topo4 + nb,
-                           topo4 + 2 * nb, topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts,
-                           edits, cands, info, use_lds, moves, path_cap);
+    const size_t lds_max = raised == hipSuccess ? (size_t)MAX_LDS_BYTES : (size_t)64 * 1024;
+    GenArgs g = args;
+    g.use_lds = g.table_bytes <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
+    const size_t lds = g.use_lds ? g.table_bytes : 0;
+    // one candidate per wave while the chip has room; beyond that waves take several
+    const uint32_t want = (g.B + GEN_WAVES - 1) / GEN_WAVES;
+    const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_max / std::max<size_t>(lds, 1))) : 8u;
+    const uint32_t nblk = std::min(want, 256u * per_cu);
+    const dim3 grid(nblk), block(GEN_THREADS);
+    if (g.idx_bytes == 2)
+        hipLaunchKernelGGL(propose_kernel<uint16_t>, grid, block, lds, stream, g);
     else
-        hipLaunchKernelGGL(propose_kernel<false>, grid, block, lds, stream, topo4, topo4 + nb, topo4 + 2 * nb,
-                           topo4 + 3 * nb, n, root, kind, mix_a, mix_b, seed, B, stride_t, stride_e, toks, dsts, edits, cands,
-                           info, use_lds, moves, 0);
+        hipLaunchKernelGGL(propose_kernel<int32_t>, grid, block, lds, stream, g);
     return hipGetLastError();
 }
 

@@ -33,6 +33,11 @@ def test_walk_timing_counts_every_scoring_walk(setup):
     ms2, k2 = ctx.walk_timing_read()
     assert k2 == 71 and ms2 == ms
     ctx.walk_timing(False)
+    ctx.walk_timing(4)                        # sampled: every 4th walk
+    for s in range(9):
+        ctx.propose_score(64, 1, s)
+    assert ctx.walk_timing_read()[1] == 3     # walks 0, 4, 8
+    ctx.walk_timing(False)
     ctx.propose_score(64, 1, 99)
     ctx.walk_timing(True)                     # enabling starts from zero
     assert ctx.walk_timing_read() == (0.0, 0)
