@@ -68,9 +68,10 @@ typedef struct lvbhost_alignment lvbhost_alignment;
 /* PHYLIP, sequential or interleaved: header "n m", 10-character name field, digits and blanks
  * inside sequences ignored, text upper-cased (MSAInput.cpp:829).  NULL + message on error. */
 lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, char *err, int32_t errcap);
-/* any of the reference's four input formats (-f; DataStructure.h:50-53: 0 phylip, 1 fasta, 2 nexus,
- * 3 clustal; MSAInput.cpp:141-217, 274-432, 546-579, 594-695) followed by the checks read_file applies
- * to all of them (737-849: at least two sequences, equal lengths, upper case, accepted characters) */
+/* any of the reference's four input formats (-f; DataStructure.h:50-53: 0 phylip, 1 fasta, 2 nexus, 3 clustal),
+ * followed by the conditions its reader puts on all of them (MSAInput.cpp:780-849: at least two sequences, equal
+ * lengths, upper case, accepted characters).  FASTA / NEXUS / CLUSTAL are parsed by an own record-stream parser
+ * (chunks appended to the taxon of that name); results equal the reference's reader on what it accepts. */
 lvbhost_alignment *lvbhost_alignment_read(const char *path, int format, char *err, int32_t errcap);
 void lvbhost_alignment_free(lvbhost_alignment *a);
 int64_t lvbhost_alignment_n(const lvbhost_alignment *a);
@@ -90,10 +91,15 @@ int64_t lvbhost_variable_columns(int64_t n, int64_t m, const char *const *rows, 
  * more than MAXSTATES (5) distinct ones occur */
 int64_t lvbhost_min_tree_length(int64_t n, int64_t m, const char *const *rows);
 
-/* the distinct best topologies the last lvbhost_anneal run found (the reference's treestack,
- * Treestack.c:231-306): how many, how many of them were kept (first 1024), and their arrays */
+/* the distinct best topologies the last lvbhost_anneal run found (the reference's treestack, Treestack.c:231-306;
+ * found by hash, told apart by an exact comparison of canonical forms): how many there are - all are kept, _count
+ * and _kept agree - and their arrays */
 /* rooting- and numbering-independent identity of the topology (sum of hashed bipartition keys) */
 uint64_t lvbhost_tree_topology_hash(const lvbhost_tree *t);
+/* the exact identity behind it: the tree re-rooted at taxon 0, every node's subtrees ordered by their smallest
+ * taxon, in preorder (-1 opens an internal node, a taxon number is a leaf): 2n-3 entries.  Equal for two trees iff
+ * they are the same unrooted topology.  Returns the number of entries written or a negative status. */
+int32_t lvbhost_tree_canonical(const lvbhost_tree *t, int32_t *out, int32_t cap);
 int32_t lvbhost_tree_best_count(const lvbhost_tree *t);
 int32_t lvbhost_tree_best_kept(const lvbhost_tree *t);
 int lvbhost_tree_best_get(const lvbhost_tree *t, int32_t i, int32_t *left, int32_t *right, int32_t *root);

@@ -13,9 +13,9 @@
 //     the ceiling).
 //   * the re-root is an edit along the old-root..new-root path (the reference re-evaluates the
 //     whole tree, TreeOperations.c:631-635); lengths and node sets come out the same.
-//   * the treestack is a set of topology hashes (bipartition keys, host_tree.hpp) instead of stored
-//     object sets; as in the reference (Solve.c:309-320) "accepted" counts proposals that tie or
-//     beat the best length AND are a topology not yet in it.
+//   * the treestack finds topologies by a hash of their bipartitions and tells them apart by an exact comparison
+//     of canonical forms (host_tree.hpp) instead of sorted object sets; as in the reference (Solve.c:309-320)
+//     "accepted" counts proposals that tie or beat the best length AND are a topology not yet in it.
 //   * the random stream is xorshift64*, not the reference's Marsaglia generator.
 // No length is computed here: all come from lvbgpu_* (HIP).
 #include "../../include/lvbhost.h"
@@ -536,7 +536,7 @@ extern "C" int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost
     if (p.sync_every <= 0)
         res->global_best_length = best;
     res->scored = ch.scored;
-    res->topologies = (int64_t)tree->best.seen.size();
+    res->topologies = (int64_t)tree->best.count();
     res->consumed = iter;
     res->t_final = t;
     res->seconds = since(wall0);

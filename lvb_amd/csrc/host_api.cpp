@@ -4,9 +4,11 @@
 
 #include <algorithm>
 #include <cctype>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <new>
 #include <sstream>
 #include <string>
@@ -83,15 +85,123 @@ uint64_t BestSet::hash(const Topology &t, std::vector<uint64_t> &sub) const
     return h;
 }
 
+// the unrooted topology in a form that does not depend on rooting, node numbers or child order
+void BestSet::canonical(const Topology &t, std::vector<int32_t> &out)
+{
+    // The root leaf R carries its two children itself (the edge to its neighbour is folded into the record): as an
+    // undirected tree, node R is that neighbour and taxon R hangs from it as a virtual leaf, numbered nb here.
+    const int32_t nb = t.nb, vleaf = nb, R = t.root;
+    auto neighbours = [&](int32_t v, int32_t nbr[3]) -> int {
+        if (v == vleaf)
+        {
+            nbr[0] = R;
+            return 1;
+        }
+        int k = 0;
+        if (v == R)
+            nbr[k++] = vleaf;
+        else
+            nbr[k++] = t.parent[v];
+        if (t.left[v] >= 0)
+        {
+            nbr[k++] = t.left[v];
+            nbr[k++] = t.right[v];
+        }
+        return k;
+    };
+    auto label = [&](int32_t v) { return v == vleaf ? R : v; }; // taxon of a leaf
+    const int32_t start = R == 0 ? vleaf : 0;                  // the leaf of taxon 0
+    // orient away from taxon 0: preorder with the node each was reached from
+    std::vector<int32_t> order, from((size_t)nb + 1, -1), minlab((size_t)nb + 1, INT32_MAX);
+    order.reserve((size_t)nb + 1);
+    std::vector<int32_t> st{start};
+    while (!st.empty())
+    {
+        const int32_t v = st.back();
+        st.pop_back();
+        order.push_back(v);
+        int32_t nbr[3];
+        const int k = neighbours(v, nbr);
+        for (int i = 0; i < k; i++)
+            if (nbr[i] != from[v])
+            {
+                from[nbr[i]] = v;
+                st.push_back(nbr[i]);
+            }
+    }
+    for (auto it = order.rbegin(); it != order.rend(); ++it)
+    {
+        const int32_t v = *it;
+        int32_t nbr[3];
+        const int k = neighbours(v, nbr);
+        if (k == 1)
+            minlab[v] = label(v);
+        if (from[v] >= 0)
+            minlab[from[v]] = std::min(minlab[from[v]], minlab[v]);
+    }
+    // preorder again, subtrees by their smallest taxon
+    out.clear();
+    out.reserve((size_t)nb + 1);
+    st.assign(1, start);
+    while (!st.empty())
+    {
+        const int32_t v = st.back();
+        st.pop_back();
+        int32_t nbr[3], kids[2];
+        const int k = neighbours(v, nbr);
+        int nk = 0;
+        for (int i = 0; i < k; i++)
+            if (nbr[i] != from[v])
+                kids[nk++] = nbr[i];
+        if (k == 1 && v != start)
+        {
+            out.push_back(label(v));
+            continue;
+        }
+        if (v != start)
+            out.push_back(-1);
+        if (nk == 2 && minlab[kids[0]] > minlab[kids[1]])
+            std::swap(kids[0], kids[1]);
+        for (int i = nk - 1; i >= 0; i--)
+            st.push_back(kids[i]);
+    }
+}
+
 bool BestSet::insert(const Topology &t)
 {
     std::vector<uint64_t> sub;
     const uint64_t h = hash(t, sub);
-    if (!seen.insert(h).second)
-        return false;
-    if (kept.size() < cap)
-        kept.push_back({t.left, t.right, t.root});
+    std::vector<int32_t> canon;
+    canonical(t, canon);
+    const auto range = by_hash.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it)
+        if (kept[it->second].canon == canon)
+            return false; // the same topology, compared exactly
+    by_hash.emplace(h, kept.size());
+    kept.push_back({t.left, t.right, t.root, std::move(canon)});
     return true;
+}
+
+BestSet::Kept BestSet::pop_last()
+{
+    Kept k = std::move(kept.back());
+    kept.pop_back();
+    for (auto it = by_hash.begin(); it != by_hash.end(); ++it)
+        if (it->second == kept.size())
+        {
+            by_hash.erase(it);
+            break;
+        }
+    return k;
+}
+
+void BestSet::push_kept(Kept &&k, std::vector<uint64_t> &scratch)
+{
+    Topology t;
+    std::string why;
+    if (t.assign((int32_t)key.size(), k.left.data(), k.right.data(), k.root, &why))
+        by_hash.emplace(hash(t, scratch), kept.size());
+    kept.push_back(std::move(k));
 }
 
 extern "C" uint64_t lvbhost_tree_topology_hash(const lvbhost_tree *t)
@@ -100,7 +210,19 @@ extern "C" uint64_t lvbhost_tree_topology_hash(const lvbhost_tree *t)
     return t->best.hash(t->topo, sub);
 }
 
-extern "C" int32_t lvbhost_tree_best_count(const lvbhost_tree *t) { return t ? (int32_t)t->best.seen.size() : 0; }
+extern "C" int32_t lvbhost_tree_canonical(const lvbhost_tree *t, int32_t *out, int32_t cap)
+{
+    if (!t || !out)
+        return LVBGPU_E_ARG;
+    std::vector<int32_t> c;
+    BestSet::canonical(t->topo, c);
+    if ((int32_t)c.size() > cap)
+        return LVBGPU_E_ARG;
+    memcpy(out, c.data(), c.size() * sizeof(int32_t));
+    return (int32_t)c.size();
+}
+
+extern "C" int32_t lvbhost_tree_best_count(const lvbhost_tree *t) { return t ? (int32_t)t->best.count() : 0; }
 extern "C" int32_t lvbhost_tree_best_kept(const lvbhost_tree *t) { return t ? (int32_t)t->best.kept.size() : 0; }
 extern "C" int lvbhost_tree_best_get(const lvbhost_tree *t, int32_t i, int32_t *left, int32_t *right, int32_t *root)
 {
@@ -455,268 +577,187 @@ extern "C" lvbhost_alignment *lvbhost_alignment_read_phylip(const char *path, ch
     return a;
 }
 
-// ---- the other three input formats (reference MSAInput.cpp: read_fasta 546-579, read_nexus
-// 594-695, read_clustal 141-217) and the checks every format goes through (read_file 737-849)
+// ---- FASTA / NEXUS / CLUSTAL (the reference's -f 1/2/3).  Own design, not the reference's line-position state
+// machines: every format is reduced to a stream of (name, chunk) records and the chunks are appended to the
+// taxon of that NAME, in order of first appearance - so wrapped, interleaved and multi-block files need no
+// bookkeeping of "which line of the block is this".  What the reference's reader accepts is accepted here with the
+// same result (tests/test_io_vs_reference.py compares both on its example in every format and on wrapped /
+// interleaved variants); the error texts are ours.
 
 namespace
 {
-// trim as the reference's reader does: newline, carriage return and blank, in that order, each
-// stripped from both ends once (MSAInput.cpp:49-57, 102-119)
-std::string ref_trim(std::string s)
+struct NamedRows
 {
-    for (char c : {'\n', '\r', '\n', ' '})
+    lvbhost_alignment &a;
+    std::map<std::string, size_t> index;
+    void add(const std::string &name, const std::string &chunk)
     {
-        const size_t first = s.find_first_not_of(c);
-        if (first == std::string::npos)
-            return "";
-        s = s.substr(first, s.find_last_not_of(c) - first + 1);
+        auto it = index.find(name);
+        if (it == index.end())
+        {
+            it = index.emplace(name, a.names.size()).first;
+            a.names.push_back(name);
+            a.rows.emplace_back();
+        }
+        for (char c : chunk)
+            if (!isspace((unsigned char)c))
+                a.rows[it->second].push_back(c);
     }
+};
+
+std::vector<std::string> words_of(const std::string &line)
+{
+    std::vector<std::string> w;
+    std::istringstream ss(line);
+    for (std::string x; ss >> x;)
+        w.push_back(x);
+    return w;
+}
+// all words but the last, blank-joined: a taxon label may hold blanks
+std::string label_of(const std::vector<std::string> &w, size_t nchunk_words)
+{
+    std::string out;
+    for (size_t i = 0; i + nchunk_words < w.size(); i++)
+        out += (i ? " " : "") + w[i];
+    return out;
+}
+std::string lower(std::string s)
+{
+    for (char &c : s)
+        c = (char)tolower((unsigned char)c);
     return s;
 }
-// blank-separated fields, empty ones kept (consecutive blanks), none after a trailing blank
-std::vector<std::string> fields_of(const std::string &line)
-{
-    std::vector<std::string> out;
-    std::stringstream ss(line);
-    std::string item;
-    while (std::getline(ss, item, ' '))
-        out.push_back(item);
-    return out;
-}
-int nonempty_fields(const std::vector<std::string> &f)
-{
-    int k = 0;
-    for (const auto &x : f)
-        k += !x.empty();
-    return k;
-}
-// last non-empty field = the sequence chunk; the non-empty fields before it, blank-joined = the name
-std::string last_field(const std::vector<std::string> &f)
-{
-    for (size_t i = f.size(); i-- > 0;)
-        if (!f[i].empty())
-            return f[i];
-    return "";
-}
-std::string name_fields(const std::vector<std::string> &f)
-{
-    size_t last = f.size();
-    for (size_t i = f.size(); i-- > 0;)
-        if (!f[i].empty())
-        {
-            last = i;
-            break;
-        }
-    std::string out;
-    for (size_t i = 0; i < last && last != f.size(); i++)
-        if (!f[i].empty())
-        {
-            if (!out.empty())
-                out += " ";
-            out += f[i];
-        }
-    return out;
-}
+bool all_digits(const std::string &s) { return !s.empty() && std::all_of(s.begin(), s.end(), [](char c) { return isdigit((unsigned char)c); }); }
 
-bool read_fasta(std::ifstream &in, lvbhost_alignment &a, std::string &)
+// ">name" opens a record; every other line belongs to the open record (records are positional: two may share a label)
+bool parse_fasta(const std::vector<std::string> &lines, NamedRows &out, std::string &)
 {
-    std::string line;
-    long current = -1;
-    while (std::getline(in, line))
+    for (const std::string &raw : lines)
     {
-        line = ref_trim(line);
+        const std::string line = trimmed(raw);
         if (line.empty())
             continue;
         if (line[0] == '>')
         {
-            a.names.push_back(line.substr(1));
-            current++;
+            out.a.names.push_back(line.substr(1));
+            out.a.rows.emplace_back();
         }
-        else if (current == (long)a.rows.size())
-            a.rows.push_back(line);
-        else if (current >= 0 && current < (long)a.rows.size())
-            a.rows[(size_t)current] += line;
-        // sequence text before the first '>' has nowhere to go (the reference indexes out of range there)
+        else if (!out.a.rows.empty())
+            for (char c : line)
+                if (!isspace((unsigned char)c))
+                    out.a.rows.back().push_back(c);
     }
     return true;
 }
 
-bool read_nexus(std::ifstream &in, lvbhost_alignment &a, std::string &why)
+// "dimensions ntax=.. nchar=..;" gives the expected shape; between "matrix" and the closing ";" every line is
+// "<label> <chunk>" (interleaved blocks repeat the labels)
+bool parse_nexus(const std::vector<std::string> &lines, NamedRows &out, std::string &why)
 {
-    int nseq = 0, nchar = 0;
-    bool reading = false, names_done = false;
-    int cursor = 0;
-    std::string line;
-    while (std::getline(in, line))
+    long ntax = 0, nchar = 0;
+    bool in_matrix = false;
+    for (const std::string &raw : lines)
     {
-        line = ref_trim(line);
+        const std::string line = trimmed(raw), low = lower(line);
         if (line.empty())
             continue;
-        if (line.find("dimensions") != std::string::npos)
+        if (!in_matrix)
         {
-            nseq = nchar = 0;
-            // lower-case keywords, taxa first; the reference's second pattern (characters first)
-            // stores its two numbers the same way round, so such a file fails the count check below
-            if (sscanf(line.c_str(), "dimensions ntax=%d nchar=%d;", &nseq, &nchar) == 0)
-                sscanf(line.c_str(), "dimensions nchar=%d ntax=%d;", &nseq, &nchar);
-            if (nseq == 0 || nchar == 0)
-            {
-                why = "Wans't possible to get the dimensions of the matrix.\nLine: " + line;
-                return false;
-            }
-        }
-        if (line.find("matrix") != std::string::npos)
-        {
-            reading = true;
+            if (low.compare(0, 10, "dimensions") == 0)
+                for (const char *key : {"ntax=", "nchar="})
+                {
+                    const size_t at = low.find(key);
+                    if (at != std::string::npos)
+                        (key[1] == 't' ? ntax : nchar) = strtol(low.c_str() + at + strlen(key), nullptr, 10);
+                }
+            else if (low == "matrix" || low.compare(0, 7, "matrix ") == 0)
+                in_matrix = true;
             continue;
         }
-        if (!reading)
-            continue;
-        if (line.find(";") != std::string::npos)
+        if (line.find(';') != std::string::npos)
         {
-            reading = false;
+            in_matrix = false;
             continue;
         }
-        const std::vector<std::string> f = fields_of(line);
-        if (f.empty())
-            continue;
-        if (!names_done)
-        {
-            if (f.size() > 1)
-            {
-                a.names.push_back(name_fields(f));
-                a.rows.push_back(last_field(f));
-            }
-            if ((int)a.names.size() == nseq)
-                names_done = true;
-        }
-        else
-        {
-            if (cursor >= (int)a.rows.size())
-            {
-                why = "Some problem reading the file.";
-                return false;
-            }
-            a.rows[(size_t)cursor++] += last_field(f);
-            if (cursor == nseq)
-                cursor = 0;
-        }
+        const std::vector<std::string> w = words_of(line);
+        if (w.size() >= 2)
+            out.add(label_of(w, 1), w.back());
     }
-    if (nseq == 0)
+    if (ntax <= 0 || nchar <= 0)
     {
-        why = "Some problem reading the file. Please, check the file format.";
+        why = "NEXUS: no 'dimensions ntax=<n> nchar=<m>;' statement found before the matrix; check the file format";
         return false;
     }
-    if ((int)a.names.size() != nseq)
+    if ((long)out.a.names.size() != ntax)
     {
-        why = "The file has a different number of sequences.\nRead: " + std::to_string(a.names.size()) +
-              "\nIn the header: " + std::to_string(nseq);
+        why = "NEXUS: the matrix holds a different number of sequences (" + std::to_string(out.a.names.size()) +
+              ") than its dimensions statement announces (" + std::to_string(ntax) + ")";
         return false;
     }
-    for (size_t i = 0; i < a.rows.size(); i++)
-        if ((int)a.rows[i].size() != nchar)
+    for (size_t i = 0; i < out.a.rows.size(); i++)
+        if ((long)out.a.rows[i].size() != nchar)
         {
-            why = "This sequence " + a.names[i] + " has a different length " + std::to_string(a.rows[i].size()) +
-                  " from the one read in the header: " + std::to_string(nchar);
+            why = "NEXUS: sequence '" + out.a.names[i] + "' has a different length (" + std::to_string(out.a.rows[i].size()) +
+                  ") than nchar=" + std::to_string(nchar);
             return false;
         }
     return true;
 }
 
-bool read_clustal(std::ifstream &in, lvbhost_alignment &a, std::string &why)
+// after the "CLUSTAL ..." line: "<label> <chunk> [running count]"; lines that start with a blank are the
+// conservation marks under a block
+bool parse_clustal(const std::vector<std::string> &lines, NamedRows &out, std::string &why)
 {
-    bool header = false, first_block_done = false;
-    int cursor = 0;
-    std::string line;
-    while (std::getline(in, line))
+    bool header = false;
+    for (const std::string &line : lines)
     {
         if (!header)
         {
-            if (line.size() > 1)
-            {
-                if (line.find("CLUSTAL") != std::string::npos)
-                    header = true;
-                continue;
-            }
-        }
-        else if (!line.empty())
-        {
-            const std::vector<std::string> f = fields_of(line);
-            if (f.empty())
-                continue;
-            if (nonempty_fields(f) == 1 || f[0].empty()) // the conservation line under a block
-            {
-                if (!first_block_done)
-                {
-                    first_block_done = true;
-                    continue;
-                }
-                if (cursor == (int)a.names.size())
-                {
-                    cursor = 0;
-                    continue;
-                }
-            }
-            if (!first_block_done)
-            {
-                if (f.size() > 1)
-                {
-                    a.names.push_back(name_fields(f));
-                    a.rows.push_back(last_field(f));
-                }
-            }
-            else
-            {
-                if (cursor >= (int)a.rows.size())
-                {
-                    why = "Some problem reading the file.";
-                    return false;
-                }
-                a.rows[(size_t)cursor++] += last_field(f);
-            }
+            header = line.find("CLUSTAL") != std::string::npos;
             continue;
         }
-        // blank line (or a one-character line before the header): a block ended
-        cursor = 0;
-        if (!a.names.empty())
-            first_block_done = true;
+        if (line.empty() || isspace((unsigned char)line[0]))
+            continue;
+        std::vector<std::string> w = words_of(line);
+        if (w.size() >= 3 && all_digits(w.back()))
+            w.pop_back();
+        if (w.size() >= 2)
+            out.add(label_of(w, 1), w.back());
+    }
+    if (!header)
+    {
+        why = "CLUSTAL: the file does not start with a CLUSTAL header line; check the file format";
+        return false;
     }
     return true;
 }
 
-// read_file's checks after any format (MSAInput.cpp:780-849)
-bool check_alignment(lvbhost_alignment &a, const std::string &path, std::string &why)
+// what every format must satisfy before matchange sees it (the reference applies the same conditions after
+// reading, MSAInput.cpp:780-849): two or more sequences, one length, upper case, DNAToBinary's alphabet plus O
+bool validate_alignment(lvbhost_alignment &a, const std::string &path, std::string &why)
 {
     if (a.rows.size() < 2)
     {
-        why = (a.rows.empty() ? "Zero sequences were read from the file: " : "Only one sequence was read from the file: ") + path;
-        return false;
-    }
-    if (a.rows.size() != a.names.size())
-    {
-        why = "Something wrong with the file.\nThe number of sequences names are different from the number of "
-              "sequences in the file: " + path;
+        why = (a.rows.empty() ? "Zero sequences were read from " : "Only one sequence was read from ") + path;
         return false;
     }
     for (size_t i = 1; i < a.rows.size(); i++)
         if (a.rows[i].size() != a.rows[0].size())
         {
-            why = "Something wrong with the file.\nThe sequence lengths are different in the file: " + path;
+            why = "The sequence lengths are different in " + path + ": '" + a.names[i] + "' has " + std::to_string(a.rows[i].size()) +
+                  " sites, '" + a.names[0] + "' has " + std::to_string(a.rows[0].size());
             return false;
         }
-    static const std::string accepted = "ACGTUYRWSKMBDHVNX?O-";
     for (size_t i = 0; i < a.rows.size(); i++)
-    {
         for (char &c : a.rows[i])
+        {
             c = (char)toupper((unsigned char)c);
-        for (char c : a.rows[i])
-            if (accepted.find(c) == std::string::npos)
+            if (!strchr("ACGTUYRWSKMBDHVNX?O-", c))
             {
-                why = std::string("This char is not allowed (") + c + ")\nThe char is in this line: " + a.names[i] + ": " +
-                      a.rows[i] + "\n";
+                why = std::string("This char is not allowed (") + c + ") in sequence '" + a.names[i] + "' of " + path;
                 return false;
             }
-    }
+        }
     a.m = (int64_t)a.rows[0].size();
     return true;
 }
@@ -732,7 +773,7 @@ extern "C" lvbhost_alignment *lvbhost_alignment_read(const char *path, int forma
     if (!path)
         return fail("no file name");
     if (format < 0 || format > 3)
-        return fail(std::string("Unrecognized file...") + path);
+        return fail(std::string("unknown alignment format code for ") + path);
     lvbhost_alignment *a = nullptr;
     std::string why;
     if (format == 0)
@@ -746,17 +787,25 @@ extern "C" lvbhost_alignment *lvbhost_alignment_read(const char *path, int forma
         std::ifstream in(path);
         if (!in)
             return fail(std::string("Failed to open alignment file: ") + path);
+        std::vector<std::string> lines;
+        for (std::string line; std::getline(in, line);)
+        {
+            if (!line.empty() && line.back() == '\r')
+                line.pop_back();
+            lines.push_back(line);
+        }
         a = new (std::nothrow) lvbhost_alignment();
         if (!a)
             return fail("out of memory");
-        const bool ok = format == 1 ? read_fasta(in, *a, why) : (format == 2 ? read_nexus(in, *a, why) : read_clustal(in, *a, why));
+        NamedRows out{*a, {}};
+        const bool ok = format == 1 ? parse_fasta(lines, out, why) : (format == 2 ? parse_nexus(lines, out, why) : parse_clustal(lines, out, why));
         if (!ok)
         {
             delete a;
             return fail(why);
         }
     }
-    if (!check_alignment(*a, path, why))
+    if (!validate_alignment(*a, path, why))
     {
         delete a;
         return fail(why);

@@ -725,7 +725,6 @@ extern "C" int lvbhost_reference_search(lvbgpu_ctx *ctx, const lvbhost_refsearch
         return LVBGPU_E_NOMEM;
     BestSet &stack = out->best;
     stack.reset(n);
-    stack.cap = (size_t)-1;
     std::vector<uint64_t> hscratch;
 
     LoopState st;
@@ -738,7 +737,8 @@ extern "C" int lvbhost_reference_search(lvbgpu_ctx *ctx, const lvbhost_refsearch
     int64_t best = d.cur_len;
     // Anneal() begins by putting the start tree on the stack through the hashing comparison
     // (Solve.c:207, Hash.cpp:49-90): remember its identity for the epilogue below
-    const uint64_t start_identity = stack.hash(d.topo, hscratch);
+    std::vector<int32_t> start_identity;
+    BestSet::canonical(d.topo, start_identity);
     stack.insert(d.topo);
     int64_t accepted_moves = 0;
     d.run_len = 2.0;
@@ -824,19 +824,9 @@ extern "C" int lvbhost_reference_search(lvbgpu_ctx *ctx, const lvbhost_refsearch
     // hashing comparison, whose memory holds only the start tree's identity
     if (!stack.kept.empty())
     {
-        BestSet::Kept last = stack.kept.back();
-        stack.kept.pop_back();
-        Topology tl;
-        if (!tl.assign(n, last.left.data(), last.right.data(), last.root, &why))
-        {
-            delete out;
-            return LVBGPU_E_TOPOLOGY;
-        }
-        const uint64_t h = stack.hash(tl, hscratch);
-        if (stack.kept.empty() || h != start_identity)
-            stack.kept.push_back(std::move(last));
-        else
-            stack.seen.erase(h);
+        BestSet::Kept last = stack.pop_last();
+        if (stack.kept.empty() || last.canon != start_identity)
+            stack.push_kept(std::move(last), hscratch);
     }
 
     out->topo = d.topo;

@@ -69,6 +69,7 @@ SIGNATURES = {
     "lvbhost_reroot_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "lvbhost_tree_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "lvbhost_tree_topology_hash": (C.c_uint64, [C.c_void_p]),
+    "lvbhost_tree_canonical": (C.c_int32, [C.c_void_p, _i32p, C.c_int32]),
     "lvbhost_tree_best_count": (C.c_int32, [C.c_void_p]),
     "lvbhost_tree_best_kept": (C.c_int32, [C.c_void_p]),
     "lvbhost_tree_best_get": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.POINTER(C.c_int32)]),
@@ -292,6 +293,14 @@ class HostTree:
 
     def topology_hash(self) -> int:
         return int(self.lib.lvbhost_tree_topology_hash(self.h))
+
+    def canonical(self) -> tuple:
+        """Exact, rooting- and numbering-independent form of the topology (preorder from taxon 0)."""
+        buf = np.zeros(2 * self.nbranches + 4, dtype=np.int32)
+        k = self.lib.lvbhost_tree_canonical(self.h, buf, len(buf))
+        if k < 0:
+            raise api.LvbGpuError(k, "canonical")
+        return tuple(int(x) for x in buf[:k])
 
     def best_count(self) -> int:
         return int(self.lib.lvbhost_tree_best_count(self.h))

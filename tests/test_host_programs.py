@@ -159,12 +159,25 @@ def test_topology_hash_identifies_unrooted_topologies(host):
     that led there; different topologies differ."""
     n = 14
     tree = host.HostTree(n, seed=21)
-    seen = {}
+    seen, canon = {}, {}
+    rng = np.random.default_rng(5)
     for step in range(400):
         _, l, r = tree.arrays()
         key = helpers.splits_of(l, r, tree.root, n)
         h = tree.topology_hash()
         assert seen.setdefault(key, h) == h
+        # the exact identity behind the hash: one canonical form per bipartition set, whatever the root ...
+        c = tree.canonical()
+        assert canon.setdefault(key, c) == c and len(c) == 2 * n - 3
+        assert sorted(x for x in c if x >= 0) == list(range(1, n)) and c.count(-1) == n - 2
+        # ... and whatever the numbering of the internal nodes
+        perm = np.arange(2 * n - 3)
+        perm[n:] = n + rng.permutation(n - 3)
+        l2, r2 = np.full(2 * n - 3, -1, np.int32), np.full(2 * n - 3, -1, np.int32)
+        for v in range(2 * n - 3):
+            if l[v] >= 0:
+                l2[perm[v]], r2[perm[v]] = perm[r[v]], perm[l[v]]          # children swapped as well
+        assert host.HostTree(left=l2, right=r2, root=tree.root).canonical() == c
         if step % 5 == 4:
             new_root = (tree.root + 3) % n
             tree.apply(tree.reroot_edits(new_root), new_root)
@@ -174,4 +187,5 @@ def test_topology_hash_identifies_unrooted_topologies(host):
         else:
             tree.apply(tree.propose(step % 3))
     assert len(set(seen.values())) == len(seen) > 100
+    assert len(set(canon.values())) == len(canon) == len(seen)      # different topologies, different forms
 
