@@ -270,6 +270,7 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
         bt->len_zeroed = false;
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     bt->full_mode = job.full;
+    bt->topo_version = ctx->topo_version;
     bt->stats.candidates = B;
     bt->stats.combines = (int64_t)ndst;
     bt->stats.rows_read = (int64_t)ntok;
@@ -311,6 +312,10 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
 {
     if (!ctx || !b || b->ctx != ctx)
         return LVBGPU_E_ARG;
+    // candidates are rewrites of ONE resident tree: a batch kept across a commit would be scored against rows
+    // that no longer mean what its programs assume (whole-topology batches read leaf rows only and stay valid)
+    if (!b->full_mode && b->topo_version != ctx->topo_version)
+        return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since this batch was built");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!b->len_zeroed) // the whole buffer: a direct step's last wave re-zeroes only the B slots it used
         HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->recycled ? b->d_len.cap : (size_t)b->B * 8, ctx->stream));

@@ -440,11 +440,13 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
         const bool in_place = total * ngroups <= DIRECT_READ_MAX_BYTES;
         if (!in_place)
             HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)(ctx->nb + 1) * 8));
-        if (!ctx->tmp_changes_zeroed)
+        // one accumulator per combine of the program (<= nb + 1); "cleared" is a property of the allocation, so it
+        // is the capacity that is remembered, not a flag that could outlive a buffer that grew
+        HIPCHK(ctx, ctx->d_tmp_changes.reserve(std::max((size_t)(ctx->nb + 1), prog.dsts.size()) * 8));
+        if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
         {
             HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
-            ctx->tmp_changes_zeroed = true;
+            ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
         }
         WalkArgs a = resident_args(ctx, in_place ? (const void *)h : dprog.p, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
         a.s_all_out = (unsigned long long *)ctx->d_scalars;

@@ -182,6 +182,7 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     bt->off_toks = o_t;
     bt->off_dsts = o_d;
     bt->full_mode = false;
+    bt->topo_version = ctx->topo_version;
     bt->stats = lvbgpu_batch_stats{};
     bt->stats.candidates = B;
     bt->stats.max_stack = 1; // at most one sibling set waits while the other path is walked

@@ -183,7 +183,7 @@ struct lvbgpu_ctx
     bool direct_steps = true; // env LVBGPU_DIRECT_STEPS=0 turns them off (A/B measurements)
     bool lpt_order = true;    // env LVBGPU_LPT=0: keep big batches in the caller's order on the device
     DevBuf d_tmp_changes;     // fused commits: per-combine accumulators, zero between launches
-    bool tmp_changes_zeroed = false;
+    size_t tmp_changes_zeroed_cap = 0; // capacity of d_tmp_changes when it was last cleared (0: never)
     DevBuf d_cin, d_cout; // strict-compat arenas
     PinBuf h_cin, h_cout;
     std::vector<int32_t> slot_of;
@@ -244,6 +244,7 @@ struct lvbgpu_batch
     bool direct = false;     // this step's lengths come back through the walk's last wave (no copy, no stream wait)
     bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
     bool launched = false;   // lengths exist (or are on their way)
+    uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)
     std::vector<int32_t> slot_of; // big batches: candidate b sits at position slot_of[b] (longest program first)
 };
 

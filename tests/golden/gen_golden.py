@@ -126,9 +126,23 @@ def generate(name: str, rr: ob.RefRun, n_trees: int, n_moves: int, store_sets: b
     print(f"{name}: n={rr.n} m={rr.m} nwords={rr.nwords} cases={len(out['kind'])} -> {path.stat().st_size} bytes")
 
 
+# regenerated from a seed: cfg2, cfg3 and cfg5 of BASELINE.json (the last: seeds, topologies, lengths, per-node
+# changes and set checksums of one start tree and two rounds of NNI / SPR / TBR at the HBM-resident size)
+SYNTH = [(64, 10000, 6, 2, 12, 4), (500, 50000, 3, 1, 9, 8), (2000, 200000, 9, 1, 6, 0)]
+
+
 def main():
     if ob.load_ref() is None:
         raise SystemExit("needs /root/reference (oracle/_ref/liblvbref.so)")
+    only = set(sys.argv[1:])  # e.g. `gen_golden.py synth_2000x200000` regenerates just that file
+    if only:
+        for (n, m, seed, trees, moves, thr) in SYNTH:
+            if f"synth_{n}x{m}" in only:
+                rr = ob.RefRun(rows=synth.treelike_rows(n, m, seed), seed=seed)
+                generate(f"synth_{n}x{m}", rr, n_trees=trees, n_moves=moves, store_sets=False, store_text=False,
+                         synth_params=(n, m, seed), threads=thr)
+                rr.close()
+        return
     # 1. the reference's own test alignments, read by the reference's own reader
     for f in sorted(REFTESTS.glob("*.phy")):
         big = f.stat().st_size > 60000
@@ -145,7 +159,7 @@ def main():
         generate(f"edge_m{m}", rr, n_trees=3, n_moves=9, store_sets=True, store_text=True)
         rr.close()
     # 3. mid-size shapes: regenerated from a seed (checksum stored), lengths/changes/crc only
-    for (n, m, seed, trees, moves, thr) in [(64, 10000, 6, 2, 12, 4), (500, 50000, 3, 1, 9, 8)]:
+    for (n, m, seed, trees, moves, thr) in SYNTH:
         rows = synth.treelike_rows(n, m, seed)
         rr = ob.RefRun(rows=rows, seed=seed)
         generate(f"synth_{n}x{m}", rr, n_trees=trees, n_moves=moves, store_sets=False, store_text=False,

@@ -83,5 +83,10 @@ def test_lengths_before_launch_is_a_state_error_and_batches_may_outlive_their_co
     assert ei.value.status == -5
     b.launch()
     assert (b.lengths() > 0).all()
+    e = tree.propose(0)
+    ctx.commit(e)                            # the batch's candidates were neighbours of the tree before this
+    with pytest.raises(api.LvbGpuError) as ei:
+        b.launch()
+    assert ei.value.status == -5 and "changed" in str(ei.value)
     ctx.close()
     b.free()                                 # detached by lvbgpu_destroy: frees its own buffers only

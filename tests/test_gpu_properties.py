@@ -121,3 +121,36 @@ def test_reference_sample_at_cfg3(mods):
         ctx.close()
     finally:
         rr.close()
+
+
+def test_reference_sample_at_cfg5(mods):
+    """A thin slice of cfg5 (2000 x 200 000, TBR: the HBM-resident size, 401 MB of state sets) against the real
+    reference: the full evaluation of its start tree, eight TBR neighbours scored from edits, then one accepted
+    and its per-node changes compared.  (Further cfg5 parity: golden synth_2000x200000 and the properties above.)"""
+    from oracle import binding as ob
+    if ob.load_ref() is None:
+        pytest.skip("oracle/_ref/liblvbref.so did not travel")
+    api, host = mods
+    n, m = 2000, 200000
+    rr = ob.RefRun(rows=synth.treelike_rows(n, m, 37), seed=41)
+    try:
+        ctx = api.FitchContext(text_rows=rr.rows())
+        _, cl, cr, _, _ = rr.tree(0)
+        assert ctx.set_tree(cl.astype(np.int32), cr.astype(np.int32), rr.root(0)) == rr.getplen(0)
+        assert np.array_equal(ctx.changes()[n:], rr.tree(0)[3][n:])
+        cands, expect = [], []
+        for b in range(8):
+            rr.mutate(2)
+            _, nl, nr, _, _ = rr.tree(1)
+            cands.append(api.edits_between(cl, cr, nl, nr))
+            expect.append(rr.getplen(1))
+        assert np.array_equal(ctx.score_batch(cands), np.array(expect))
+        # the last one accepted on both sides (SwapTrees / lvbgpu_commit): same bookkeeping afterwards
+        rr.swap()
+        assert ctx.commit(cands[-1]) == expect[-1]
+        assert np.array_equal(ctx.changes()[n:], rr.tree(0)[3][n:])
+        for v in (n, n + 777, 2 * n - 4):
+            assert np.array_equal(ctx.sets(v), rr.sets(0, v))
+        ctx.close()
+    finally:
+        rr.close()
