@@ -104,6 +104,15 @@ void lvbgpu_destroy(lvbgpu_ctx *ctx);
 long lvbgpu_n(const lvbgpu_ctx *ctx);
 long lvbgpu_nwords(const lvbgpu_ctx *ctx);
 
+/* ---- several resident trees (chains) in one context --------------------------------------
+ * Independent annealing chains on one GPU share the alignment: lvbgpu_set_chains(ctx, R) gives the context R
+ * tree slots (state sets of the leaves once, R blocks of internal node sets; any resident tree is dropped),
+ * lvbgpu_select_chain says which slot the single-tree calls below (set_tree, score_batch, commit,
+ * propose_score, current_length, get_*) mean.  A fresh context has one slot, selected. */
+int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains); /* 1 .. 64 */
+int lvbgpu_select_chain(lvbgpu_ctx *ctx, int32_t chain);
+int32_t lvbgpu_chains(const lvbgpu_ctx *ctx);
+
 /* ---- resident current tree ------------------------------------------------------------ */
 /* Full evaluation (every internal node recomputed: getplen's all-dirty case after ss_init /
  * lvb_reroot, TreeEvaluation.c:204-264) of the tree given by child arrays of 2n-3 entries;

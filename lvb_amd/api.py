@@ -53,6 +53,9 @@ SIGNATURES = {
     "lvbgpu_destroy": (None, [C.c_void_p]),
     "lvbgpu_n": (C.c_long, [C.c_void_p]),
     "lvbgpu_nwords": (C.c_long, [C.c_void_p]),
+    "lvbgpu_set_chains": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lvbgpu_select_chain": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lvbgpu_chains": (C.c_int32, [C.c_void_p]),
     "lvbgpu_set_tree": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int32, C.POINTER(C.c_int64)]),
     "lvbgpu_current_length": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "lvbgpu_get_topology": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, C.POINTER(C.c_int32)]),
@@ -209,6 +212,13 @@ class FitchContext:
             self.close()
         except Exception:
             pass
+
+    # ---- several resident trees (chains)
+    def set_chains(self, nchains: int) -> None:
+        self._chk(self.lib.lvbgpu_set_chains(self.h, int(nchains)))
+
+    def select_chain(self, chain: int) -> None:
+        self._chk(self.lib.lvbgpu_select_chain(self.h, int(chain)))
 
     # ---- resident tree
     def set_tree(self, left, right, root: int) -> int:

@@ -113,7 +113,7 @@ void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const 
         cd.ntok = (uint32_t)(w.prog.toks.size() - tok0);
         cd.dst_off = (uint32_t)dst0;
         cd.ncomb = (uint32_t)(w.prog.dsts.size() - dst0);
-        cd.flags = CAND_RESIDENT_BASE;
+        cd.flags = CAND_RESIDENT_BASE | ((uint32_t)ctx->chain << CAND_CHAIN_SHIFT);
         for (size_t i = tok0; i < w.prog.toks.size(); i++)
             cd.nfresh += (w.prog.toks[i] & TOK_FRESH) ? 1u : 0u;
         w.cands.push_back(cd);
@@ -271,6 +271,7 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     bt->full_mode = job.full;
     bt->topo_version = ctx->topo_version;
+    bt->chain = ctx->chain;
     bt->stats.candidates = B;
     bt->stats.combines = (int64_t)ndst;
     bt->stats.rows_read = (int64_t)ntok;
@@ -314,7 +315,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         return LVBGPU_E_ARG;
     // candidates are rewrites of ONE resident tree: a batch kept across a commit would be scored against rows
     // that no longer mean what its programs assume (whole-topology batches read leaf rows only and stay valid)
-    if (!b->full_mode && b->topo_version != ctx->topo_version)
+    if (!b->full_mode && (b->chain >= ctx->nchains || b->topo_version != ctx->version_of(b->chain)))
         return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since this batch was built");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!b->len_zeroed) // the whole buffer: a direct step's last wave re-zeroes only the B slots it used

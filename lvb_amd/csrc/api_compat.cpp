@@ -122,6 +122,8 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     a.root_slot = n_out;
     a.in_stride4 = Wp / 2;
     a.nrows = n_in; // rows of this call's staging block
+    a.bias_from = UINT32_MAX; // tokens name staging slots, not nodes of a resident tree
+    a.chain_rows = 0;
     a.out_stride4 = Wp / 2;
     a.B = 1;
     a.ntiles = ctx->ntiles;

@@ -42,14 +42,16 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const void *prog, size_t off_toks, size_
     a.len_out = (unsigned long long *)d_len;
     a.changes_out = ctx->d_changes;
     a.in_stride4 = ctx->stride4;
-    a.nrows = (uint32_t)ctx->nb;
+    a.nrows = ctx->rows_total();
+    a.bias_from = (uint32_t)ctx->n;
+    a.chain_rows = ctx->chain_rows();
     a.out_stride4 = ctx->stride4;
     a.B = B;
     a.ntiles = ctx->ntiles;
     a.ngroups = choose_groups(B, ctx->ntiles, ctx->target_waves);
     a.nitems = B * a.ngroups;
     a.stack_depth = (uint32_t)std::max(max_stack, 1);
-    a.root_slot = (uint32_t)ctx->nb;
+    a.root_slot = ctx->rows_total(); // + the candidate's chain
     return a;
 }
 
@@ -87,10 +89,13 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)ctx->nb * ctx->stride_words * 8));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_changes, (size_t)(ctx->nb + 1) * 8));
+    ctx->nchains = 1;
+    ctx->chain = 0;
+    ctx->parked.assign(1, ChainSlot{});
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)ctx->rows_total() * ctx->stride_words * 8));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_changes, (size_t)(ctx->rows_total() + ctx->nchains) * 8));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_scalars, 4 * 8)); // [2]: finished-wave count of direct steps
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->rows_total() + ctx->nchains) * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_scalars, 0, 32, ctx->stream));
     HIPCHK(ctx, ctx->h_step.reserve(64));
     memset(ctx->h_step.p, 0, 64);
@@ -111,7 +116,7 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
 // from the reference's nibble layout to the device's bit-plane layout (all-ones stays all-ones)
 int finish_rows(lvbgpu_ctx *ctx)
 {
-    HIPCHK(ctx, launch_fill_pad(ctx->d_rows, (uint32_t)ctx->nb, (uint32_t)ctx->nwords, ctx->stride_words,
+    HIPCHK(ctx, launch_fill_pad(ctx->d_rows, ctx->rows_total(), (uint32_t)ctx->nwords, ctx->stride_words,
                                 (uint32_t)ctx->n, ctx->stream));
     HIPCHK(ctx, launch_relayout((uint4 *)ctx->d_rows, (uint32_t)ctx->n, ctx->stride4, true, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -371,8 +376,8 @@ int read_current_length(lvbgpu_ctx *ctx)
         return LVBGPU_OK;
     // length = S_all (kept current by every commit) + the root slot of changes[]
     long long s_all = 0, root_changes = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&s_all, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&root_changes, ctx->d_changes + ctx->nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&s_all, ctx->scalars(), 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&root_changes, ctx->d_changes + ctx->root_slot(), 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cur_length = s_all + root_changes;
     ctx->cur_length_stale = false;
@@ -387,7 +392,7 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
     if (rc != LVBGPU_OK)
         return rc;
     Packed pk;
-    pk.add(prog, 0, 0, 0, 0);
+    pk.add(prog, 0, 0, 0, (uint32_t)ctx->chain << CAND_CHAIN_SHIFT);
     // the program goes through one of a few pinned slots, each guarded by an event, so the host
     // never waits for the device here
     const size_t o_t = align16(sizeof(CandDesc));
@@ -413,10 +418,12 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
         HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_len.p, 0, 8, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes, 0, (size_t)(ctx->nb + 1) * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes + ctx->row_of((int32_t)ctx->n), 0, (size_t)ctx->chain_rows() * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_changes + ctx->root_slot(), 0, 8, ctx->stream));
         WalkArgs a = resident_args(ctx, dprog.p, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
         HIPCHK(ctx, launch_walk(a, true, ctx->stream));
-        HIPCHK(ctx, launch_sum_changes(ctx->d_changes, (uint32_t)ctx->n, (uint32_t)ctx->nb, ctx->d_scalars, ctx->stream));
+        HIPCHK(ctx, launch_sum_changes(ctx->d_changes, ctx->row_of((int32_t)ctx->n), ctx->row_of((int32_t)ctx->n) + ctx->chain_rows(),
+                                       ctx->root_slot(), ctx->scalars(), ctx->stream));
     }
     else if (!ctx->direct_steps)
     {
@@ -425,11 +432,11 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
         HIPCHK(ctx, hipMemcpyAsync(dprog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->commit_ev[slot], ctx->stream));
         HIPCHK(ctx, launch_zero_changes((unsigned long long *)ctx->d_changes, (const int32_t *)((const char *)dprog.p + o_d),
-                                        (uint32_t)prog.dsts.size(), (unsigned long long *)ctx->d_changes + ctx->nb,
-                                        (unsigned long long *)ctx->d_len.p, (unsigned long long *)ctx->d_scalars,
-                                        ctx->stream));
+                                        (uint32_t)prog.dsts.size(), (unsigned long long *)ctx->d_changes + ctx->root_slot(),
+                                        (unsigned long long *)ctx->d_len.p, (unsigned long long *)ctx->scalars(),
+                                        (uint32_t)ctx->n, (uint32_t)ctx->chain * ctx->chain_rows(), ctx->stream));
         WalkArgs a = resident_args(ctx, dprog.p, o_t, o_d, ctx->d_len.p, 1, prog.max_stack);
-        a.s_all_out = (unsigned long long *)ctx->d_scalars; // the walk adds the new counts: S_all stays current
+        a.s_all_out = (unsigned long long *)ctx->d_scalars; // the walk adds the new counts (to its chain's slot): S_all stays current
         HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     }
     else
@@ -460,6 +467,104 @@ int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool
 }
 } // namespace lvbgpu_detail
 
+namespace lvbgpu_detail
+{
+// the selected chain's state lives in the context's own fields: put it away / fetch another
+void park_chain(lvbgpu_ctx *ctx)
+{
+    ChainSlot &s = ctx->parked[(size_t)ctx->chain];
+    s.topo = std::move(ctx->topo);
+    s.topo_version = ctx->topo_version;
+    s.have_tree = ctx->have_tree;
+    s.cur_length = ctx->cur_length;
+    s.cur_length_stale = ctx->cur_length_stale;
+    s.d_topo_version = ctx->d_topo_version;
+    s.gen_table_bytes = ctx->gen_table_bytes;
+    s.gen_K = ctx->gen_K;
+}
+void unpark_chain(lvbgpu_ctx *ctx, int32_t c)
+{
+    ChainSlot &s = ctx->parked[(size_t)c];
+    ctx->chain = c;
+    ctx->topo = std::move(s.topo);
+    ctx->topo_version = s.topo_version;
+    ctx->have_tree = s.have_tree;
+    ctx->cur_length = s.cur_length;
+    ctx->cur_length_stale = s.cur_length_stale;
+    ctx->d_topo_version = s.d_topo_version;
+    ctx->gen_table_bytes = s.gen_table_bytes;
+    ctx->gen_K = s.gen_K;
+}
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
+{
+    if (!ctx || nchains < 1 || nchains > MAX_CHAINS)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((uint64_t)(ctx->n + (long)nchains * (ctx->n - 3)) >= (uint64_t)MAX_ROWS)
+        return ctx->fail(LVBGPU_E_ARG, "too many rows for the token format");
+    // new blocks: leaf rows move over, every tree slot starts empty (all-ones rows, no resident tree)
+    const int32_t old_chains = ctx->nchains;
+    uint64_t *rows = nullptr;
+    unsigned long long *changes = nullptr;
+    long long *scalars = nullptr;
+    ctx->nchains = nchains;
+    const size_t row_bytes = (size_t)ctx->stride_words * 8;
+    hipError_t e = hipMalloc((void **)&rows, (size_t)ctx->rows_total() * row_bytes);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&changes, (size_t)(ctx->rows_total() + nchains) * 8);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&scalars, (size_t)nchains * 32);
+    if (e != hipSuccess)
+    {
+        ctx->nchains = old_chains;
+        (void)hipFree(rows);
+        (void)hipFree(changes);
+        (void)hipFree(scalars);
+        return ctx->fail_hip(e, "lvbgpu_set_chains: allocate");
+    }
+    HIPCHK(ctx, hipMemcpyAsync(rows, ctx->d_rows, (size_t)ctx->n * row_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(rows + (size_t)ctx->n * ctx->stride_words, 0xFF, (size_t)(ctx->rows_total() - ctx->n) * row_bytes,
+                               ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(changes, 0, (size_t)(ctx->rows_total() + nchains) * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(scalars, 0, (size_t)nchains * 32, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_rows);
+    (void)hipFree(ctx->d_changes);
+    (void)hipFree(ctx->d_scalars);
+    ctx->d_rows = rows;
+    ctx->d_changes = changes;
+    ctx->d_scalars = scalars;
+    ctx->parked.assign((size_t)nchains, ChainSlot{});
+    ctx->chain = 0;
+    ctx->topo = Topology{};
+    ctx->topo_version = ++ctx->version_counter;
+    ctx->have_tree = false;
+    ctx->cur_length = 0;
+    ctx->cur_length_stale = false;
+    ctx->d_topo_version = ~0ull;
+    ctx->p_B = 0;
+    ctx->tmp_changes_zeroed_cap = 0;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_select_chain(lvbgpu_ctx *ctx, int32_t chain)
+{
+    if (!ctx || chain < 0 || chain >= ctx->nchains)
+        return LVBGPU_E_ARG;
+    if (chain != ctx->chain)
+    {
+        park_chain(ctx);
+        unpark_chain(ctx, chain);
+        ctx->p_B = 0; // the device batch of the last propose call belonged to the other chain's tree
+    }
+    return LVBGPU_OK;
+}
+
+extern "C" int32_t lvbgpu_chains(const lvbgpu_ctx *ctx) { return ctx ? ctx->nchains : 0; }
+
 extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32_t *right, int32_t root,
                                int64_t *length_out)
 {
@@ -471,7 +576,7 @@ extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32
     if (!t.assign((int32_t)ctx->n, left, right, root, &why))
         return ctx->fail(LVBGPU_E_TOPOLOGY, why);
     ctx->topo = std::move(t);
-    ctx->topo_version++;
+    ctx->topo_version = ++ctx->version_counter;
     ctx->have_tree = false;
     Program prog;
     ctx->pb.build_full(ctx->topo, prog);
@@ -524,7 +629,9 @@ extern "C" int lvbgpu_get_changes(lvbgpu_ctx *ctx, int64_t *changes)
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(changes, ctx->d_changes, (size_t)ctx->nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+    memset(changes, 0, (size_t)ctx->n * 8); // leaves hold nothing
+    HIPCHK(ctx, hipMemcpyAsync(changes + ctx->n, ctx->d_changes + ctx->row_of((int32_t)ctx->n), (size_t)ctx->chain_rows() * 8,
+                               hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return LVBGPU_OK;
 }
@@ -538,7 +645,7 @@ extern "C" int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // resident rows are bit planes; hand back the reference's nibble layout
     HIPCHK(ctx, ctx->d_export.reserve((size_t)ctx->stride_words * 8));
-    HIPCHK(ctx, launch_export_row((const uint4 *)(ctx->d_rows + (size_t)node * ctx->stride_words),
+    HIPCHK(ctx, launch_export_row((const uint4 *)(ctx->d_rows + (size_t)ctx->row_of(node) * ctx->stride_words),
                                   (uint4 *)ctx->d_export.p, ctx->stride4, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_export.p, (size_t)ctx->nwords * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -561,7 +668,7 @@ extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit
         return ctx->fail(LVBGPU_E_TOPOLOGY, why);
     if (!ctx->pb.apply_edits(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, &why))
         return ctx->fail(LVBGPU_E_TOPOLOGY, why);
-    ctx->topo_version++;
+    ctx->topo_version = ++ctx->version_counter;
     // length_out == NULL: the caller knows the length (it scored this candidate): nothing is
     // read back and nothing waits - the commit is ordered before later work on the stream
     int rc = run_commit_program(ctx, prog, false, length_out != nullptr);
@@ -665,12 +772,12 @@ extern "C" int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave
     {
         uint64_t loads = 0;
         for (int i = 0; i < 3; i++) // warm the caches and the clocks
-            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, (uint32_t)ctx->nb, ctx->ntiles, ngroups,
+            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, ctx->rows_total(), ctx->ntiles, ngroups,
                                         (uint32_t)B, (uint32_t)rows_per_wave, ring, (uint4 *)ctx->d_probe_sink.p, &loads,
                                         ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         for (int i = 0; i < reps; i++)
-            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, (uint32_t)ctx->nb, ctx->ntiles, ngroups,
+            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, ctx->rows_total(), ctx->ntiles, ngroups,
                                         (uint32_t)B, (uint32_t)rows_per_wave, ring, (uint4 *)ctx->d_probe_sink.p, &loads,
                                         ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));

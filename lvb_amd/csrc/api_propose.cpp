@@ -86,11 +86,26 @@ int sync_device_topology(lvbgpu_ctx *ctx)
         ctx->gen_idx_bytes = 4;
     }
     bytes &= ~(size_t)15; // whole 16-byte pieces (the arrays end 8 elements before the vector does)
-    HIPCHK(ctx, ctx->d_topo4.reserve(bytes));
+    // one slot per chain, wide enough for the deepest tree these taxa can form (K <= bits of 2n-3)
+    {
+        int32_t kmax = 1;
+        while ((1 << kmax) <= nb)
+            kmax++;
+        const size_t widest = ((7 + (size_t)kmax) * (size_t)nb + (size_t)ctx->n + 8) * ctx->gen_idx_bytes;
+        ctx->gen_table_stride = (uint32_t)((widest + 255) & ~(size_t)255);
+    }
+    if (bytes > ctx->gen_table_stride)
+        return ctx->fail(LVBGPU_E_ARG, "generator tables exceed their slot");
+    const size_t old_cap = ctx->d_topo4.cap;
+    HIPCHK(ctx, ctx->d_topo4.reserve((size_t)ctx->nchains * ctx->gen_table_stride));
+    if (ctx->d_topo4.cap != old_cap) // a new buffer holds no chain's tables
+        for (ChainSlot &cs : ctx->parked)
+            cs.d_topo_version = ~0ull;
     HIPCHK(ctx, ctx->h_topo.reserve(bytes));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // an upload still reading the staging buffer
     memcpy(ctx->h_topo.p, src, bytes);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_topo4.p, ctx->h_topo.p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + (size_t)ctx->chain * ctx->gen_table_stride, ctx->h_topo.p, bytes,
+                               hipMemcpyHostToDevice, ctx->stream));
     ctx->gen_table_bytes = (uint32_t)bytes;
     ctx->gen_K = K;
     ctx->d_topo_version = ctx->topo_version;
@@ -183,6 +198,7 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     bt->off_dsts = o_d;
     bt->full_mode = false;
     bt->topo_version = ctx->topo_version;
+    bt->chain = ctx->chain;
     bt->stats = lvbgpu_batch_stats{};
     bt->stats.candidates = B;
     bt->stats.max_stack = 1; // at most one sibling set waits while the other path is walked
@@ -235,7 +251,8 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
         }
     }
     GenArgs ga{};
-    ga.tables = ctx->d_topo4.p;
+    ga.tables = (const char *)ctx->d_topo4.p + (size_t)ctx->chain * ctx->gen_table_stride;
+    ga.chain = (uint32_t)ctx->chain;
     ga.table_bytes = ctx->gen_table_bytes;
     ga.idx_bytes = ctx->gen_idx_bytes;
     ga.n = (int32_t)ctx->n;

@@ -128,6 +128,20 @@ struct Rccl
 
 using namespace lvbgpu_detail;
 
+// what belongs to ONE resident tree (a chain).  The selected chain's copy lives in the context's own fields
+// (topo, topo_version, have_tree, ...); the others wait in lvbgpu_ctx::parked until lvbgpu_select_chain swaps them in.
+struct ChainSlot
+{
+    Topology topo;
+    uint64_t topo_version = 0;
+    bool have_tree = false;
+    int64_t cur_length = 0;
+    bool cur_length_stale = false;
+    uint64_t d_topo_version = ~0ull;
+    uint32_t gen_table_bytes = 0;
+    int32_t gen_K = 1;
+};
+
 struct lvbgpu_ctx
 {
     int device = 0;
@@ -138,9 +152,22 @@ struct lvbgpu_ctx
     uint32_t stride_words = 0, stride4 = 0, ntiles = 0;
     uint32_t target_waves = TARGET_WAVES; // tuning knob (env LVBGPU_TARGET_WAVES)
 
-    uint64_t *d_rows = nullptr;              // [nb][stride_words]
-    unsigned long long *d_changes = nullptr; // [nb + 1]; slot nb = the two root combines
-    long long *d_scalars = nullptr;          // [0] S_all, [1] current length
+    // several resident trees (chains) in one context: they share the leaf rows, chain c's internal node v (>= n)
+    // has its row and its change slot at v + c (n - 3); lvbgpu_set_chains sizes the buffers, lvbgpu_select_chain
+    // says which tree the single-tree calls mean (chain 0 by default)
+    int32_t nchains = 1, chain = 0;
+    std::vector<ChainSlot> parked;           // [nchains]; entry `chain` is stale while that chain is selected
+    uint64_t version_counter = 0;            // topology versions are unique across chains (workers key copies on them)
+    uint32_t rows_total() const { return (uint32_t)(n + (long)nchains * (n - 3)); }
+    uint32_t chain_rows() const { return (uint32_t)(n - 3); }
+    uint32_t row_of(int32_t v) const { return v < n ? (uint32_t)v : (uint32_t)(v + (long)chain * (n - 3)); }
+    uint32_t root_slot() const { return rows_total() + (uint32_t)chain; }
+    long long *scalars() const { return d_scalars + 4 * (size_t)chain; }
+    uint64_t version_of(int32_t c) const { return c == chain ? topo_version : parked[(size_t)c].topo_version; }
+
+    uint64_t *d_rows = nullptr;              // [rows_total][stride_words]
+    unsigned long long *d_changes = nullptr; // [rows_total + nchains]; the last nchains slots = the chains' two root combines
+    long long *d_scalars = nullptr;          // per chain 4: [0] S_all, [1] current length; [2] of chain 0: finished-wave count
     bool have_tree = false;
     int64_t cur_length = 0;
 
@@ -164,7 +191,8 @@ struct lvbgpu_ctx
     lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
     // device-side proposals (lvbgpu_propose_score)
     lvbgpu_batch *prop_batch = nullptr;
-    DevBuf d_topo4, d_pedits, d_pinfo; // d_topo4: the generator's tables of the resident topology (GenArgs)
+    DevBuf d_topo4, d_pedits, d_pinfo; // d_topo4: the generator's tables of the resident topologies, gen_table_stride each
+    uint32_t gen_table_stride = 0;
     PinBuf h_pinfo, h_topo;
     std::vector<uint16_t> gen_tab16;
     std::vector<int32_t> gen_tab32;
@@ -245,6 +273,7 @@ struct lvbgpu_batch
     bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
     bool launched = false;   // lengths exist (or are on their way)
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)
+    int32_t chain = 0;         // ... and which chain's tree that is
     std::vector<int32_t> slot_of; // big batches: candidate b sits at position slot_of[b] (longest program first)
 };
 

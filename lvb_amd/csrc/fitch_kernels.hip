@@ -166,6 +166,10 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
 
     const CandDesc cd = a.cands[cand];
+    // which resident tree: node numbers from bias_from on (the internal nodes) move by the chain's row block
+    const uint32_t chain = cd.flags >> CAND_CHAIN_SHIFT;
+    const uint32_t row_bias = chain * a.chain_rows;
+    auto biased = [&](uint32_t v) { return v >= a.bias_from ? v + row_bias : v; };
     const uint32_t *__restrict__ tk = a.toks + cd.tok_off;
     const int32_t *__restrict__ ds = a.dsts + cd.dst_off;
     uint32_t col = tile_begin * 64u + lane;          // 16-byte group within a row
@@ -205,9 +209,9 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
             atomicAdd(a.tmp_changes + k, (unsigned long long)s); // settled by the launch's last wave
         else
         {
-            atomicAdd(a.changes_out + (dst >= 0 ? (uint32_t)dst : a.root_slot), (unsigned long long)s);
+            atomicAdd(a.changes_out + (dst >= 0 ? biased((uint32_t)dst) : a.root_slot + chain), (unsigned long long)s);
             if (dst >= 0 && a.s_all_out)
-                atomicAdd(a.s_all_out, (unsigned long long)s); // S_all follows the commit: no separate summing pass
+                atomicAdd(a.s_all_out + 4u * chain, (unsigned long long)s); // S_all follows the commit: no separate summing pass
         }
     };
     // write out what waits in LDS: destinations fetched with one vector load BEFORE the first store, so the
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         {
             const int32_t dst = __builtin_amdgcn_readlane(mydst, (int)s);
             if (dst >= 0)
-                a.rows_out[(size_t)dst * a.out_stride4 + col] = my_rows[(size_t)s * 64u];
+                a.rows_out[(size_t)biased((uint32_t)dst) * a.out_stride4 + col] = my_rows[(size_t)s * 64u];
         }
         if (mycnt)
             add_count(k_flushed + lane, mydst, mycnt);
@@ -267,9 +271,9 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
         {
             const int32_t dst = ds[i];
             if (dst >= 0)
-                sub_early += a.node_changes[dst];
+                sub_early += a.node_changes[biased((uint32_t)dst)];
         }
-        s_all_early = *a.s_all;
+        s_all_early = a.s_all[4u * chain];
     }
 
     for (uint32_t tile = tile_begin; tile < tile_end; tile++, col += 64u, lane_ptr += 1024)
@@ -286,8 +290,9 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
             // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
             const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
             // that row's offset: bytes in two vectors (WIDE) or 16-byte units in one
-            const uint64_t myoff64 = WIDE ? (uint64_t)(mytok & TOK_ROW_MASK) * ((uint64_t)a.in_stride4 << 4)
-                                          : (uint64_t)((mytok & TOK_ROW_MASK) * a.in_stride4); // bytes | 16-byte units
+            const uint32_t myrow = biased(mytok & TOK_ROW_MASK);
+            const uint64_t myoff64 = WIDE ? (uint64_t)myrow * ((uint64_t)a.in_stride4 << 4)
+                                          : (uint64_t)(myrow * a.in_stride4); // bytes | 16-byte units
             OffVec o0{(uint32_t)myoff64, (uint32_t)(myoff64 >> 32)};
             // the same offsets seen from 1, 2, 3 lanes further down, so that the four refills of a
             // group read lane j of four vectors with ONE scalar index
@@ -480,8 +485,9 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
                     const int32_t dst = ds[i];
                     if (dst >= 0)
                     {
-                        delta += (long long)v - (long long)a.changes_out[dst];
-                        a.changes_out[dst] = v;
+                        const uint32_t slot = biased((uint32_t)dst);
+                        delta += (long long)v - (long long)a.changes_out[slot];
+                        a.changes_out[slot] = v;
                     }
                     else
                         root_changes += v;
@@ -493,8 +499,8 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
                 }
                 if (lane == 0)
                 {
-                    a.changes_out[a.root_slot] = root_changes;
-                    *a.s_all_out += (unsigned long long)delta;
+                    a.changes_out[a.root_slot + chain] = root_changes;
+                    a.s_all_out[4u * chain] += (unsigned long long)delta;
                     __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -539,13 +545,14 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 // ... and S_all gives up what those nodes had contributed (the walk adds the new counts back)
 __global__ void zero_changes_kernel(unsigned long long *changes, const int32_t *dsts, uint32_t n,
                                     unsigned long long *root_slot, unsigned long long *len_slot,
-                                    unsigned long long *s_all)
+                                    unsigned long long *s_all, uint32_t bias_from, uint32_t row_bias)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && dsts[i] >= 0)
     {
-        const unsigned long long old = changes[dsts[i]];
-        changes[dsts[i]] = 0ull;
+        const uint32_t slot = (uint32_t)dsts[i] >= bias_from ? (uint32_t)dsts[i] + row_bias : (uint32_t)dsts[i];
+        const unsigned long long old = changes[slot];
+        changes[slot] = 0ull;
         if (old)
             atomicAdd(s_all, 0ull - old); // two's complement: subtracts
     }
@@ -556,10 +563,10 @@ __global__ void zero_changes_kernel(unsigned long long *changes, const int32_t *
     }
 }
 
-// scalars[0] = sum of changes[first .. last) (all internal nodes); scalars[1] = that + changes[last]
-// (the root combines) = length of the resident tree.  One block.
+// scalars[0] = sum of changes[first .. last) (all internal nodes of one resident tree); scalars[1] = that +
+// changes[root_slot] (the root combines) = length of that tree.  One block.
 __global__ __launch_bounds__(256) void sum_changes_kernel(const unsigned long long *changes, uint32_t first,
-                                                          uint32_t last, long long *scalars)
+                                                          uint32_t last, uint32_t root_slot, long long *scalars)
 {
     __shared__ long long part[4];
     long long s = 0;
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256) void sum_changes_kernel(const unsigned long lo
     {
         const long long all = part[0] + part[1] + part[2] + part[3];
         scalars[0] = all;
-        scalars[1] = all + (long long)changes[last];
+        scalars[1] = all + (long long)changes[root_slot];
     }
 }
 
@@ -840,17 +847,18 @@ hipError_t raise_lds_limit()
 }
 
 hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,
-                               unsigned long long *len_slot, unsigned long long *s_all, hipStream_t stream)
+                               unsigned long long *len_slot, unsigned long long *s_all, uint32_t bias_from, uint32_t row_bias,
+                               hipStream_t stream)
 {
     hipLaunchKernelGGL(zero_changes_kernel, dim3(n ? (n + 255) / 256 : 1), dim3(256), 0, stream, changes, dsts, n, root_slot,
-                       len_slot, s_all);
+                       len_slot, s_all, bias_from, row_bias);
     return hipGetLastError();
 }
 
-hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first, uint32_t last, long long *scalars,
-                              hipStream_t stream)
+hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first, uint32_t last, uint32_t root_slot,
+                              long long *scalars, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sum_changes_kernel, dim3(1), dim3(256), 0, stream, changes, first, last, scalars);
+    hipLaunchKernelGGL(sum_changes_kernel, dim3(1), dim3(256), 0, stream, changes, first, last, root_slot, scalars);
     return hipGetLastError();
 }
 

@@ -24,6 +24,11 @@ constexpr uint32_t MAX_TILES_PER_WAVE = 8;
 // too short, no admissible move): the host turns anything this large into INT64_MAX
 constexpr long long PROPOSAL_OVERFLOW_LENGTH = 1ll << 61;
 constexpr uint32_t CAND_RESIDENT_BASE = 1u;       // base += *s_all - sum(node_changes[dst])
+// CandDesc::flags bits 8..: the CHAIN (resident tree slot) the candidate belongs to.  Programs name nodes by their
+// numbers in ONE tree (0..2n-4); the state sets of several resident trees share the leaf rows and keep their internal
+// rows one block after the other, so the walk turns node v of chain c into row v + c * chain_rows for v >= bias_from.
+constexpr uint32_t CAND_CHAIN_SHIFT = 8;
+constexpr int32_t MAX_CHAINS = 64;
 
 struct CandDesc
 {
@@ -49,6 +54,10 @@ struct WalkArgs
     unsigned long long *s_all_out;      // COMMIT on the resident tree: running sum of all internal changes (may be null)
     uint32_t in_stride4, out_stride4;   // row strides in 16-byte units
     uint32_t nrows;                     // rows addressable through rows_in (picks 32- or 64-bit row offsets)
+    // several resident trees in one block: rows / change slots of node v of chain c sit at v + c * chain_rows for
+    // v >= bias_from (the internal nodes; bias_from = UINT32_MAX turns the mapping off: staging arenas), the root
+    // slot of chain c at root_slot + c, its S_all at s_all[4 c]
+    uint32_t bias_from, chain_rows;
     uint32_t B, ntiles;
     uint32_t ngroups;                   // tiles are dealt to this many groups; one wave walks one (group, candidate)
     uint32_t nitems;                    // B * ngroups
@@ -123,6 +132,7 @@ struct GenArgs
     uint32_t table_bytes, idx_bytes;
     int32_t n, nb, root, K;
     uint32_t leaf_order_len;
+    uint32_t chain; // resident tree slot the candidates belong to (CandDesc::flags)
     int32_t kind_all;
     uint32_t mix_a, mix_b;
     uint64_t seed;
@@ -142,10 +152,11 @@ hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
 hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);
 hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,
-                               unsigned long long *len_slot, unsigned long long *s_all, hipStream_t stream);
-// scalars[0] = sum of changes[first, last), scalars[1] = scalars[0] + changes[last] (tree length)
-hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first, uint32_t last, long long *scalars,
-                              hipStream_t stream);
+                               unsigned long long *len_slot, unsigned long long *s_all, uint32_t bias_from, uint32_t row_bias,
+                               hipStream_t stream);
+// scalars[0] = sum of changes[first, last), scalars[1] = scalars[0] + changes[root_slot] (tree length)
+hipError_t launch_sum_changes(const unsigned long long *changes, uint32_t first, uint32_t last, uint32_t root_slot,
+                              long long *scalars, hipStream_t stream);
 hipError_t launch_fill_pad(uint64_t *rows, uint32_t nrows, uint32_t nwords, uint32_t stride_words,
                            uint32_t first_full_row, hipStream_t stream);
 // reference nibble layout <-> device bit-plane layout, in place, rows [0, nrows)

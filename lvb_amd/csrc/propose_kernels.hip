@@ -515,7 +515,7 @@ __device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const uint32_
         {
             cd.ntok = e.o.ntok;
             cd.ncomb = e.o.ndst;
-            cd.flags = CAND_RESIDENT_BASE;
+            cd.flags = CAND_RESIDENT_BASE | (g.chain << CAND_CHAIN_SHIFT);
             cd.nfresh = e.o.nfresh;
         }
         g.cands[b] = cd;

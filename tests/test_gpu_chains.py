@@ -1,0 +1,86 @@
+"""Several resident trees (chains) in one context: each slot must behave exactly like a context of its own."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from lvb_amd import api, host
+    assert api.device_count() >= 1
+    return api, host
+
+
+@pytest.mark.parametrize("n,m", [(9, 70), (60, 5000)])
+def test_every_chain_slot_equals_a_context_of_its_own(mods, n, m):
+    api, host = mods
+    R = 3
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 51))
+    multi = api.FitchContext(text_rows=rows)
+    multi.set_chains(R)
+    singles = [api.FitchContext(text_rows=rows) for _ in range(R)]
+    trees = [host.HostTree(n, seed=60 + c) for c in range(R)]
+    for c in range(R):
+        multi.select_chain(c)
+        assert trees[c].upload(multi) == trees[c].upload(singles[c])
+    rng = np.random.default_rng(3)
+    for step in range(12):
+        for c in rng.permutation(R):
+            c = int(c)
+            multi.select_chain(c)
+            one = singles[c]
+            assert multi.current_length() == one.current_length()
+            cands = [trees[c].propose(k % 3) for k in range(17)]
+            want = one.score_batch(cands)
+            assert np.array_equal(multi.score_batch(cands), want)
+            # neighbourhoods drawn on the device: same tree, same seed => same moves, same lengths
+            seed = 100 * step + c
+            lens = multi.propose_score(40, -1, seed)
+            assert np.array_equal(lens, one.propose_score(40, -1, seed))
+            b = int(np.argmin(lens))
+            e_multi, info_m = multi.proposal_edits(b)
+            e_one, info_o = one.proposal_edits(b)
+            assert np.array_equal(e_multi, e_one) and np.array_equal(info_m, info_o)
+            # accept on both sides: lengths, per-node changes and node sets stay equal
+            pick = cands[int(np.argmin(want))] if step % 2 else e_multi
+            assert multi.commit(pick) == one.commit(pick)
+            trees[c].apply(pick)
+            assert np.array_equal(multi.changes(), one.changes())
+            for v in (n, n + (n - 3) // 2, 2 * n - 4):
+                assert np.array_equal(multi.sets(v), one.sets(v))
+            if step % 5 == 4:   # a re-root as a commit
+                nr = (trees[c].root + 2) % n
+                ed = trees[c].reroot_edits(nr)
+                assert multi.commit(ed, root=nr) == one.commit(ed, root=nr)
+                trees[c].apply(ed, nr)
+    # the other chains were never disturbed by what happened to one of them
+    for c in range(R):
+        multi.select_chain(c)
+        assert multi.current_length() == singles[c].current_length()
+        assert np.array_equal(multi.all_sets(), singles[c].all_sets())
+        p1, l1, r1, root1 = multi.topology()
+        p2, l2, r2, root2 = singles[c].topology()
+        assert np.array_equal(l1, l2) and np.array_equal(r1, r2) and root1 == root2
+    for s in singles:
+        s.close()
+    multi.close()
+
+
+def test_chain_calls_reject_bad_arguments(mods):
+    api, host = mods
+    rows, _ = host.prepare_alignment(synth.treelike_rows(8, 40, 2))
+    ctx = api.FitchContext(text_rows=rows)
+    for bad in (0, 65):
+        with pytest.raises(api.LvbGpuError):
+            ctx.set_chains(bad)
+    ctx.set_chains(2)
+    with pytest.raises(api.LvbGpuError):
+        ctx.select_chain(2)
+    ctx.select_chain(1)
+    with pytest.raises(api.LvbGpuError) as ei:      # no tree in this slot yet
+        ctx.current_length()
+    assert ei.value.status == -5
+    ctx.close()
