@@ -163,6 +163,32 @@ int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_nni, double 
                                uint64_t seed, int64_t *lengths_out);
 int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits,
                           int32_t *info4);
+/* ---- several chains in one step ----------------------------------------------------------------
+ * What lvbgpu_select_chain + lvbgpu_propose_score* would do chain by chain, in ONE generator launch, ONE walk
+ * and ONE read-back: draws[i] asks for `count` neighbours of chain `chain`'s resident tree (kind as
+ * lvbgpu_propose_score: 0 / 1 / 2, -1 = candidate j gets kind j % 3; -2 = SPR if (mix_a + j) is odd else NNI;
+ * -3 = drawn per candidate, NNI below mix_a, SPR below mix_b, else TBR, thresholds scaled to 2^32).  Candidate j
+ * of a chain is a function of (seed, j) only - the same move, the same length as the single-tree call gives
+ * with that seed.  lengths_out holds the chains' candidates one chain after the other, in the order of draws[].
+ * Chains must be distinct.  An annealing host keeps R independent chains busy with one step's latency. */
+typedef struct
+{
+    int32_t chain, count, kind;
+    uint32_t mix_a, mix_b;
+    uint64_t seed;
+} lvbgpu_chain_draw;
+int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out);
+/* accept candidate `b` (index within its chain's draw of the LAST lvbgpu_chains_propose_score /
+ * lvbgpu_propose_score* call) for each listed chain, at most one per chain: the candidates' own device-built
+ * programs are walked in commit form (one launch for all picks), and the chains' topologies follow (the moves'
+ * rewrites are fetched from the device).  Asynchronous like lvbgpu_commit(.., NULL): the lengths are known
+ * from scoring.  A pick of a candidate that overflowed (INT64_MAX) is LVBGPU_E_ARG. */
+typedef struct
+{
+    int32_t chain, b;
+} lvbgpu_chain_pick;
+int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_pick *picks);
+
 /* counts of the LAST device-built batch (as lvbgpu_batch_get_stats gives for host-built ones; candidates that
  * overflowed are left out): reads the batch's descriptors back - for measurement, not for the search */
 int lvbgpu_proposal_stats(lvbgpu_ctx *ctx, lvbgpu_batch_stats *out);

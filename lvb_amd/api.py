@@ -35,6 +35,9 @@ class BatchStats(C.Structure):
 
 EDIT_DTYPE = np.dtype([("node", np.int32), ("left", np.int32), ("right", np.int32)])
 MOVE_DTYPE = np.dtype([("kind", np.int32), ("a", np.int32), ("b", np.int32), ("c", np.int32)])  # lvbgpu_move
+DRAW_DTYPE = np.dtype([("chain", np.int32), ("count", np.int32), ("kind", np.int32), ("mix_a", np.uint32), ("mix_b", np.uint32),
+                       ("_pad", np.uint32), ("seed", np.uint64)])  # lvbgpu_chain_draw (seed 8-byte aligned)
+PICK_DTYPE = np.dtype([("chain", np.int32), ("b", np.int32)])  # lvbgpu_chain_pick
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
@@ -72,6 +75,8 @@ SIGNATURES = {
     "lvbgpu_propose_score_mixed": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_uint64,
                                             _i64p]),
     "lvbgpu_proposal_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _i32p]),
+    "lvbgpu_chains_propose_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, _i64p]),
+    "lvbgpu_chains_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "lvbgpu_proposal_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
     "lvbgpu_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
@@ -219,6 +224,22 @@ class FitchContext:
 
     def select_chain(self, chain: int) -> None:
         self._chk(self.lib.lvbgpu_select_chain(self.h, int(chain)))
+
+    def chains_propose_score(self, draws) -> list[np.ndarray]:
+        """draws: (chain, count, kind, seed[, mix_a, mix_b]) per chain -> the lengths, one array per draw."""
+        d = np.zeros(len(draws), dtype=DRAW_DTYPE)
+        for i, row in enumerate(draws):
+            d[i]["chain"], d[i]["count"], d[i]["kind"], d[i]["seed"] = row[0], row[1], row[2], row[3]
+            if len(row) > 4:
+                d[i]["mix_a"], d[i]["mix_b"] = row[4], row[5]
+        out = np.zeros(int(d["count"].sum()), dtype=np.int64)
+        self._chk(self.lib.lvbgpu_chains_propose_score(self.h, len(d), d.ctypes.data, out))
+        return np.split(out, np.cumsum(d["count"])[:-1])
+
+    def chains_commit(self, picks) -> None:
+        """picks: (chain, b) - candidate b of that chain's draw in the last chains_propose_score call."""
+        p = np.array([tuple(int(v) for v in row) for row in picks], dtype=PICK_DTYPE)
+        self._chk(self.lib.lvbgpu_chains_commit(self.h, len(p), p.ctypes.data))
 
     # ---- resident tree
     def set_tree(self, left, right, root: int) -> int:

@@ -315,7 +315,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         return LVBGPU_E_ARG;
     // candidates are rewrites of ONE resident tree: a batch kept across a commit would be scored against rows
     // that no longer mean what its programs assume (whole-topology batches read leaf rows only and stay valid)
-    if (!b->full_mode && (b->chain >= ctx->nchains || b->topo_version != ctx->version_of(b->chain)))
+    if (!b->full_mode && !b->spans_chains && (b->chain >= ctx->nchains || b->topo_version != ctx->version_of(b->chain)))
         return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since this batch was built");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!b->len_zeroed) // the whole buffer: a direct step's last wave re-zeroes only the B slots it used

@@ -265,6 +265,13 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->d_pinfo.release();
     ctx->h_pinfo.release();
     ctx->h_topo.release();
+    ctx->d_done.release();
+    for (int i = 0; i < lvbgpu_ctx::PICK_SLOTS; i++)
+    {
+        ctx->h_pick[i].release();
+        if (ctx->pick_ev[i])
+            (void)hipEventDestroy(ctx->pick_ev[i]);
+    }
     ctx->d_moves.release();
     ctx->h_moves.release();
     ctx->h_step.release();
@@ -546,6 +553,7 @@ extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
     ctx->cur_length_stale = false;
     ctx->d_topo_version = ~0ull;
     ctx->p_B = 0;
+    ctx->p_segs.clear();
     ctx->tmp_changes_zeroed_cap = 0;
     return LVBGPU_OK;
 }
@@ -558,7 +566,7 @@ extern "C" int lvbgpu_select_chain(lvbgpu_ctx *ctx, int32_t chain)
     {
         park_chain(ctx);
         unpark_chain(ctx, chain);
-        ctx->p_B = 0; // the device batch of the last propose call belonged to the other chain's tree
+        ctx->p_B = 0; // lvbgpu_proposal_edits names candidates of the selected chain's last batch only
     }
     return LVBGPU_OK;
 }

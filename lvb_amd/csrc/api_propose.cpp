@@ -1,19 +1,57 @@
-// api_propose.cpp - liblvbgpu.so: neighbourhoods whose rewrites and programs are built on the device (drawn there, or named by the host).
+// api_propose.cpp - liblvbgpu.so: neighbourhoods whose rewrites and programs are built on the device (drawn there, or
+// named by the host) - for one resident tree, or for several chains in ONE generator launch and ONE walk.
 #include "ctx.hpp"
-
-// ---- device-side neighbourhoods
 
 namespace lvbgpu_detail
 {
-// the generator's tables of the resident topology (layout: GenArgs in kernels.hpp)
-template <typename IdxT>
-static void fill_tables(const Topology &t, int32_t K, const std::vector<int32_t> &order, const std::vector<int32_t> &depth,
-                        const std::vector<int32_t> &nleaf, std::vector<IdxT> &out)
+void park_chain(lvbgpu_ctx *ctx);
+void unpark_chain(lvbgpu_ctx *ctx, int32_t c);
+
+// Multi-chain calls work on lvbgpu_ctx::parked only: the selected chain's state is put there on entry and taken
+// back on every way out.
+struct AllParked
 {
-    const size_t nb = (size_t)t.nb;
-    const size_t nlo = (size_t)t.n; // leaf_order: n - 1 used
-    out.assign((7 + (size_t)K) * nb + nlo + 8, (IdxT)0);
-    IdxT *parent = out.data(), *left = parent + nb, *right = left + nb, *nl = right + nb, *dep = nl + nb, *tin = dep + nb,
+    lvbgpu_ctx *ctx;
+    int32_t sel;
+    explicit AllParked(lvbgpu_ctx *c) : ctx(c), sel(c->chain) { park_chain(c); }
+    ~AllParked() { unpark_chain(ctx, sel); }
+    AllParked(const AllParked &) = delete;
+    AllParked &operator=(const AllParked &) = delete;
+};
+
+// the generator's tables of one topology (layout: GenArgs in kernels.hpp), written where the upload reads them
+template <typename IdxT>
+static uint32_t fill_tables(const Topology &t, IdxT *out, size_t cap_elems, int32_t *K_out)
+{
+    const size_t nb = (size_t)t.nb, nlo = (size_t)t.n;
+    // preorder from the root leaf; children before parents when read backwards
+    std::vector<int32_t> order, depth(nb, 0), nleaf(nb, 1), st{t.root};
+    order.reserve(nb);
+    int32_t maxdepth = 1;
+    while (!st.empty())
+    {
+        const int32_t v = st.back();
+        st.pop_back();
+        order.push_back(v);
+        if (t.left[v] >= 0)
+        {
+            depth[t.left[v]] = depth[t.right[v]] = depth[v] + 1;
+            maxdepth = std::max(maxdepth, depth[v] + 1);
+            st.push_back(t.right[v]);
+            st.push_back(t.left[v]);
+        }
+    }
+    for (auto it = order.rbegin(); it != order.rend(); ++it)
+        if (t.left[*it] >= 0)
+            nleaf[*it] = nleaf[t.left[*it]] + nleaf[t.right[*it]];
+    int32_t K = 1;
+    while ((1 << K) <= maxdepth)
+        K++;
+    const size_t elems = (7 + (size_t)K) * nb + nlo;
+    if (elems + 8 > cap_elems)
+        return 0;
+    memset(out, 0, (elems + 8) * sizeof(IdxT));
+    IdxT *parent = out, *left = parent + nb, *right = left + nb, *nl = right + nb, *dep = nl + nb, *tin = dep + nb,
          *first = tin + nb, *lo = first + nb, *up = lo + nlo;
     size_t nleaves = 0;
     for (size_t i = 0; i < order.size(); i++)
@@ -36,57 +74,17 @@ static void fill_tables(const Topology &t, int32_t K, const std::vector<int32_t>
     for (int32_t k = 1; k < K; k++)
         for (size_t v = 0; v < nb; v++)
             up[(size_t)k * nb + v] = up[(size_t)(k - 1) * nb + (size_t)up[(size_t)(k - 1) * nb + v]];
+    *K_out = K;
+    return (uint32_t)(((elems + 8) * sizeof(IdxT)) & ~(size_t)15); // whole 16-byte pieces
 }
 
-int sync_device_topology(lvbgpu_ctx *ctx)
+// bring the device tables of the listed chains (all parked) up to date: the stale ones are rebuilt on the host
+// threads, each into its own pinned staging slot, and uploaded.  A staging slot is rewritten only after the step
+// that followed its last upload has been waited for, so no upload can still be reading it.
+int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
 {
-    if (ctx->d_topo_version == ctx->topo_version)
-        return LVBGPU_OK;
     const int32_t nb = ctx->nb;
-    const Topology &t = ctx->topo;
-    // preorder from the root leaf; children before parents when read backwards
-    std::vector<int32_t> order;
-    order.reserve(nb);
-    std::vector<int32_t> depth((size_t)nb, 0), nleaf((size_t)nb, 1);
-    std::vector<int32_t> st{t.root};
-    int32_t maxdepth = 1;
-    while (!st.empty())
-    {
-        const int32_t v = st.back();
-        st.pop_back();
-        order.push_back(v);
-        if (t.left[v] >= 0)
-        {
-            depth[t.left[v]] = depth[t.right[v]] = depth[v] + 1;
-            maxdepth = std::max(maxdepth, depth[v] + 1);
-            st.push_back(t.right[v]);
-            st.push_back(t.left[v]);
-        }
-    }
-    for (auto it = order.rbegin(); it != order.rend(); ++it)
-        if (t.left[*it] >= 0)
-            nleaf[*it] = nleaf[t.left[*it]] + nleaf[t.right[*it]];
-    int32_t K = 1;
-    while ((1 << K) <= maxdepth)
-        K++;
-    size_t bytes;
-    const void *src;
-    if (nb <= 65535)
-    {
-        fill_tables<uint16_t>(t, K, order, depth, nleaf, ctx->gen_tab16);
-        bytes = ctx->gen_tab16.size() * 2;
-        src = ctx->gen_tab16.data();
-        ctx->gen_idx_bytes = 2;
-    }
-    else
-    {
-        fill_tables<int32_t>(t, K, order, depth, nleaf, ctx->gen_tab32);
-        bytes = ctx->gen_tab32.size() * 4;
-        src = ctx->gen_tab32.data();
-        ctx->gen_idx_bytes = 4;
-    }
-    bytes &= ~(size_t)15; // whole 16-byte pieces (the arrays end 8 elements before the vector does)
-    // one slot per chain, wide enough for the deepest tree these taxa can form (K <= bits of 2n-3)
+    ctx->gen_idx_bytes = nb <= 65535 ? 2u : 4u;
     {
         int32_t kmax = 1;
         while ((1 << kmax) <= nb)
@@ -94,21 +92,58 @@ int sync_device_topology(lvbgpu_ctx *ctx)
         const size_t widest = ((7 + (size_t)kmax) * (size_t)nb + (size_t)ctx->n + 8) * ctx->gen_idx_bytes;
         ctx->gen_table_stride = (uint32_t)((widest + 255) & ~(size_t)255);
     }
-    if (bytes > ctx->gen_table_stride)
-        return ctx->fail(LVBGPU_E_ARG, "generator tables exceed their slot");
     const size_t old_cap = ctx->d_topo4.cap;
     HIPCHK(ctx, ctx->d_topo4.reserve((size_t)ctx->nchains * ctx->gen_table_stride));
     if (ctx->d_topo4.cap != old_cap) // a new buffer holds no chain's tables
         for (ChainSlot &cs : ctx->parked)
             cs.d_topo_version = ~0ull;
-    HIPCHK(ctx, ctx->h_topo.reserve(bytes));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // an upload still reading the staging buffer
-    memcpy(ctx->h_topo.p, src, bytes);
-    HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + (size_t)ctx->chain * ctx->gen_table_stride, ctx->h_topo.p, bytes,
-                               hipMemcpyHostToDevice, ctx->stream));
-    ctx->gen_table_bytes = (uint32_t)bytes;
-    ctx->gen_K = K;
-    ctx->d_topo_version = ctx->topo_version;
+    const size_t old_stage = ctx->h_topo.cap;
+    if ((size_t)ctx->nchains * ctx->gen_table_stride > old_stage)
+    {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // nothing may still read the buffer that is about to go
+        HIPCHK(ctx, ctx->h_topo.reserve((size_t)ctx->nchains * ctx->gen_table_stride));
+    }
+    std::vector<int32_t> stale;
+    for (int32_t i = 0; i < k; i++)
+        if (ctx->parked[(size_t)chains[i]].d_topo_version != ctx->parked[(size_t)chains[i]].topo_version)
+            stale.push_back(chains[i]);
+    if (stale.empty())
+        return LVBGPU_OK;
+    std::vector<uint32_t> bytes(stale.size(), 0);
+    auto build = [&](int32_t i) {
+        ChainSlot &cs = ctx->parked[(size_t)stale[(size_t)i]];
+        char *slot = (char *)ctx->h_topo.p + (size_t)stale[(size_t)i] * ctx->gen_table_stride;
+        bytes[(size_t)i] = ctx->gen_idx_bytes == 2
+                               ? fill_tables<uint16_t>(cs.topo, (uint16_t *)slot, ctx->gen_table_stride / 2, &cs.gen_K)
+                               : fill_tables<int32_t>(cs.topo, (int32_t *)slot, ctx->gen_table_stride / 4, &cs.gen_K);
+    };
+    int T = 1;
+    if (stale.size() > 1)
+    {
+        if (!ctx->pool && host_threads() > 1)
+            ctx->pool = new (std::nothrow) Pool(host_threads());
+        if (ctx->pool)
+            T = std::min<int>(ctx->pool->size(), (int)stale.size());
+    }
+    if (T == 1)
+        for (size_t i = 0; i < stale.size(); i++)
+            build((int32_t)i);
+    else
+        ctx->pool->run(T, [&](int t) {
+            for (size_t i = (size_t)t; i < stale.size(); i += (size_t)T)
+                build((int32_t)i);
+        });
+    for (size_t i = 0; i < stale.size(); i++)
+    {
+        if (bytes[i] == 0)
+            return ctx->fail(LVBGPU_E_ARG, "generator tables exceed their slot");
+        ChainSlot &cs = ctx->parked[(size_t)stale[i]];
+        const size_t off = (size_t)stale[i] * ctx->gen_table_stride;
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + off, (const char *)ctx->h_topo.p + off, bytes[i], hipMemcpyHostToDevice,
+                                   ctx->stream));
+        cs.gen_table_bytes = bytes[i];
+        cs.d_topo_version = cs.topo_version;
+    }
     return LVBGPU_OK;
 }
 } // namespace lvbgpu_detail
@@ -154,24 +189,39 @@ const char *move_defect(const Topology &t, const lvbgpu_move &m)
     return nullptr;
 }
 
-int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a, uint32_t mix_b, uint64_t seed,
-                       int64_t *lengths_out, const lvbgpu_move *moves = nullptr)
+// one generator launch + one walk over the candidates of k chains (draws[i].chain distinct, all with a resident
+// tree); lengths_out holds the segments one after the other.  `moves` (host-named moves): k == 1 only.
+int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out, const lvbgpu_move *moves)
 {
-    if (!ctx || B < 1 || kind < -3 || kind > 2 || !lengths_out)
+    if (!ctx || k < 1 || k > (int32_t)MAX_GEN_SEGS || !draws || !lengths_out || (moves && k != 1))
         return LVBGPU_E_ARG;
-    if (!ctx->have_tree)
-        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
     if (ctx->n < 5)
         return ctx->fail(LVBGPU_E_ARG, "rearrangements need at least 5 taxa");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = sync_device_topology(ctx);
-    if (rc != LVBGPU_OK)
-        return rc;
+    AllParked guard(ctx);
+    int64_t total = 0;
+    std::vector<int32_t> chains((size_t)k);
+    uint64_t seen = 0;
+    for (int32_t i = 0; i < k; i++)
+    {
+        const lvbgpu_chain_draw &d = draws[i];
+        if (d.chain < 0 || d.chain >= ctx->nchains || d.count < 1 || d.kind < -3 || d.kind > 2 || ((seen >> d.chain) & 1u))
+            return ctx->fail(LVBGPU_E_ARG, "draw " + std::to_string(i) + ": chain out of range or listed twice, or bad count / kind");
+        if (!ctx->parked[(size_t)d.chain].have_tree)
+            return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+        seen |= 1ull << d.chain;
+        chains[(size_t)i] = d.chain;
+        total += d.count;
+    }
     // fixed strides: a program has at most (n-3)+3 tokens; edits are capped (longer TBR paths overflow)
     const uint32_t stride_t = (uint32_t)ctx->n + 8u;
     const uint32_t stride_e = (uint32_t)std::min<int64_t>(ctx->nb, 512);
-    if ((uint64_t)B * stride_t >= (1ull << 32) || (uint64_t)B * ctx->ntiles >= (1ull << 31))
+    if ((uint64_t)total * stride_t >= (1ull << 32) || (uint64_t)total * ctx->ntiles >= (1ull << 31))
         return ctx->fail(LVBGPU_E_ARG, "batch too large");
+    const int32_t B = (int32_t)total;
+    int rc = prepare_tables(ctx, chains.data(), k);
+    if (rc != LVBGPU_OK)
+        return rc;
     if (!ctx->prop_batch)
     {
         ctx->prop_batch = new (std::nothrow) lvbgpu_batch();
@@ -181,14 +231,9 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     lvbgpu_batch *bt = ctx->prop_batch;
     const size_t o_t = align16((size_t)B * sizeof(CandDesc));
     const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
-    const size_t total = o_d + align16((size_t)B * stride_t * 4);
-    HIPCHK(ctx, bt->d_prog.reserve(total));
-    // a buffer that grew holds whatever its new memory held - and may well sit at the old address, so it is
-    // the capacity that tells, not the pointer
-    const size_t old_len_cap = bt->d_len.cap;
+    const size_t bytes = o_d + align16((size_t)B * stride_t * 4);
+    HIPCHK(ctx, bt->d_prog.reserve(bytes));
     HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
-    if (bt->d_len.cap != old_len_cap)
-        bt->len_zeroed = false;
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
     HIPCHK(ctx, ctx->d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
     HIPCHK(ctx, ctx->d_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
@@ -197,18 +242,19 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     bt->off_toks = o_t;
     bt->off_dsts = o_d;
     bt->full_mode = false;
-    bt->topo_version = ctx->topo_version;
-    bt->chain = ctx->chain;
+    bt->spans_chains = true; // its programs name their own chains; each segment's tree version is kept in p_segs
     bt->stats = lvbgpu_batch_stats{};
     bt->stats.candidates = B;
     bt->stats.max_stack = 1; // at most one sibling set waits while the other path is walked
     ctx->p_stride_t = stride_t;
     ctx->p_stride_e = stride_e;
     ctx->p_B = 0;
+    ctx->p_segs.clear();
     const lvbgpu_move_dev *d_moves = nullptr;
     if (moves)
     {
         static_assert(sizeof(lvbgpu_move) == sizeof(lvbgpu_move_dev), "move layout");
+        const Topology &topo = ctx->parked[(size_t)draws[0].chain].topo;
         // admissibility is an O(depth) walk per move: spread it over the host threads for long batches
         int T = 1;
         if (B >= 8192) // measured: waking the pool costs more than it saves below that
@@ -221,7 +267,7 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
         std::vector<int32_t> first_bad((size_t)T, -1);
         auto check = [&](int t) {
             for (int32_t b = (int32_t)((int64_t)B * t / T); b < (int32_t)((int64_t)B * (t + 1) / T); b++)
-                if (move_defect(ctx->topo, moves[b]))
+                if (move_defect(topo, moves[b]))
                 {
                     first_bad[(size_t)t] = b;
                     return;
@@ -235,12 +281,12 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
             if (first_bad[(size_t)t] >= 0)
             {
                 const int32_t b = first_bad[(size_t)t];
-                return ctx->fail(LVBGPU_E_TOPOLOGY, "move " + std::to_string(b) + ": " + move_defect(ctx->topo, moves[b]));
+                return ctx->fail(LVBGPU_E_TOPOLOGY, "move " + std::to_string(b) + ": " + move_defect(topo, moves[b]));
             }
         HIPCHK(ctx, ctx->d_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
         HIPCHK(ctx, ctx->h_moves.reserve((size_t)B * sizeof(lvbgpu_move)));
         memcpy(ctx->h_moves.p, moves, (size_t)B * sizeof(lvbgpu_move)); // pinned staging: the caller's array may go away
-        // a short list is read by the generator where it lies (16 bytes per thread, once); a long one is copied
+        // a short list is read by the generator where it lies (16 bytes per wave, once); a long one is copied
         if (ctx->direct_steps && (size_t)B * sizeof(lvbgpu_move) <= DIRECT_READ_MAX_BYTES)
             d_moves = (const lvbgpu_move_dev *)ctx->h_moves.p;
         else
@@ -251,20 +297,11 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
         }
     }
     GenArgs ga{};
-    ga.tables = (const char *)ctx->d_topo4.p + (size_t)ctx->chain * ctx->gen_table_stride;
-    ga.chain = (uint32_t)ctx->chain;
-    ga.table_bytes = ctx->gen_table_bytes;
+    ga.tables = ctx->d_topo4.p;
     ga.idx_bytes = ctx->gen_idx_bytes;
     ga.n = (int32_t)ctx->n;
     ga.nb = ctx->nb;
-    ga.root = ctx->topo.root;
-    ga.K = ctx->gen_K;
     ga.leaf_order_len = (uint32_t)ctx->n;
-    ga.kind_all = kind;
-    ga.mix_a = mix_a;
-    ga.mix_b = mix_b;
-    ga.seed = seed;
-    ga.B = (uint32_t)B;
     ga.stride_t = stride_t;
     ga.stride_e = stride_e;
     ga.toks = (uint32_t *)((char *)bt->d_prog.p + o_t);
@@ -274,13 +311,38 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
     ga.info = (ProposalInfo *)ctx->d_pinfo.p;
     ga.len_out = (unsigned long long *)bt->d_len.p;
     ga.moves = d_moves;
+    ga.nseg = (uint32_t)k;
+    uint32_t start = 0;
+    for (int32_t i = 0; i < k; i++)
+    {
+        const lvbgpu_chain_draw &d = draws[i];
+        const ChainSlot &cs = ctx->parked[(size_t)d.chain];
+        GenSeg &sg = ga.seg[i];
+        sg.start = start;
+        sg.count = (uint32_t)d.count;
+        sg.kind_all = d.kind;
+        sg.mix_a = d.mix_a;
+        sg.mix_b = d.mix_b;
+        sg.seed_lo = (uint32_t)d.seed;
+        sg.seed_hi = (uint32_t)(d.seed >> 32);
+        sg.table_off = (uint32_t)d.chain * ctx->gen_table_stride;
+        sg.table_bytes = cs.gen_table_bytes;
+        sg.root = cs.topo.root;
+        sg.chain = (uint16_t)d.chain;
+        sg.K = (uint16_t)cs.gen_K;
+        ctx->p_segs.push_back({d.chain, (int32_t)start, d.count, cs.topo_version});
+        start += (uint32_t)d.count;
+    }
     HIPCHK(ctx, launch_propose(ga, ctx->stream));
     bt->len_zeroed = true; // by the generator
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
+    {
+        ctx->p_segs.clear();
         return rc;
+    }
     // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
-    // when) the caller wants that candidate (lvbgpu_proposal_edits)
+    // when) the caller wants that candidate (lvbgpu_proposal_edits) or accepts it (lvbgpu_chains_commit)
     HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, wait_for_step(ctx, B));
     const int64_t *len = (const int64_t *)bt->h_len.p;
@@ -293,11 +355,27 @@ int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a,
         }
         lengths_out[b] = len[b];
         if (len[b] <= 0)
+        {
+            ctx->p_segs.clear();
             return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (device-built candidate " + std::to_string(b) +
                                                    " of " + std::to_string(B) + " scored " + std::to_string(len[b]) + ")");
+        }
     }
-    ctx->p_B = B;
+    if (k == 1 && draws[0].chain == guard.sel)
+        ctx->p_B = B; // lvbgpu_proposal_edits may name its candidates
     return LVBGPU_OK;
+}
+
+// the single-tree forms: the selected chain, one segment
+int propose_score_impl(lvbgpu_ctx *ctx, int32_t B, int32_t kind, uint32_t mix_a, uint32_t mix_b, uint64_t seed,
+                       int64_t *lengths_out, const lvbgpu_move *moves = nullptr)
+{
+    if (!ctx || B < 1 || kind < -3 || kind > 2 || !lengths_out)
+        return LVBGPU_E_ARG;
+    if (!ctx->have_tree)
+        return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+    const lvbgpu_chain_draw d{ctx->chain, B, kind, mix_a, mix_b, seed};
+    return propose_core(ctx, 1, &d, lengths_out, moves);
 }
 } // namespace lvbgpu_detail
 
@@ -324,6 +402,110 @@ extern "C" int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_n
         return LVBGPU_E_ARG;
     auto scaled = [](double p) { return (uint32_t)std::min(4294967295.0, p * 4294967296.0); };
     return propose_score_impl(ctx, B, -3, scaled(p_nni), scaled(p_nni + p_spr), seed, lengths_out);
+}
+
+extern "C" int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out)
+{
+    return propose_core(ctx, k, draws, lengths_out, nullptr);
+}
+
+extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_pick *picks)
+{
+    if (!ctx || k < 1 || k > MAX_CHAINS || !picks)
+        return LVBGPU_E_ARG;
+    if (ctx->p_segs.empty() || !ctx->prop_batch)
+        return ctx->fail(LVBGPU_E_STATE, "no device batch to pick from: call lvbgpu_chains_propose_score first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    AllParked guard(ctx);
+    lvbgpu_batch *bt = ctx->prop_batch;
+    // where each pick sits in the batch; nothing may have changed that chain's tree since it was drawn
+    std::vector<uint32_t> where((size_t)k);
+    uint64_t seen = 0;
+    for (int32_t j = 0; j < k; j++)
+    {
+        const lvbgpu_chain_pick &pk = picks[j];
+        const lvbgpu_ctx::PSeg *seg = nullptr;
+        for (const lvbgpu_ctx::PSeg &sgm : ctx->p_segs)
+            if (sgm.chain == pk.chain)
+                seg = &sgm;
+        if (!seg || pk.b < 0 || pk.b >= seg->count || ((seen >> pk.chain) & 1u))
+            return ctx->fail(LVBGPU_E_ARG, "pick " + std::to_string(j) + ": that chain drew no such candidate in the last batch, or is picked twice");
+        if (seg->version != ctx->parked[(size_t)pk.chain].topo_version)
+            return ctx->fail(LVBGPU_E_STATE, "the resident tree of chain " + std::to_string(pk.chain) + " changed since that batch was drawn");
+        seen |= 1ull << pk.chain;
+        where[(size_t)j] = (uint32_t)(seg->start + pk.b);
+        if (((const int64_t *)bt->h_len.p)[where[(size_t)j]] >= PROPOSAL_OVERFLOW_LENGTH)
+            return ctx->fail(LVBGPU_E_ARG, "pick " + std::to_string(j) + ": that candidate overflowed the per-candidate buffers");
+    }
+    // a pinned slot: [flag][picks][k x (descriptor + rewrites)]
+    const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
+    const size_t o_pick = 64, o_out = 64 + align16((size_t)MAX_CHAINS * 4);
+    const int slot = ctx->pick_slot;
+    ctx->pick_slot = (slot + 1) % lvbgpu_ctx::PICK_SLOTS;
+    if (!ctx->pick_ev[slot])
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pick_ev[slot], hipEventDisableTiming));
+    else
+        HIPCHK(ctx, hipEventSynchronize(ctx->pick_ev[slot])); // long done unless 4 commits are in flight
+    HIPCHK(ctx, ctx->h_pick[slot].reserve(o_out + (size_t)MAX_CHAINS * out_stride));
+    char *h = (char *)ctx->h_pick[slot].p;
+    uint32_t *flag = (uint32_t *)h;
+    uint32_t *h_picks = (uint32_t *)(h + o_pick);
+    memcpy(h_picks, where.data(), (size_t)k * 4);
+    const uint32_t seq = ++ctx->pick_seq;
+    const size_t old_done = ctx->d_done.cap;
+    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
+    if (ctx->d_done.cap != old_done)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+    uint32_t *done = (uint32_t *)ctx->d_done.p;
+    // 1. what the host needs to follow the moves (so that it can work while the walk runs)
+    HIPCHK(ctx, launch_gather_picks(h_picks, (uint32_t)k, (const ProposalInfo *)ctx->d_pinfo.p, (const lvbgpu_edit_dev *)ctx->d_pedits.p,
+                                    ctx->p_stride_e, h + o_out, out_stride, flag, seq, done + MAX_CHAINS, ctx->stream));
+    // 2. the picked candidates' own programs in commit form: produced sets and change counts go to their chains'
+    //    rows, every candidate's last wave settles its chain's changes[] and S_all (fused commit)
+    HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
+    if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
+    {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
+        ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
+    }
+    HIPCHK(ctx, ctx->d_len.reserve(8));
+    WalkArgs a = resident_args(ctx, bt->d_prog.p, bt->off_toks, bt->off_dsts, ctx->d_len.p, (uint32_t)k, 1);
+    a.pick = h_picks;
+    a.s_all_out = (unsigned long long *)ctx->d_scalars;
+    a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
+    a.tmp_stride = (uint32_t)(ctx->nb + 1);
+    a.done_count = done;
+    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->pick_ev[slot], ctx->stream)); // the slot is free once the walk has read its picks
+    // 3. follow the moves on the host
+    for (uint32_t spins = 1;; spins++)
+    {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq)
+            break;
+        if ((spins & 1023u) == 0)
+        {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess)
+                break; // everything the kernels wrote is visible
+            if (q != hipErrorNotReady)
+                return ctx->fail_hip(q, "lvbgpu_chains_commit: waiting for the picked moves");
+        }
+    }
+    for (int32_t j = 0; j < k; j++)
+    {
+        const char *rec = h + o_out + (size_t)j * out_stride;
+        const ProposalInfo pi = *(const ProposalInfo *)rec;
+        ChainSlot &cs = ctx->parked[(size_t)picks[j].chain];
+        std::string why;
+        if (pi.overflow || !ctx->pb.apply_edits(cs.topo, (const Edit *)(rec + sizeof(ProposalInfo)), pi.n_edits, -1, &why))
+        {
+            cs.have_tree = false; // the device has walked it: this chain's resident state is no longer trustworthy
+            return ctx->fail(LVBGPU_E_TOPOLOGY, "chain " + std::to_string(picks[j].chain) + ": " + (pi.overflow ? "overflowed candidate" : why));
+        }
+        cs.topo_version = ++ctx->version_counter;
+        cs.cur_length_stale = true;
+    }
+    return LVBGPU_OK;
 }
 
 extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits,
@@ -368,10 +550,13 @@ extern "C" int lvbgpu_proposal_stats(lvbgpu_ctx *ctx, lvbgpu_batch_stats *out)
 {
     if (!ctx || !out)
         return LVBGPU_E_ARG;
-    if (ctx->p_B <= 0 || !ctx->prop_batch)
+    int64_t total = 0;
+    for (const lvbgpu_ctx::PSeg &sgm : ctx->p_segs)
+        total += sgm.count;
+    if (total <= 0 || !ctx->prop_batch)
         return ctx->fail(LVBGPU_E_STATE, "no device batch: call lvbgpu_propose_score first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<ProposalInfo> info((size_t)ctx->p_B);
+    std::vector<ProposalInfo> info((size_t)total);
     HIPCHK(ctx, hipMemcpyAsync(info.data(), ctx->d_pinfo.p, info.size() * sizeof(ProposalInfo), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -202,7 +202,20 @@ struct lvbgpu_ctx
     PinBuf h_moves;
     uint64_t d_topo_version = ~0ull;
     uint32_t p_stride_t = 0, p_stride_e = 0;
-    int32_t p_B = 0; // candidates of the last device batch (0: none)
+    int32_t p_B = 0; // candidates of the last device batch whose candidates lvbgpu_proposal_edits may name (0: none)
+    struct PSeg
+    {
+        int32_t chain, start, count;
+        uint64_t version; // that chain's tree when the candidates were drawn
+    };
+    std::vector<PSeg> p_segs; // the segments of the last device batch (lvbgpu_chains_commit picks from them)
+    // lvbgpu_chains_commit: picks / fetched rewrites travel through a small ring of pinned slots
+    static constexpr int PICK_SLOTS = 4;
+    PinBuf h_pick[PICK_SLOTS];
+    hipEvent_t pick_ev[PICK_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int pick_slot = 0;
+    uint32_t pick_seq = 0;
+    DevBuf d_done; // per picked candidate: finished-wave count of a multi-chain commit (zero between launches)
     PinBuf h_pin;
     // direct steps: small batches whose programs the walk reads straight from h_pin and whose lengths its last
     // wave writes straight into the batch's pinned buffer; the host polls h_step's first word for step_seq
@@ -272,6 +285,7 @@ struct lvbgpu_batch
     bool direct = false;     // this step's lengths come back through the walk's last wave (no copy, no stream wait)
     bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
     bool launched = false;   // lengths exist (or are on their way)
+    bool spans_chains = false; // device-built batch over several chains: every program names its own chain
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)
     int32_t chain = 0;         // ... and which chain's tree that is
     std::vector<int32_t> slot_of; // big batches: candidate b sits at position slot_of[b] (longest program first)

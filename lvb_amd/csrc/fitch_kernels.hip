@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     const uint32_t tile_begin = group * a.tiles_per + (group < a.tiles_rem ? group : a.tiles_rem);
     const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
 
-    const CandDesc cd = a.cands[cand];
+    const CandDesc cd = a.cands[a.pick ? a.pick[cand] : cand];
     // which resident tree: node numbers from bias_from on (the internal nodes) move by the chain's row block
     const uint32_t chain = cd.flags >> CAND_CHAIN_SHIFT;
     const uint32_t row_bias = chain * a.chain_rows;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     uint32_t k_flushed = 0; // combines of this tile already written out
     auto add_count = [&](uint32_t k, int32_t dst, uint32_t s) {
         if (a.tmp_changes)
-            atomicAdd(a.tmp_changes + k, (unsigned long long)s); // settled by the launch's last wave
+            atomicAdd(a.tmp_changes + (size_t)cand * a.tmp_stride + k, (unsigned long long)s); // settled by the candidate's last wave
         else
         {
             atomicAdd(a.changes_out + (dst >= 0 ? biased((uint32_t)dst) : a.root_slot + chain), (unsigned long long)s);
@@ -467,11 +467,13 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
     {
         if (a.tmp_changes)
         {
+            // every candidate of the launch is walked by ngroups waves: the last of them to finish settles it
             uint32_t last = 0;
+            unsigned long long *const tmp = a.tmp_changes + (size_t)cand * a.tmp_stride;
             if (lane == 0)
             {
                 __threadfence(); // our partial counts before our tick
-                last = atomicAdd(a.done_count, 1u) == a.nitems - 1u ? 1u : 0u;
+                last = atomicAdd(a.done_count + cand, 1u) == a.ngroups - 1u ? 1u : 0u;
             }
             if (__builtin_amdgcn_readfirstlane(last))
             {
@@ -480,8 +482,8 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
                 unsigned long long root_changes = 0; // the two root combines (dst < 0)
                 for (uint32_t i = lane; i < cd.ncomb; i += 64u)
                 {
-                    const unsigned long long v = __hip_atomic_load(a.tmp_changes + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(a.tmp_changes + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long v = __hip_atomic_load(tmp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(tmp + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int32_t dst = ds[i];
                     if (dst >= 0)
                     {
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
                 {
                     a.changes_out[a.root_slot + chain] = root_changes;
                     a.s_all_out[4u * chain] += (unsigned long long)delta;
-                    __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.done_count + cand, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -538,6 +540,31 @@ __global__ __launch_bounds__(WALK_THREADS) void fitch_walk(const WalkArgs a)
 
 // ---------------------------------------------------------------------------------------------
 // small helpers around the walk
+
+// descriptors and rewrites of the picked candidates of a device-built batch -> pinned host memory (one wave per
+// pick), then the flag: the host applies the moves to its topologies while the commit walk runs
+__global__ __launch_bounds__(64) void gather_picks_kernel(const uint32_t *pick, uint32_t k, const ProposalInfo *info,
+                                                          const lvbgpu_edit_dev *edits, uint32_t stride_e, char *out,
+                                                          uint32_t out_stride, uint32_t *flag, uint32_t seq, uint32_t *arrived)
+{
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    const uint32_t g = pick[j];
+    const ProposalInfo pi = info[g];
+    char *dst = out + (size_t)j * out_stride;
+    if (lane == 0)
+        *reinterpret_cast<ProposalInfo *>(dst) = pi;
+    const uint32_t ne = pi.overflow ? 0u : (uint32_t)pi.n_edits;
+    lvbgpu_edit_dev *ed = reinterpret_cast<lvbgpu_edit_dev *>(dst + sizeof(ProposalInfo));
+    for (uint32_t i = lane; i < ne && i < stride_e; i += 64u)
+        ed[i] = edits[(size_t)g * stride_e + i];
+    __threadfence_system();
+    if (lane == 0 && atomicAdd(arrived, 1u) == k - 1u)
+    {
+        __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // changes[dst] = 0 for every node a commit program is about to recompute, plus the two scalars the
 // commit walk accumulates into (the root slot of changes[] and the program's length slot): one launch
@@ -828,6 +855,17 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         hipLaunchKernelGGL((fitch_walk<false, true>), grid, block, lds, stream, a);
     else
         hipLaunchKernelGGL((fitch_walk<false, false>), grid, block, lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_picks(const uint32_t *pick, uint32_t k, const ProposalInfo *info, const lvbgpu_edit_dev *edits,
+                               uint32_t stride_e, char *out, uint32_t out_stride, uint32_t *flag, uint32_t seq, uint32_t *arrived,
+                               hipStream_t stream)
+{
+    if (k == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(gather_picks_kernel, dim3(k), dim3(64), 0, stream, pick, k, info, edits, stride_e, out, out_stride, flag, seq,
+                       arrived);
     return hipGetLastError();
 }
 

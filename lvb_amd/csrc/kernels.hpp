@@ -78,6 +78,11 @@ struct WalkArgs
     // with the difference to what those nodes held before, and clears tmp_changes and done_count again - no
     // separate zeroing launch in front of a commit.
     unsigned long long *tmp_changes;
+    // several candidates committed in one launch (one per chain): launch candidate j walks cands[pick[j]] (pick ==
+    // null: cands[j]), accumulates in tmp_changes + j * tmp_stride and ticks done_count[j]; the last of ITS waves
+    // settles that candidate.  A single commit is j = 0, tmp_stride irrelevant.
+    const uint32_t *pick;
+    uint32_t tmp_stride;
     // COMMIT: produced sets and their counts wait in LDS, this many per wave, and go out in bursts (filled by
     // launch_walk, >= 1 for COMMIT).  A store or atomic inside the chain makes every wait for a
     // row a full drain of the memory counter (reads and writes return out of order with respect to each other),
@@ -126,28 +131,46 @@ struct ProposalInfo
 // Built by the host when the resident topology changes (api_propose.cpp), padded to 16 bytes.
 constexpr uint32_t GEN_WAVES = 4;
 constexpr uint32_t GEN_THREADS = 64 * GEN_WAVES;
+constexpr uint32_t MAX_GEN_SEGS = 64; // = MAX_CHAINS: one segment of a launch per resident tree
+// one run of candidates of ONE resident tree inside a generator launch
+struct GenSeg
+{
+    uint32_t start, count;   // candidates [start, start + count) of the batch
+    int32_t kind_all;        // 0 NNI, 1 SPR, 2 TBR; -1 / -2 / -3: see propose_kernels.hip
+    uint32_t mix_a, mix_b;
+    uint32_t seed_lo, seed_hi; // the draw is a function of (seed, index within the segment)
+    uint32_t table_off;      // byte offset of this tree's tables in GenArgs::tables
+    uint32_t table_bytes;
+    int32_t root;
+    uint16_t chain, K;
+    uint32_t blk_start;      // first workgroup of the launch that works on this segment (filled by launch_propose)
+};
 struct GenArgs
 {
     const void *tables;
-    uint32_t table_bytes, idx_bytes;
-    int32_t n, nb, root, K;
+    uint32_t idx_bytes;
+    int32_t n, nb;
     uint32_t leaf_order_len;
-    uint32_t chain; // resident tree slot the candidates belong to (CandDesc::flags)
-    int32_t kind_all;
-    uint32_t mix_a, mix_b;
-    uint64_t seed;
-    uint32_t B, stride_t, stride_e;
+    uint32_t stride_t, stride_e;
     uint32_t *toks;
     int32_t *dsts;
     lvbgpu_edit_dev *edits;
     CandDesc *cands;
     ProposalInfo *info;
     unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
-    const lvbgpu_move_dev *moves;
-    int32_t use_lds; // filled by launch_propose
+    const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
+    int32_t use_lds;              // filled by launch_propose
+    uint32_t nseg;
+    GenSeg seg[MAX_GEN_SEGS];
 };
+static_assert(sizeof(GenArgs) <= 4000, "GenArgs travels as a kernel argument");
 hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
 
+// what lvbgpu_chains_commit needs on the host of every picked candidate, written straight into pinned memory:
+// out + j * out_stride: [ProposalInfo][n_edits rewrites]; then *flag = seq (released after the data)
+hipError_t launch_gather_picks(const uint32_t *pick, uint32_t k, const ProposalInfo *info, const lvbgpu_edit_dev *edits,
+                               uint32_t stride_e, char *out, uint32_t out_stride, uint32_t *flag, uint32_t seq, uint32_t *arrived,
+                               hipStream_t stream);
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
 hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);

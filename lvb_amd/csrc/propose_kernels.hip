@@ -217,23 +217,27 @@ struct Gen
 // kind_all: 0 NNI, 1 SPR, 2 TBR; -1: candidate b gets kind b % 3; -2: NNI/SPR alternate by the
 // parity of (mix_a + b) (reference -a 0, Solve.c:288-297); -3: drawn per candidate, NNI below
 // threshold mix_a, SPR below mix_b, else TBR, both scaled to 2^32 (reference -a 1, Solve.c:262-283)
+// bl: the candidate's index within its segment (what the draw is a function of, with the segment's seed);
+// b = sg.start + bl: its slot in the batch
 template <typename IdxT>
-__device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const uint32_t b, const uint32_t lane)
+__device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const GenSeg &sg, const uint32_t bl, const uint32_t lane)
 {
     const int32_t n = t.n, nb = t.nb, root = t.root;
-    const DevRng rng{g.seed ^ ((uint64_t)(b + 1u) * 0xD1B54A32D192ED03ull)};
+    const uint32_t b = sg.start + bl;
+    const uint64_t seed = ((uint64_t)sg.seed_hi << 32) | sg.seed_lo;
+    const DevRng rng{seed ^ ((uint64_t)(bl + 1u) * 0xD1B54A32D192ED03ull)};
     Gen<IdxT> e{t, GenOut{g.toks + (size_t)b * g.stride_t, g.dsts + (size_t)b * g.stride_t, g.edits + (size_t)b * g.stride_e, 0, 0,
                           0, 0, g.stride_e},
                 lane};
-    int32_t kind = g.kind_all;
-    if (g.kind_all == -1)
-        kind = (int32_t)(b % 3u);
-    else if (g.kind_all == -2)
-        kind = ((g.mix_a + b) & 1u) ? 1 : 0;
-    else if (g.kind_all == -3)
+    int32_t kind = sg.kind_all;
+    if (sg.kind_all == -1)
+        kind = (int32_t)(bl % 3u);
+    else if (sg.kind_all == -2)
+        kind = ((sg.mix_a + bl) & 1u) ? 1 : 0;
+    else if (sg.kind_all == -3)
     {
         const uint32_t r = (uint32_t)(rng.draw(0, 0) >> 32);
-        kind = r < g.mix_a ? 0 : (r < g.mix_b ? 1 : 2);
+        kind = r < sg.mix_a ? 0 : (r < sg.mix_b ? 1 : 2);
     }
     // moves != nullptr: nothing is drawn, candidate b IS moves[b] (validated by the host side of
     // lvbgpu_score_moves); everything after the draws is shared
@@ -515,7 +519,7 @@ __device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const uint32_
         {
             cd.ntok = e.o.ntok;
             cd.ncomb = e.o.ndst;
-            cd.flags = CAND_RESIDENT_BASE | (g.chain << CAND_CHAIN_SHIFT);
+            cd.flags = CAND_RESIDENT_BASE | ((uint32_t)sg.chain << CAND_CHAIN_SHIFT);
             cd.nfresh = e.o.nfresh;
         }
         g.cands[b] = cd;
@@ -533,12 +537,20 @@ template <typename IdxT>
 __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 {
     extern __shared__ uint4 lds_tables[];
-    const IdxT *tab = reinterpret_cast<const IdxT *>(g.tables);
+    // which segment (resident tree) this workgroup works for: its first workgroup is seg[s].blk_start
+    uint32_t s = 0;
+    while (s + 1u < g.nseg && blockIdx.x >= g.seg[s + 1u].blk_start)
+        s++;
+    const GenSeg &sg = g.seg[s];
+    const uint32_t blk_local = blockIdx.x - sg.blk_start;
+    const uint32_t seg_blocks = (s + 1u < g.nseg ? g.seg[s + 1u].blk_start : gridDim.x) - sg.blk_start;
+    const char *tables = reinterpret_cast<const char *>(g.tables) + sg.table_off;
+    const IdxT *tab = reinterpret_cast<const IdxT *>(tables);
     if (g.use_lds)
     {
         // one coalesced copy per workgroup; everything after it is LDS latency instead of L2 latency
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(g.tables);
-        const uint32_t n16 = g.table_bytes / 16u;
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(tables);
+        const uint32_t n16 = sg.table_bytes / 16u;
         for (uint32_t i0 = 0; i0 < n16; i0 += 4u * GEN_THREADS)
         {
             uint4 v[4];
@@ -573,18 +585,18 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
     t.up = tab + 7 * nb + (size_t)g.leaf_order_len;
     t.n = g.n;
     t.nb = g.nb;
-    t.root = g.root;
-    t.K = g.K;
+    t.root = sg.root;
+    t.K = (int32_t)sg.K;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (uint32_t b = blockIdx.x * GEN_WAVES + wave; b < g.B; b += gridDim.x * GEN_WAVES)
-        generate_one(t, g, b, lane);
+    for (uint32_t bl = blk_local * GEN_WAVES + wave; bl < sg.count; bl += seg_blocks * GEN_WAVES)
+        generate_one(t, g, sg, bl, lane);
 }
 
 hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
 {
-    if (args.B == 0)
-        return hipSuccess;
+    if (args.nseg == 0 || args.nseg > MAX_GEN_SEGS)
+        return hipErrorInvalidValue;
     // the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raise it once for each device a
     // context of this process launches on (the walk does the same per context, raise_lds_limit)
     static hipError_t raised_on[64];
@@ -608,12 +620,31 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
     }
     const size_t lds_max = raised == hipSuccess ? (size_t)MAX_LDS_BYTES : (size_t)64 * 1024;
     GenArgs g = args;
-    g.use_lds = g.table_bytes <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
-    const size_t lds = g.use_lds ? g.table_bytes : 0;
-    // one candidate per wave while the chip has room; beyond that waves take several
-    const uint32_t want = (g.B + GEN_WAVES - 1) / GEN_WAVES;
+    size_t widest = 0;
+    uint32_t total = 0;
+    for (uint32_t s = 0; s < g.nseg; s++)
+    {
+        widest = std::max<size_t>(widest, g.seg[s].table_bytes);
+        total += g.seg[s].count;
+    }
+    if (total == 0)
+        return hipSuccess;
+    g.use_lds = widest <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
+    const size_t lds = g.use_lds ? widest : 0;
+    // one candidate per wave while the chip has room; beyond that waves take several.  Every segment gets
+    // workgroups in proportion to its candidates (at least one)
     const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_max / std::max<size_t>(lds, 1))) : 8u;
-    const uint32_t nblk = std::min(want, 256u * per_cu);
+    const uint32_t budget = 256u * per_cu;
+    const uint32_t want_all = (total + GEN_WAVES - 1) / GEN_WAVES;
+    uint32_t nblk = 0;
+    for (uint32_t s = 0; s < g.nseg; s++)
+    {
+        const uint32_t want = (g.seg[s].count + GEN_WAVES - 1) / GEN_WAVES;
+        uint32_t give = want_all <= budget ? want : (uint32_t)((uint64_t)want * budget / want_all);
+        give = std::max(1u, std::min(give, std::max(want, 1u)));
+        g.seg[s].blk_start = nblk;
+        nblk += give;
+    }
     const dim3 grid(nblk), block(GEN_THREADS);
     if (g.idx_bytes == 2)
         hipLaunchKernelGGL(propose_kernel<uint16_t>, grid, block, lds, stream, g);

@@ -84,3 +84,63 @@ def test_chain_calls_reject_bad_arguments(mods):
         ctx.current_length()
     assert ei.value.status == -5
     ctx.close()
+
+
+@pytest.mark.parametrize("n,m,R", [(12, 300, 4), (500, 50000, 6)])
+def test_one_step_over_all_chains_equals_the_chains_stepped_one_by_one(mods, n, m, R):
+    """lvbgpu_chains_propose_score / lvbgpu_chains_commit: one generator launch, one walk and one commit walk for
+    all chains must give each chain exactly what the single-tree calls give it (same seeds => same moves, same
+    lengths; same picks => same trees, node sets and per-node changes)."""
+    api, host = mods
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 71))
+    multi = api.FitchContext(text_rows=rows)
+    multi.set_chains(R)
+    ref = api.FitchContext(text_rows=rows)          # stepped chain by chain through the single-tree calls
+    ref.set_chains(R)
+    for c in range(R):
+        t = host.HostTree(n, seed=80 + c)
+        for ctx in (multi, ref):
+            ctx.select_chain(c)
+            t.upload(ctx)
+    rng = np.random.default_rng(9)
+    kinds = [0, 1, 2, -1]
+    for step in range(10):
+        active = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
+        draws = [(c, int(rng.integers(1, 70 if n > 100 else 30)), kinds[(step + c) % 4], 1000 * step + c) for c in active]
+        got = multi.chains_propose_score(draws)
+        picks = []
+        for (c, count, kind, seed), lens in zip(draws, got):
+            ref.select_chain(c)
+            want = ref.propose_score(count, kind, seed)
+            assert np.array_equal(lens, want), (step, c)
+            ok = np.nonzero(lens < np.iinfo(np.int64).max)[0]
+            if len(ok) and (step + c) % 3 != 2:      # some chains accept, some do not
+                b = int(ok[np.argmin(lens[ok])])
+                picks.append((c, b))
+                edits, _ = ref.proposal_edits(b)
+                assert ref.commit(edits) == lens[b]
+        if picks:
+            multi.chains_commit(picks)
+        for c in range(R):
+            multi.select_chain(c)
+            ref.select_chain(c)
+            assert multi.current_length() == ref.current_length(), (step, c)
+            assert np.array_equal(multi.changes(), ref.changes())
+            pm, pr = multi.topology(), ref.topology()
+            assert all(np.array_equal(a, b) for a, b in zip(pm[:3], pr[:3])) and pm[3] == pr[3]
+            for v in (n, n + (n - 3) // 2, 2 * n - 4):
+                assert np.array_equal(multi.sets(v), ref.sets(v))
+    # stale picks and bad arguments are refused
+    got = multi.chains_propose_score([(0, 5, 1, 1), (1, 5, 1, 2)])
+    multi.chains_commit([(0, 0)])
+    with pytest.raises(api.LvbGpuError) as ei:
+        multi.chains_commit([(0, 1)])                  # chain 0's tree has changed since the draw
+    assert ei.value.status == -5
+    multi.chains_commit([(1, 4)])                      # chain 1's draw is still good
+    for bad in ([(2, 0)], [(1, 9)], [(0, 0), (0, 1)]):
+        with pytest.raises(api.LvbGpuError):
+            multi.chains_commit(bad)
+    with pytest.raises(api.LvbGpuError):
+        multi.chains_propose_score([(0, 5, 1, 1), (0, 5, 1, 2)])
+    multi.close()
+    ref.close()
