@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--anneal-seconds", type=float, default=4.0,
                     help="run the batched SA host end to end for this long and report best-length-vs-wallclock (0 = skip)")
     ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
+    ap.add_argument("--anneal-chains", type=int, default=16, help="independent chains stepped together on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 and uniform-alignment legs")
     ap.add_argument("--headline-only", action="store_true",
@@ -524,28 +525,49 @@ def rank_main(args) -> None:
         tree.upload(ctx)
 
     if args.anneal_seconds > 0 and not args.headline_only and (extras or world > 1):
-        # second half of the metric: best length vs wall clock, whole host loop included
-        # (proposal generation, program build, H2D, kernels, D2H, accept/commit) - not part of `value`
-        p = host.anneal_defaults()
-        p.seed = args.seed * 7919 + rank + 1
-        p.algorithm = {"nni": 10, "spr": 11, "tbr": 12}[args.move]
-        p.batch = args.anneal_batch
-        p.t0 = 0.0   # estimated as StartingTemperature() does (65 % of uphill moves accepted)
-        p.min_len_tree = min_len
-        p.max_seconds = args.anneal_seconds
-        p.log_cap = 4096
-        res, log = host.anneal(ctx, tree, p)
+        # second half of the metric: best length vs wall clock, whole host loop included (starting temperature,
+        # neighbours drawn + scored + committed on the GPU, accept / cool on the host) - not part of `value`.
+        # R independent chains are stepped together on this GPU: a device step serves all of them.
+        def params_for(c):
+            p = host.anneal_defaults()
+            p.seed = args.seed * 7919 + 1000 * rank + c + 1
+            p.algorithm = {"nni": 10, "spr": 11, "tbr": 12}[args.move]
+            p.batch = args.anneal_batch
+            p.t0 = 0.0   # estimated as StartingTemperature() does (65 % of uphill moves accepted)
+            p.min_len_tree = min_len
+            p.max_seconds = args.anneal_seconds
+            p.log_cap = 4096
+            return p
+        R = max(1, args.anneal_chains)
+        actx = api.FitchContext(text_rows=rows, device=ranks.device)
+        atrees = [host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100 + c) for c in range(R)]
+        res, log = host.anneal_chains(actx, atrees, [params_for(c) for c in range(R)])
         keep = log[:: max(1, len(log) // 12)] + log[-1:]
+        secs = max(r["seconds"] for r in res)
+        tot = lambda k: sum(r[k] for r in res)
         if rank == 0:
             out["anneal"] = {
-                "seconds": round(res["seconds"], 3), "start_length": res["start_length"],
-                "best_length": res["best_length"], "scored": res["scored"], "consumed": res["consumed"],
-                "accepted": res["accepted"], "device_steps": res["device_steps"],
-                "scored_per_s": round(res["scored"] / res["seconds"]), "consumed_per_s": round(res["consumed"] / res["seconds"]),
-                "device_fraction": round(res["seconds_device"] / res["seconds"], 3), "batch": args.anneal_batch,
-                "t_final": res["t_final"], "temperatures": res["temperatures"], "frozen": res["frozen"],
+                "chains": R, "seconds": round(secs, 3),
+                "best_length": min(r["best_length"] for r in res), "best_lengths": [r["best_length"] for r in res],
+                "start_lengths": [r["start_length"] for r in res],
+                "scored": tot("scored"), "consumed": tot("consumed"), "accepted": tot("accepted"),
+                "device_steps": max(r["device_steps"] for r in res), "chain_steps": tot("device_steps"),
+                "scored_per_s": round(tot("scored") / secs), "consumed_per_s": round(tot("consumed") / secs),
+                "device_fraction": round(res[0]["seconds_device"] / secs, 3), "batch": args.anneal_batch,
+                "temperatures": [r["temperatures"] for r in res], "frozen": sum(r["frozen"] for r in res),
                 "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
+                "what": f"{R} independent chains (own seeds and start trees) stepped together: one generator launch, one "
+                        "walk and one commit walk per device step for all of them; starting temperatures included",
             }
+            # one chain alone, for comparison: the same loop with R = 1
+            one, _ = host.anneal_chains(actx, atrees[:1], [params_for(0)])
+            out["anneal"]["single_chain"] = {
+                "seconds": round(one[0]["seconds"], 3), "best_length": one[0]["best_length"], "scored": one[0]["scored"],
+                "consumed": one[0]["consumed"], "device_steps": one[0]["device_steps"],
+                "scored_per_s": round(one[0]["scored"] / one[0]["seconds"]), "frozen": one[0]["frozen"]}
+        for t in atrees:
+            t.close()
+        actx.close()
     tree.close()
     ctx.close()
     ranks.close()

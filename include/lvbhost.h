@@ -169,6 +169,16 @@ int lvbhost_anneal(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost_anneal_par
                    lvbhost_anneal_result *result, double *log_seconds, int64_t *log_best);
 int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost_anneal_params *params,
                                  double *t0_out);
+/* R independent chains (restarts) on one GPU, stepped together: every device step draws, scores and commits for all
+ * of them at once (lvbgpu_chains_propose_score / lvbgpu_chains_commit), so a step's latency is paid once instead of
+ * R times.  trees[c] is chain c's start tree (made resident in slot c here; the context gets R slots if it has another
+ * number), params[c] its parameters (own seed; t0 <= 0: estimated per chain as StartingTemperature() does, in the
+ * same steps), results[c] its outcome; neighbours are always drawn on the device.  A chain's trajectory depends on its
+ * own parameters only, not on R.  params[0] supplies what concerns the whole run: max_seconds, max_device_steps,
+ * sync_every (lockstep RCCL min-reduce of the best length over ranks, as lvbhost_anneal) and log_cap of the shared
+ * log (wall time, best length over all chains).  1 <= R <= 64. */
+int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, const lvbhost_anneal_params *params,
+                          lvbhost_anneal_result *results, double *log_seconds, int64_t *log_best, int32_t *n_log);
 /* make `tree` resident in ctx (full evaluation) */
 int lvbhost_tree_upload(lvbgpu_ctx *ctx, const lvbhost_tree *tree, int64_t *length_out);
 

@@ -24,7 +24,7 @@ GPU_SOURCES = ["fitch_kernels.hip", "propose_kernels.hip", "api_core.cpp", "api_
                "api_compat.cpp", "api_comm.cpp", "program.cpp"]
 GPU_HEADERS = ["kernels.hpp", "program.hpp", "pool.hpp", "ctx.hpp"]
 COMPAT_SOURCES = ["getplen_adapter.cpp"]
-HOST_SOURCES = ["host_api.cpp", "proposals.cpp", "anneal.cpp", "refsearch.cpp", "program.cpp"]
+HOST_SOURCES = ["host_api.cpp", "proposals.cpp", "anneal.cpp", "anneal_chains.cpp", "refsearch.cpp", "program.cpp"]
 HOST_HEADERS = ["program.hpp", "proposals.hpp", "host_tree.hpp", "refrng.hpp"]
 
 

@@ -1,0 +1,529 @@
+// anneal_chains.cpp - R independent annealing chains on ONE GPU, stepped together.
+//
+// A single chain cannot fill the chip: its step is a chain of small dependent launches (generator, walk, commit) on a
+// device that could run a hundred such chains at once, and while most proposals are accepted a step carries only a
+// handful of candidates.  The remedy the reference's design offers is the one north_star names for GPUs: independent
+// restarts.  Here R of them live in one context (lvbgpu_set_chains: the alignment once, R resident trees) and every
+// device step serves all of them: ONE generator launch draws every chain's candidates, ONE walk scores them, the
+// lengths come back together, every chain consumes its own candidates exactly as the serial loop would (Solve.c:300-378),
+// and ONE commit walk applies every chain's accepted move.  The step's latency is paid once, not R times.
+//
+// Each chain is the loop of anneal.cpp / the reference's Anneal() and StartingTemperature() turned into a state
+// machine: plan() says how many candidates of which kinds the chain wants next (speculation depth from its own
+// acceptance rate; never across a cooling step or a re-root tick), consume() eats the lengths in order up to the first
+// acceptance, after_commit() finishes that proposal once the tree has moved.  A chain's decisions depend on its own
+// state and random stream only, so its trajectory is the same whatever R is (tests/test_gpu_chains.py).
+#include "../../include/lvbhost.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#include "host_tree.hpp"
+
+using namespace lvbgpu;
+
+namespace
+{
+
+constexpr double LVB_EPS = 1e-11;   // LVB.h:102
+constexpr double FROZEN_T = 0.0001; // LVB.h:115
+constexpr double DBL_EPS = 2.220446049250313e-16;
+
+using Clock = std::chrono::steady_clock;
+inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+// Metropolis decision of Solve.c:303-378 for a proposal that is worse than the current tree
+inline bool accept_worse(double deltah, double t, Rng &rng)
+{
+    static const double log_eps = std::log(LVB_EPS);
+    if (-deltah < t * log_eps)
+    {
+        (void)rng.uniform(); // the reference draws here too (Solve.c:352-355)
+        return false;
+    }
+    return rng.uniform() < std::exp(-deltah / t);
+}
+inline double energy_delta(double minlen, int64_t cur, int64_t prop)
+{
+    double d = minlen / (double)cur - minlen / (double)prop;
+    return d > 1.0 ? 1.0 : d;
+}
+inline uint32_t scaled(double p) { return (uint32_t)std::min(4294967295.0, std::max(0.0, p) * 4294967296.0); }
+
+struct ChainRun
+{
+    int32_t chain = 0;
+    lvbgpu_ctx *ctx = nullptr;
+    lvbhost_tree *tree = nullptr;
+    lvbhost_anneal_params p{};
+    lvbhost_anneal_result *res = nullptr;
+    double minlen = 1.0;
+
+    enum Phase
+    {
+        START_TEMP,
+        ANNEAL,
+        DONE
+    } phase = START_TEMP;
+
+    int64_t cur = 0, best = 0;
+    // starting temperature (StartingTemperature.c:49-195)
+    double st_t = LVB_EPS;
+    int st_acc_pos = 0, st_prop_pos = 0, st_iter = 0;
+    bool st_rerooted = false;
+    // annealing (Solve.c:144-479)
+    double t0 = 0, t = 0, log_t0 = 0;
+    int64_t accepted = 0, proposed = 0, failedcnt = 0, t_n = 0, iter = 0, current_iter = 0;
+    double probs[3] = {0, 0, 0}, counter[3] = {1, 1, 1};
+    double accept_rate = 0.5;
+    // the step in flight
+    int B = 0;
+    int consumed_now = 0, accepted_now = 0;
+    int64_t pending_len = 0; // length of the accepted candidate (after_commit finishes the proposal)
+    bool pending_stack = false;
+    int rc = LVBGPU_OK;
+
+    void probs_from_counters()
+    {
+        const long total = (long)(counter[0] + counter[1] + counter[2]); // a long in the reference too
+        for (int i = 0; i < 3; i++)
+            probs[i] = counter[i] / total;
+    }
+
+    // arbreroot (TreeOperations.c:639-656): a random leaf other than the current root, as a commit of the rewrites
+    // along the old-root..new-root path; the length does not change (it is root-independent), nothing is read back
+    int reroot()
+    {
+        int32_t nr;
+        do
+            nr = (int32_t)tree->rng.below((uint32_t)tree->topo.n);
+        while (nr == tree->topo.root);
+        std::vector<Edit> ed;
+        reroot_edits(tree->topo, nr, ed);
+        int r = lvbgpu_select_chain(ctx, chain);
+        if (r == LVBGPU_OK)
+            r = lvbgpu_commit(ctx, (int32_t)ed.size(), reinterpret_cast<const lvbgpu_edit *>(ed.data()), nr, nullptr);
+        if (r == LVBGPU_OK)
+            r = lvbhost_tree_apply(tree, reinterpret_cast<const lvbgpu_edit *>(ed.data()), (int32_t)ed.size(), nr);
+        res->reroots++;
+        return r;
+    }
+
+    void begin_anneal(double start_t)
+    {
+        phase = ANNEAL;
+        t0 = t = start_t;
+        log_t0 = std::log(t0);
+        best = cur;
+        if (p.algorithm == 2)
+            probs_from_counters();
+        tree->best.clear();
+        tree->best.insert(tree->topo); // the initial tree is initially the best (Solve.c:208)
+    }
+
+    // what the chain wants scored next; false: nothing (done, or an error in rc)
+    bool plan(lvbgpu_chain_draw &d)
+    {
+        if (phase == DONE)
+            return false;
+        d.chain = chain;
+        d.mix_a = d.mix_b = 0;
+        if (phase == START_TEMP)
+        {
+            const int sample = 100; // StartingTemperature.c:86; iter runs 0..sample inclusive
+            if (st_iter % 1000 == 0 && !st_rerooted) // REROOT_INTERVAL: once per temperature (116-117)
+            {
+                rc = reroot();
+                if (rc != LVBGPU_OK)
+                    return false;
+                st_rerooted = true;
+            }
+            B = std::min(std::max(1, std::min(p.batch, 64)), sample + 1 - st_iter);
+            d.kind = -2; // NNI / SPR alternate (123-126)
+            d.mix_a = (uint32_t)(st_iter & 1);
+        }
+        else
+        {
+            // Speculation depth follows the acceptance rate: when most proposals are accepted, all but the first few
+            // of a batch would be thrown away; when acceptances are rare the whole batch is consumed
+            int64_t room = std::min<int64_t>(p.batch, std::max<int64_t>(8, (int64_t)std::ceil(2.0 / accept_rate)));
+            if (p.reroot_interval > 0)
+            {
+                const int64_t to_tick = p.reroot_interval - (current_iter % p.reroot_interval);
+                if (to_tick == 1) // the reference re-roots when the incremented counter hits a multiple (Solve.c:238-242)
+                {
+                    rc = reroot();
+                    if (rc != LVBGPU_OK)
+                        return false;
+                    room = std::min<int64_t>(room, p.reroot_interval);
+                }
+                else
+                    room = std::min(room, to_tick - 1);
+            }
+            room = std::min(room, std::max<int64_t>(1, p.maxpropose - proposed));
+            if (p.max_proposals > 0)
+                room = std::min(room, std::max<int64_t>(1, p.max_proposals - iter));
+            B = (int)std::max<int64_t>(1, room);
+            if (p.algorithm == 2)
+                probs_from_counters(); // per batch here, per iteration in the reference
+            switch (p.algorithm)
+            {
+            case 0: // Solve.c:288-297
+                d.kind = -2;
+                d.mix_a = (uint32_t)(iter & 1);
+                break;
+            case 10: d.kind = MOVE_NNI; break;
+            case 11: d.kind = MOVE_SPR; break;
+            case 12: d.kind = MOVE_TBR; break;
+            default: // Solve.c:262-283
+                d.kind = -3;
+                d.mix_a = scaled(probs[0]);
+                d.mix_b = scaled(probs[0] + probs[1]);
+            }
+        }
+        d.count = B;
+        d.seed = tree->rng.next();
+        consumed_now = accepted_now = 0;
+        res->device_steps++;
+        res->scored += B;
+        return true;
+    }
+
+    // cooling decision after one consumed proposal (Solve.c:380-443); returns true if the temperature changed
+    bool after_proposal()
+    {
+        proposed++;
+        iter++;
+        bool dect = false;
+        if (accepted >= p.maxaccept)
+        {
+            failedcnt = 0;
+            dect = true;
+        }
+        else if (proposed >= p.maxpropose)
+        {
+            failedcnt++;
+            if (failedcnt >= p.maxfail && t < FROZEN_T)
+            {
+                res->frozen = 1;
+                phase = DONE;
+            }
+            else
+                dect = true;
+        }
+        if (dect)
+        {
+            static const double log_eps = std::log(LVB_EPS), grad_geom = 0.99, log_geom = std::log(0.99), grad_linear = 10 * LVB_EPS;
+            t_n++;
+            if (p.cooling_schedule == 0)
+            {
+                const double ln_t = (double)t_n * log_geom + log_t0;
+                t = (ln_t < log_eps) ? LVB_EPS : std::pow(grad_geom, (double)t_n) * t0;
+                if (p.algorithm == 1)
+                {
+                    probs[2] = t / t0;
+                    probs[1] = (1 - probs[2]) / 2;
+                    probs[0] = probs[1];
+                }
+            }
+            else
+            {
+                t = t0 - grad_linear * t_n;
+                if (t < DBL_EPS || t <= LVB_EPS)
+                    t = LVB_EPS;
+            }
+            proposed = 0;
+            accepted = 0;
+            res->temperatures++;
+        }
+        if (p.max_proposals > 0 && iter >= p.max_proposals)
+            phase = DONE;
+        return dect;
+    }
+
+    void end_of_start_temperature_sample()
+    {
+        const double ratio = st_prop_pos ? (double)st_acc_pos / st_prop_pos : 0.0;
+        st_t += 0.00001; // increment_size
+        st_acc_pos = st_prop_pos = st_iter = 0;
+        st_rerooted = false;
+        if (st_t >= 1 || st_t <= 0)
+            begin_anneal(1.0);
+        else if (ratio > 0.65)
+            begin_anneal(st_t - 0.00001);
+    }
+
+    // eat this step's lengths in order; returns the index of the accepted candidate (the rest is stale then), or -1
+    int consume(const int64_t *lens)
+    {
+        if (phase == START_TEMP)
+        {
+            for (int b = 0; b < B; b++)
+            {
+                st_iter++;
+                const int64_t len = lens[b];
+                if (len == INT64_MAX)
+                    continue; // a device candidate that did not fit its buffers: not a proposal
+                bool take = len <= cur;
+                if (!take)
+                {
+                    st_prop_pos++;
+                    take = accept_worse(energy_delta(minlen, cur, len), st_t, tree->rng);
+                    if (take)
+                        st_acc_pos++;
+                }
+                if (take)
+                {
+                    pending_len = len;
+                    return b;
+                }
+            }
+            if (st_iter > 100)
+                end_of_start_temperature_sample();
+            return -1;
+        }
+        for (int b = 0; b < B && phase == ANNEAL; b++)
+        {
+            const int64_t len = lens[b];
+            if (len == INT64_MAX)
+                continue;
+            current_iter++;
+            consumed_now++;
+            if (p.algorithm == 2) // the kinds of device-drawn candidates stay on the device: expected gain under the probabilities
+                for (int i = 0; i < 3; i++)
+                    counter[i] += 0.5 * (1.0 - probs[i]);
+            const bool take = len <= cur || accept_worse(energy_delta(minlen, cur, len), t, tree->rng);
+            if (take)
+            {
+                accepted_now++;
+                pending_stack = len <= cur && len <= best; // ties or beats the best (Solve.c:309)
+                pending_len = len;
+                return b;
+            }
+            if (after_proposal())
+                break; // new temperature: start a fresh batch
+        }
+        end_of_step();
+        return -1;
+    }
+
+    void end_of_step()
+    {
+        if (consumed_now > 0)
+            accept_rate = std::max(1e-4, 0.8 * accept_rate + 0.2 * (double)accepted_now / consumed_now);
+    }
+
+    // the accepted candidate has been committed on the device: follow it here and finish the proposal.
+    // Returns true if the chain's best length improved.
+    bool after_commit()
+    {
+        // the chain's topology after the move, as the library holds it
+        rc = lvbgpu_select_chain(ctx, chain);
+        if (rc == LVBGPU_OK)
+            rc = lvbgpu_get_topology(ctx, tree->topo.parent.data(), tree->topo.left.data(), tree->topo.right.data(), &tree->topo.root);
+        if (rc != LVBGPU_OK)
+            return false;
+        cur = pending_len;
+        if (phase == START_TEMP)
+        {
+            if (st_iter > 100)
+                end_of_start_temperature_sample();
+            return false;
+        }
+        res->accepted++;
+        bool improved = false;
+        if (pending_stack)
+        {
+            if (cur < best)
+                tree->best.clear(); // discard old bests (Solve.c:312-315)
+            if (tree->best.insert(tree->topo))
+                accepted++; // only topologies new to the treestack count (316-319)
+        }
+        if (cur < best)
+        {
+            best = cur;
+            improved = true;
+        }
+        (void)after_proposal();
+        end_of_step();
+        return improved;
+    }
+
+    void finish()
+    {
+        res->best_length = best;
+        res->final_length = cur;
+        res->global_best_length = best;
+        res->topologies = (int64_t)tree->best.count();
+        res->consumed = iter;
+        res->t_final = t;
+    }
+};
+
+} // namespace
+
+extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, const lvbhost_anneal_params *params,
+                                     lvbhost_anneal_result *results, double *log_seconds, int64_t *log_best, int32_t *n_log)
+{
+    if (!ctx || R < 1 || R > 64 || !trees || !params || !results)
+        return LVBGPU_E_ARG;
+    const auto wall0 = Clock::now();
+    int rc = LVBGPU_OK;
+    if (lvbgpu_chains(ctx) != R)
+        rc = lvbgpu_set_chains(ctx, R);
+    std::vector<ChainRun> runs((size_t)R);
+    for (int32_t c = 0; c < R && rc == LVBGPU_OK; c++)
+    {
+        if (!trees[c])
+            return LVBGPU_E_ARG;
+        ChainRun &r = runs[(size_t)c];
+        r.chain = c;
+        r.ctx = ctx;
+        r.tree = trees[c];
+        r.p = params[c];
+        if (r.p.batch < 1)
+            r.p.batch = 1;
+        r.res = &results[c];
+        *r.res = lvbhost_anneal_result{};
+        r.minlen = (double)r.p.min_len_tree;
+        r.tree->rng = Rng(r.p.seed);
+        rc = lvbgpu_select_chain(ctx, c);
+        if (rc == LVBGPU_OK)
+            rc = lvbhost_tree_upload(ctx, r.tree, &r.cur);
+        r.res->start_length = r.cur;
+        if (r.p.t0 > 0.0)
+            r.begin_anneal(r.p.t0);
+    }
+    if (rc != LVBGPU_OK)
+        return rc;
+    const int32_t log_cap = params[0].log_cap;
+    int32_t nlog = 0;
+    int64_t global_best = INT64_MAX;
+    auto log_point = [&] {
+        // best length of the annealing proper: what a chain passes through while its starting temperature is being
+        // estimated does not count (the reference's best starts with Anneal(), Solve.c:208)
+        int64_t g = INT64_MAX;
+        for (const ChainRun &r : runs)
+            if (r.phase != ChainRun::START_TEMP)
+                g = std::min(g, r.best);
+        if (g < global_best)
+        {
+            global_best = g;
+            if (log_seconds && log_best && nlog < log_cap)
+            {
+                log_seconds[nlog] = since(wall0);
+                log_best[nlog] = g;
+                nlog++;
+            }
+        }
+    };
+    log_point();
+
+    std::vector<lvbgpu_chain_draw> draws;
+    std::vector<int32_t> who;
+    std::vector<int64_t> lens;
+    std::vector<lvbgpu_chain_pick> picks;
+    std::vector<int32_t> picked;
+    int64_t steps = 0;
+    double dev_seconds = 0.0;
+    const bool lockstep = params[0].sync_every > 0;
+    if (lockstep && params[0].max_device_steps <= 0)
+        return LVBGPU_E_ARG;
+    for (;;)
+    {
+        draws.clear();
+        who.clear();
+        size_t total = 0;
+        for (ChainRun &r : runs)
+        {
+            lvbgpu_chain_draw d{};
+            if (r.plan(d))
+            {
+                draws.push_back(d);
+                who.push_back(r.chain);
+                total += (size_t)d.count;
+            }
+            else if (r.rc != LVBGPU_OK)
+                return r.rc;
+        }
+        if (draws.empty() && !lockstep)
+            break;
+        if (!draws.empty())
+        {
+            lens.resize(total);
+            auto td = Clock::now();
+            rc = lvbgpu_chains_propose_score(ctx, (int32_t)draws.size(), draws.data(), lens.data());
+            dev_seconds += since(td);
+            if (rc != LVBGPU_OK)
+                return rc;
+            picks.clear();
+            picked.clear();
+            size_t off = 0;
+            for (size_t i = 0; i < draws.size(); i++)
+            {
+                ChainRun &r = runs[(size_t)who[i]];
+                const int b = r.consume(lens.data() + off);
+                off += (size_t)draws[i].count;
+                if (b >= 0)
+                {
+                    picks.push_back({r.chain, b});
+                    picked.push_back(r.chain);
+                }
+            }
+            if (!picks.empty())
+            {
+                td = Clock::now();
+                rc = lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
+                dev_seconds += since(td);
+                if (rc != LVBGPU_OK)
+                    return rc;
+                for (int32_t c : picked)
+                {
+                    (void)runs[(size_t)c].after_commit();
+                    if (runs[(size_t)c].rc != LVBGPU_OK)
+                        return runs[(size_t)c].rc;
+                }
+            }
+            log_point(); // R comparisons: nothing next to a device step
+        }
+        steps++;
+        bool stop = false;
+        if (params[0].max_seconds > 0 && since(wall0) >= params[0].max_seconds)
+            stop = true;
+        if (params[0].max_device_steps > 0 && steps >= params[0].max_device_steps)
+            stop = true;
+        if (lockstep) // every rank runs the same number of steps so that the collectives pair up
+        {
+            stop = steps >= params[0].max_device_steps;
+            if (steps % params[0].sync_every == 0 || stop)
+            {
+                int64_t g = global_best;
+                rc = lvbgpu_allreduce_min(ctx, &g, nullptr);
+                if (rc != LVBGPU_OK)
+                    return rc;
+                for (ChainRun &r : runs)
+                    r.res->global_best_length = g;
+            }
+        }
+        if (stop)
+            break;
+    }
+    const double secs = since(wall0);
+    for (ChainRun &r : runs)
+    {
+        const int64_t keep_global = r.res->global_best_length;
+        r.finish();
+        if (lockstep)
+            r.res->global_best_length = keep_global;
+        r.res->seconds = secs;
+        r.res->seconds_device = dev_seconds;
+    }
+    if (n_log)
+        *n_log = nlog;
+    return LVBGPU_OK;
+}

@@ -89,6 +89,8 @@ SIGNATURES = {
     "lvbhost_anneal_defaults": (None, [C.POINTER(AnnealParams)]),
     "lvbhost_anneal": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AnnealParams), C.POINTER(AnnealResult),
                                  C.c_void_p, C.c_void_p]),
+    "lvbhost_anneal_chains": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(AnnealParams),
+                                        C.POINTER(AnnealResult), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "lvbhost_starting_temperature": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AnnealParams),
                                                C.POINTER(C.c_double)]),
     "lvbhost_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
@@ -384,6 +386,22 @@ def anneal(ctx: api.FitchContext, tree: HostTree, params: AnnealParams):
     out = {k: getattr(res, k) for k, _ in AnnealResult._fields_}
     log = [(float(secs[i]), int(best[i])) for i in range(res.n_log)]
     return out, log
+
+
+def anneal_chains(ctx: api.FitchContext, trees: list[HostTree], params: list[AnnealParams]):
+    """R chains stepped together on one GPU -> ([result dict per chain], [(seconds, best over all chains), ...])."""
+    lib = load_library()
+    R = len(trees)
+    cap = max(int(params[0].log_cap), 0)
+    secs = np.zeros(max(cap, 1), dtype=np.float64)
+    best = np.zeros(max(cap, 1), dtype=np.int64)
+    handles = (C.c_void_p * R)(*[t.h for t in trees])
+    pars = (AnnealParams * R)(*params)
+    res = (AnnealResult * R)()
+    nlog = C.c_int32()
+    ctx._chk(lib.lvbhost_anneal_chains(ctx.h, R, handles, pars, res, secs.ctypes.data, best.ctypes.data, C.byref(nlog)))
+    out = [{k: getattr(res[c], k) for k, _ in AnnealResult._fields_} for c in range(R)]
+    return out, [(float(secs[i]), int(best[i])) for i in range(nlog.value)]
 
 
 def starting_temperature(ctx: api.FitchContext, tree: HostTree, params: AnnealParams) -> float:

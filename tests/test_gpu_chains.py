@@ -144,3 +144,51 @@ def test_one_step_over_all_chains_equals_the_chains_stepped_one_by_one(mods, n, 
         multi.chains_propose_score([(0, 5, 1, 1), (0, 5, 1, 2)])
     multi.close()
     ref.close()
+
+
+def _run_chains(api, host, rows, min_len, n, seeds, max_proposals, algorithm):
+    ctx = api.FitchContext(text_rows=rows)
+    trees = [host.HostTree(n, seed=1000 + s) for s in seeds]
+    params = []
+    for s in seeds:
+        p = host.anneal_defaults()
+        p.seed = 7000 + s
+        p.algorithm = algorithm
+        p.batch = 256
+        p.t0 = 0.0                      # every chain estimates its own starting temperature
+        p.min_len_tree = min_len
+        p.max_proposals = max_proposals
+        p.log_cap = 64
+        params.append(p)
+    res, log = host.anneal_chains(ctx, trees, params)
+    final = []
+    for c, t in enumerate(trees):
+        ctx.select_chain(c)
+        _, l, r = t.arrays()
+        # the host's mirror is the library's tree, and the resident length is what the chain believes
+        _, ll, lr, lroot = ctx.topology()
+        assert np.array_equal(l, ll) and np.array_equal(r, lr) and t.root == lroot
+        assert ctx.current_length() == res[c]["final_length"]
+        final.append((l.copy(), r.copy(), t.root, t.best_count()))
+    ctx.close()
+    return res, final, log
+
+
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_a_chains_trajectory_does_not_depend_on_how_many_chains_run_beside_it(mods, algorithm):
+    """R = 1 vs R = 6: identical decisions per chain for fixed seeds (the chains share launches, nothing else)."""
+    api, host = mods
+    n, m = 40, 1500
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 91))
+    seeds = [3, 4, 5, 6, 7, 8]
+    many, many_final, log = _run_chains(api, host, rows, min_len, n, seeds, 2500, algorithm)
+    keys = ("start_length", "best_length", "final_length", "consumed", "accepted", "temperatures", "device_steps", "scored",
+            "reroots", "topologies", "t_final")
+    for pick in (0, 3, 5):
+        one, one_final, _ = _run_chains(api, host, rows, min_len, n, [seeds[pick]], 2500, algorithm)
+        assert {k: one[0][k] for k in keys} == {k: many[pick][k] for k in keys}
+        assert all(np.array_equal(a, b) for a, b in zip(one_final[0][:2], many_final[pick][:2]))
+        assert one_final[0][2:] == many_final[pick][2:]
+    assert all(r["consumed"] == 2500 and r["best_length"] <= r["start_length"] for r in many)
+    assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)      # the shared log only ever improves
+    assert log[-1][1] == min(r["best_length"] for r in many)
