@@ -560,7 +560,9 @@ def rank_main(args) -> None:
                         "walk and one commit walk per device step for all of them; starting temperatures included",
             }
             # one chain alone, for comparison: the same loop with R = 1
-            one, _ = host.anneal_chains(actx, atrees[:1], [params_for(0)])
+            fresh = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100)
+            one, _ = host.anneal_chains(actx, [fresh], [params_for(0)])
+            fresh.close()
             out["anneal"]["single_chain"] = {
                 "seconds": round(one[0]["seconds"], 3), "best_length": one[0]["best_length"], "scored": one[0]["scored"],
                 "consumed": one[0]["consumed"], "device_steps": one[0]["device_steps"],

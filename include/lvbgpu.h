@@ -188,6 +188,9 @@ typedef struct
     int32_t chain, b;
 } lvbgpu_chain_pick;
 int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_pick *picks);
+/* the rewrites of pick j of the LAST lvbgpu_chains_commit (for a host that mirrors the topologies): already on the
+ * host, no device access */
+int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits);
 
 /* counts of the LAST device-built batch (as lvbgpu_batch_get_stats gives for host-built ones; candidates that
  * overflowed are left out): reads the batch's descriptors back - for measurement, not for the search */

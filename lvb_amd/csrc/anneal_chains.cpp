@@ -20,6 +20,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -87,6 +88,7 @@ struct ChainRun
     int64_t pending_len = 0; // length of the accepted candidate (after_commit finishes the proposal)
     bool pending_stack = false;
     int rc = LVBGPU_OK;
+    std::vector<lvbgpu_edit> fetched;
 
     void probs_from_counters()
     {
@@ -320,12 +322,14 @@ struct ChainRun
 
     // the accepted candidate has been committed on the device: follow it here and finish the proposal.
     // Returns true if the chain's best length improved.
-    bool after_commit()
+    bool after_commit(int32_t pick_index)
     {
-        // the chain's topology after the move, as the library holds it
-        rc = lvbgpu_select_chain(ctx, chain);
+        // the move's rewrites are on the host already (the commit fetched them): follow them
+        fetched.resize((size_t)2 * tree->topo.nb + 8);
+        int32_t ne = 0;
+        rc = lvbgpu_chains_picked_edits(ctx, pick_index, fetched.data(), (int32_t)fetched.size(), &ne);
         if (rc == LVBGPU_OK)
-            rc = lvbgpu_get_topology(ctx, tree->topo.parent.data(), tree->topo.left.data(), tree->topo.right.data(), &tree->topo.root);
+            rc = lvbhost_tree_apply(tree, fetched.data(), ne, -1);
         if (rc != LVBGPU_OK)
             return false;
         cur = pending_len;
@@ -431,6 +435,7 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
     std::vector<int32_t> picked;
     int64_t steps = 0;
     double dev_seconds = 0.0;
+    double t_plan = 0, t_score = 0, t_consume = 0, t_commit = 0, t_after = 0; // LVBHOST_PROFILE=1 prints them
     const bool lockstep = params[0].sync_every > 0;
     if (lockstep && params[0].max_device_steps <= 0)
         return LVBGPU_E_ARG;
@@ -439,6 +444,7 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
         draws.clear();
         who.clear();
         size_t total = 0;
+        auto tp = Clock::now();
         for (ChainRun &r : runs)
         {
             lvbgpu_chain_draw d{};
@@ -451,6 +457,7 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
             else if (r.rc != LVBGPU_OK)
                 return r.rc;
         }
+        t_plan += since(tp);
         if (draws.empty() && !lockstep)
             break;
         if (!draws.empty())
@@ -459,11 +466,13 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
             auto td = Clock::now();
             rc = lvbgpu_chains_propose_score(ctx, (int32_t)draws.size(), draws.data(), lens.data());
             dev_seconds += since(td);
+            t_score += since(td);
             if (rc != LVBGPU_OK)
                 return rc;
             picks.clear();
             picked.clear();
             size_t off = 0;
+            tp = Clock::now();
             for (size_t i = 0; i < draws.size(); i++)
             {
                 ChainRun &r = runs[(size_t)who[i]];
@@ -475,19 +484,24 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
                     picked.push_back(r.chain);
                 }
             }
+            t_consume += since(tp);
             if (!picks.empty())
             {
                 td = Clock::now();
                 rc = lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
                 dev_seconds += since(td);
+                t_commit += since(td);
                 if (rc != LVBGPU_OK)
                     return rc;
-                for (int32_t c : picked)
+                tp = Clock::now();
+                for (size_t j = 0; j < picked.size(); j++)
                 {
-                    (void)runs[(size_t)c].after_commit();
+                    const int32_t c = picked[j];
+                    (void)runs[(size_t)c].after_commit((int32_t)j);
                     if (runs[(size_t)c].rc != LVBGPU_OK)
                         return runs[(size_t)c].rc;
                 }
+                t_after += since(tp);
             }
             log_point(); // R comparisons: nothing next to a device step
         }
@@ -514,6 +528,11 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
             break;
     }
     const double secs = since(wall0);
+    if (getenv("LVBHOST_PROFILE"))
+        fprintf(stderr, "[anneal_chains] R=%d steps=%lld  per step (us): plan %.1f  propose_score %.1f  consume %.1f  commit %.1f  "
+                        "after_commit %.1f  total %.1f\n",
+                R, (long long)steps, 1e6 * t_plan / steps, 1e6 * t_score / steps, 1e6 * t_consume / steps, 1e6 * t_commit / steps,
+                1e6 * t_after / steps, 1e6 * secs / steps);
     for (ChainRun &r : runs)
     {
         const int64_t keep_global = r.res->global_best_length;

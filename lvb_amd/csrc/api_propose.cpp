@@ -133,17 +133,32 @@ int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
             for (size_t i = (size_t)t; i < stale.size(); i += (size_t)T)
                 build((int32_t)i);
         });
+    int32_t lo = INT32_MAX, hi = -1;
     for (size_t i = 0; i < stale.size(); i++)
     {
         if (bytes[i] == 0)
             return ctx->fail(LVBGPU_E_ARG, "generator tables exceed their slot");
         ChainSlot &cs = ctx->parked[(size_t)stale[i]];
-        const size_t off = (size_t)stale[i] * ctx->gen_table_stride;
-        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + off, (const char *)ctx->h_topo.p + off, bytes[i], hipMemcpyHostToDevice,
-                                   ctx->stream));
         cs.gen_table_bytes = bytes[i];
         cs.d_topo_version = cs.topo_version;
+        lo = std::min(lo, stale[i]);
+        hi = std::max(hi, stale[i]);
     }
+    // a copy costs a few microseconds before its first byte moves: from three stale chains on, ONE copy of the span
+    // they cover (a staging slot always holds its chain's current tables, so what lies between is merely re-sent)
+    if (stale.size() >= 3)
+    {
+        const size_t off = (size_t)lo * ctx->gen_table_stride;
+        const size_t len = (size_t)(hi - lo) * ctx->gen_table_stride + ctx->parked[(size_t)hi].gen_table_bytes;
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + off, (const char *)ctx->h_topo.p + off, len, hipMemcpyHostToDevice, ctx->stream));
+    }
+    else
+        for (size_t i = 0; i < stale.size(); i++)
+        {
+            const size_t off = (size_t)stale[i] * ctx->gen_table_stride;
+            HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + off, (const char *)ctx->h_topo.p + off, bytes[i], hipMemcpyHostToDevice,
+                                       ctx->stream));
+        }
     return LVBGPU_OK;
 }
 } // namespace lvbgpu_detail
@@ -415,6 +430,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         return LVBGPU_E_ARG;
     if (ctx->p_segs.empty() || !ctx->prop_batch)
         return ctx->fail(LVBGPU_E_STATE, "no device batch to pick from: call lvbgpu_chains_propose_score first");
+    ctx->last_pick_count = 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     AllParked guard(ctx);
     lvbgpu_batch *bt = ctx->prop_batch;
@@ -505,6 +521,24 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         cs.topo_version = ++ctx->version_counter;
         cs.cur_length_stale = true;
     }
+    ctx->last_pick_slot = slot;
+    ctx->last_pick_count = k;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits)
+{
+    if (!ctx || !edits || !n_edits || j < 0)
+        return LVBGPU_E_ARG;
+    if (j >= ctx->last_pick_count)
+        return ctx->fail(LVBGPU_E_STATE, "the last lvbgpu_chains_commit had no such pick");
+    const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
+    const char *rec = (const char *)ctx->h_pick[ctx->last_pick_slot].p + 64 + align16((size_t)MAX_CHAINS * 4) + (size_t)j * out_stride;
+    const ProposalInfo pi = *(const ProposalInfo *)rec;
+    if (pi.n_edits > cap)
+        return ctx->fail(LVBGPU_E_ARG, "edit buffer too small");
+    memcpy(edits, rec + sizeof(ProposalInfo), (size_t)pi.n_edits * sizeof(lvbgpu_edit));
+    *n_edits = pi.n_edits;
     return LVBGPU_OK;
 }
 

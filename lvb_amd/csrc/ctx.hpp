@@ -215,6 +215,7 @@ struct lvbgpu_ctx
     hipEvent_t pick_ev[PICK_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int pick_slot = 0;
     uint32_t pick_seq = 0;
+    int last_pick_slot = 0, last_pick_count = 0; // what lvbgpu_chains_picked_edits reads
     DevBuf d_done; // per picked candidate: finished-wave count of a multi-chain commit (zero between launches)
     PinBuf h_pin;
     // direct steps: small batches whose programs the walk reads straight from h_pin and whose lengths its last

@@ -167,8 +167,32 @@ void BestSet::canonical(const Topology &t, std::vector<int32_t> &out)
     }
 }
 
+// A search that is still descending replaces the set at every improvement (clear + insert): the lone tree of a
+// fresh set is stored as it is, and its canonical form and hash are only worked out when a second tree of the same
+// length turns up and has to be compared with it.
+void BestSet::index_all()
+{
+    std::vector<uint64_t> sub;
+    for (size_t i = 0; i < kept.size(); i++)
+        if (kept[i].canon.empty())
+        {
+            Topology t;
+            std::string why;
+            if (!t.assign((int32_t)key.size(), kept[i].left.data(), kept[i].right.data(), kept[i].root, &why))
+                continue;
+            canonical(t, kept[i].canon);
+            by_hash.emplace(hash(t, sub), i);
+        }
+}
+
 bool BestSet::insert(const Topology &t)
 {
+    if (kept.empty())
+    {
+        kept.push_back({t.left, t.right, t.root, {}});
+        return true;
+    }
+    index_all();
     std::vector<uint64_t> sub;
     const uint64_t h = hash(t, sub);
     std::vector<int32_t> canon;
@@ -184,6 +208,7 @@ bool BestSet::insert(const Topology &t)
 
 BestSet::Kept BestSet::pop_last()
 {
+    index_all();
     Kept k = std::move(kept.back());
     kept.pop_back();
     for (auto it = by_hash.begin(); it != by_hash.end(); ++it)
@@ -197,10 +222,8 @@ BestSet::Kept BestSet::pop_last()
 
 void BestSet::push_kept(Kept &&k, std::vector<uint64_t> &scratch)
 {
-    Topology t;
-    std::string why;
-    if (t.assign((int32_t)key.size(), k.left.data(), k.right.data(), k.root, &why))
-        by_hash.emplace(hash(t, scratch), kept.size());
+    (void)scratch;
+    k.canon.clear(); // indexed again when needed
     kept.push_back(std::move(k));
 }
 

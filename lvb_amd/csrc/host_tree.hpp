@@ -24,7 +24,7 @@ struct BestSet
     {
         std::vector<int32_t> left, right;
         int32_t root;
-        std::vector<int32_t> canon;
+        std::vector<int32_t> canon; // empty until a second tree has to be told apart from this one (lazy)
     };
     std::vector<Kept> kept;                                   // every distinct topology, in order of arrival
     std::unordered_multimap<uint64_t, size_t> by_hash;        // hash -> index into kept
@@ -39,6 +39,7 @@ struct BestSet
     uint64_t hash(const lvbgpu::Topology &t, std::vector<uint64_t> &scratch) const;
     static void canonical(const lvbgpu::Topology &t, std::vector<int32_t> &out);
     bool insert(const lvbgpu::Topology &t); // true if the topology is new
+    void index_all();                       // canonical forms and hashes of the trees kept without them
     Kept pop_last();                        // take the newest tree off (and out of the index)
     void push_kept(Kept &&k, std::vector<uint64_t> &scratch); // put one back without comparing
 };

@@ -157,3 +157,34 @@ int lvbgpu_allreduce_min(lvbgpu_ctx *c, int64_t *v, int32_t *r)
     (void)c, (void)v, (void)r;
     return LVBGPU_E_NODEVICE;
 }
+/* several chains per context: device-only as well */
+int lvbgpu_set_chains(lvbgpu_ctx *c, int32_t r)
+{
+    (void)c, (void)r;
+    return LVBGPU_E_NODEVICE;
+}
+int lvbgpu_select_chain(lvbgpu_ctx *c, int32_t k)
+{
+    (void)c;
+    return k == 0 ? LVBGPU_OK : LVBGPU_E_NODEVICE;
+}
+int32_t lvbgpu_chains(const lvbgpu_ctx *c)
+{
+    (void)c;
+    return 1;
+}
+int lvbgpu_chains_propose_score(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_draw *d, int64_t *l)
+{
+    (void)c, (void)k, (void)d, (void)l;
+    return LVBGPU_E_NODEVICE;
+}
+int lvbgpu_chains_commit(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_pick *p)
+{
+    (void)c, (void)k, (void)p;
+    return LVBGPU_E_NODEVICE;
+}
+int lvbgpu_chains_picked_edits(lvbgpu_ctx *c, int32_t j, lvbgpu_edit *e, int32_t cap, int32_t *n)
+{
+    (void)c, (void)j, (void)e, (void)cap, (void)n;
+    return LVBGPU_E_NODEVICE;
+}
