@@ -87,6 +87,8 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
         ctx->target_waves = (uint32_t)std::max(1, atoi(tw));
     // (row offsets are 64-bit in the kernels: the tree block is limited by HBM, not by index width)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
     ctx->nchains = 1;
@@ -250,6 +252,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->comm)
         (void)lvbgpu_comm_destroy(ctx);
+    if (ctx->side_stream)
+        (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_rows)
@@ -309,6 +313,10 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1)
         (void)hipEventDestroy(ctx->ev1);
+    if (ctx->side_ev)
+        (void)hipEventDestroy(ctx->side_ev);
+    if (ctx->side_stream)
+        (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -509,6 +517,8 @@ extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
     if (!ctx || nchains < 1 || nchains > MAX_CHAINS)
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->side_stream));
+    ctx->side_pending = false;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if ((uint64_t)(ctx->n + (long)nchains * (ctx->n - 3)) >= (uint64_t)MAX_ROWS)
         return ctx->fail(LVBGPU_E_ARG, "too many rows for the token format");

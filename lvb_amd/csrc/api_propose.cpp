@@ -21,13 +21,12 @@ struct AllParked
 
 // the generator's tables of one topology (layout: GenArgs in kernels.hpp), written where the upload reads them
 template <typename IdxT>
-static uint32_t fill_tables(const Topology &t, IdxT *out, size_t cap_elems, int32_t *K_out)
+static uint32_t fill_tables(const Topology &t, IdxT *out, size_t cap_elems, int32_t K)
 {
     const size_t nb = (size_t)t.nb, nlo = (size_t)t.n;
     // preorder from the root leaf; children before parents when read backwards
     std::vector<int32_t> order, depth(nb, 0), nleaf(nb, 1), st{t.root};
     order.reserve(nb);
-    int32_t maxdepth = 1;
     while (!st.empty())
     {
         const int32_t v = st.back();
@@ -36,7 +35,6 @@ static uint32_t fill_tables(const Topology &t, IdxT *out, size_t cap_elems, int3
         if (t.left[v] >= 0)
         {
             depth[t.left[v]] = depth[t.right[v]] = depth[v] + 1;
-            maxdepth = std::max(maxdepth, depth[v] + 1);
             st.push_back(t.right[v]);
             st.push_back(t.left[v]);
         }
@@ -44,9 +42,7 @@ static uint32_t fill_tables(const Topology &t, IdxT *out, size_t cap_elems, int3
     for (auto it = order.rbegin(); it != order.rend(); ++it)
         if (t.left[*it] >= 0)
             nleaf[*it] = nleaf[t.left[*it]] + nleaf[t.right[*it]];
-    int32_t K = 1;
-    while ((1 << K) <= maxdepth)
-        K++;
+    // K is the same for every tree of these taxa (2^K exceeds any depth): the device rebuilds a slot in place
     const size_t elems = (7 + (size_t)K) * nb + nlo;
     if (elems + 8 > cap_elems)
         return 0;
@@ -74,7 +70,6 @@ static uint32_t fill_tables(const Topology &t, IdxT *out, size_t cap_elems, int3
     for (int32_t k = 1; k < K; k++)
         for (size_t v = 0; v < nb; v++)
             up[(size_t)k * nb + v] = up[(size_t)(k - 1) * nb + (size_t)up[(size_t)(k - 1) * nb + v]];
-    *K_out = K;
     return (uint32_t)(((elems + 8) * sizeof(IdxT)) & ~(size_t)15); // whole 16-byte pieces
 }
 
@@ -85,10 +80,11 @@ int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
 {
     const int32_t nb = ctx->nb;
     ctx->gen_idx_bytes = nb <= 65535 ? 2u : 4u;
+    int32_t kmax = 1;
+    while ((1 << kmax) <= nb)
+        kmax++;
+    ctx->gen_kmax = kmax;
     {
-        int32_t kmax = 1;
-        while ((1 << kmax) <= nb)
-            kmax++;
         const size_t widest = ((7 + (size_t)kmax) * (size_t)nb + (size_t)ctx->n + 8) * ctx->gen_idx_bytes;
         ctx->gen_table_stride = (uint32_t)((widest + 255) & ~(size_t)255);
     }
@@ -113,9 +109,9 @@ int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
     auto build = [&](int32_t i) {
         ChainSlot &cs = ctx->parked[(size_t)stale[(size_t)i]];
         char *slot = (char *)ctx->h_topo.p + (size_t)stale[(size_t)i] * ctx->gen_table_stride;
-        bytes[(size_t)i] = ctx->gen_idx_bytes == 2
-                               ? fill_tables<uint16_t>(cs.topo, (uint16_t *)slot, ctx->gen_table_stride / 2, &cs.gen_K)
-                               : fill_tables<int32_t>(cs.topo, (int32_t *)slot, ctx->gen_table_stride / 4, &cs.gen_K);
+        cs.gen_K = kmax;
+        bytes[(size_t)i] = ctx->gen_idx_bytes == 2 ? fill_tables<uint16_t>(cs.topo, (uint16_t *)slot, ctx->gen_table_stride / 2, kmax)
+                                                   : fill_tables<int32_t>(cs.topo, (int32_t *)slot, ctx->gen_table_stride / 4, kmax);
     };
     int T = 1;
     if (stale.size() > 1)
@@ -133,7 +129,8 @@ int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
             for (size_t i = (size_t)t; i < stale.size(); i += (size_t)T)
                 build((int32_t)i);
         });
-    int32_t lo = INT32_MAX, hi = -1;
+    // (a staging slot is only current for chains the HOST built last: accepted device moves rebuild their chain's
+    // tables on the device, lvbgpu_chains_commit - so every stale chain is sent on its own, nothing in between)
     for (size_t i = 0; i < stale.size(); i++)
     {
         if (bytes[i] == 0)
@@ -141,24 +138,10 @@ int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
         ChainSlot &cs = ctx->parked[(size_t)stale[i]];
         cs.gen_table_bytes = bytes[i];
         cs.d_topo_version = cs.topo_version;
-        lo = std::min(lo, stale[i]);
-        hi = std::max(hi, stale[i]);
+        const size_t off = (size_t)stale[i] * ctx->gen_table_stride;
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + off, (const char *)ctx->h_topo.p + off, bytes[i], hipMemcpyHostToDevice,
+                                   ctx->stream));
     }
-    // a copy costs a few microseconds before its first byte moves: from three stale chains on, ONE copy of the span
-    // they cover (a staging slot always holds its chain's current tables, so what lies between is merely re-sent)
-    if (stale.size() >= 3)
-    {
-        const size_t off = (size_t)lo * ctx->gen_table_stride;
-        const size_t len = (size_t)(hi - lo) * ctx->gen_table_stride + ctx->parked[(size_t)hi].gen_table_bytes;
-        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + off, (const char *)ctx->h_topo.p + off, len, hipMemcpyHostToDevice, ctx->stream));
-    }
-    else
-        for (size_t i = 0; i < stale.size(); i++)
-        {
-            const size_t off = (size_t)stale[i] * ctx->gen_table_stride;
-            HIPCHK(ctx, hipMemcpyAsync((char *)ctx->d_topo4.p + off, (const char *)ctx->h_topo.p + off, bytes[i], hipMemcpyHostToDevice,
-                                       ctx->stream));
-        }
     return LVBGPU_OK;
 }
 } // namespace lvbgpu_detail
@@ -234,6 +217,11 @@ int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int
     if ((uint64_t)total * stride_t >= (1ull << 32) || (uint64_t)total * ctx->ntiles >= (1ull << 31))
         return ctx->fail(LVBGPU_E_ARG, "batch too large");
     const int32_t B = (int32_t)total;
+    if (ctx->side_pending) // tables rebuilt on the side stream after the last accepted moves: before anything reads them
+    {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
+        ctx->side_pending = false;
+    }
     int rc = prepare_tables(ctx, chains.data(), k);
     if (rc != LVBGPU_OK)
         return rc;
@@ -470,12 +458,41 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     const uint32_t seq = ++ctx->pick_seq;
     const size_t old_done = ctx->d_done.cap;
     HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
-    if (ctx->d_done.cap != old_done)
+    if (ctx->d_done.cap != old_done) // once per context: both streams below use it
+    {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     uint32_t *done = (uint32_t *)ctx->d_done.p;
     // 1. what the host needs to follow the moves (so that it can work while the walk runs)
+    //    (on the side stream: descriptors and rewrites are complete - the batch's lengths have been read - and nothing
+    //    here touches state sets, so it runs beside the commit walk)
     HIPCHK(ctx, launch_gather_picks(h_picks, (uint32_t)k, (const ProposalInfo *)ctx->d_pinfo.p, (const lvbgpu_edit_dev *)ctx->d_pedits.p,
-                                    ctx->p_stride_e, h + o_out, out_stride, flag, seq, done + MAX_CHAINS, ctx->stream));
+                                    ctx->p_stride_e, h + o_out, out_stride, flag, seq, done + MAX_CHAINS, ctx->side_stream));
+    // 1b. the generator's tables of the picked chains follow their moves on the device (they describe the trees the
+    //     candidates were drawn from: the picks were checked against the chains' versions above)
+    bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES;
+    for (int32_t j = 0; j < k && tables_on_device; j++)
+        tables_on_device = ctx->parked[(size_t)picks[j].chain].d_topo_version == ctx->parked[(size_t)picks[j].chain].topo_version;
+    if (tables_on_device)
+    {
+        RebuildArgs ra{};
+        ra.tables = ctx->d_topo4.p;
+        ra.table_stride = ctx->gen_table_stride;
+        ra.idx_bytes = ctx->gen_idx_bytes;
+        ra.n = (int32_t)ctx->n;
+        ra.nb = ctx->nb;
+        ra.K = ctx->gen_kmax;
+        ra.leaf_order_len = (uint32_t)ctx->n;
+        ra.pick = h_picks;
+        ra.cands = (const CandDesc *)bt->d_prog.p;
+        ra.info = (const ProposalInfo *)ctx->d_pinfo.p;
+        ra.edits = (const lvbgpu_edit_dev *)ctx->d_pedits.p;
+        ra.stride_e = ctx->p_stride_e;
+        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
+        ctx->side_pending = true;
+    }
     // 2. the picked candidates' own programs in commit form: produced sets and change counts go to their chains'
     //    rows, every candidate's last wave settles its chain's changes[] and S_all (fused commit)
     HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
@@ -500,7 +517,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
             break;
         if ((spins & 1023u) == 0)
         {
-            const hipError_t q = hipStreamQuery(ctx->stream);
+            const hipError_t q = hipStreamQuery(ctx->side_stream);
             if (q == hipSuccess)
                 break; // everything the kernels wrote is visible
             if (q != hipErrorNotReady)
@@ -520,6 +537,8 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         }
         cs.topo_version = ++ctx->version_counter;
         cs.cur_length_stale = true;
+        if (tables_on_device)
+            cs.d_topo_version = cs.topo_version; // rebuilt in place by the launch above
     }
     ctx->last_pick_slot = slot;
     ctx->last_pick_count = k;

@@ -146,6 +146,11 @@ struct lvbgpu_ctx
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    // side stream: what follows an accepted device move but does not touch state sets (the rewrites' way to the host,
+    // the generator's tables) runs beside the commit walk; side_ev orders the next generator launch after it
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_ev = nullptr;
+    bool side_pending = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     long n = 0, nwords = 0;
     int32_t nb = 0;
@@ -193,6 +198,7 @@ struct lvbgpu_ctx
     lvbgpu_batch *prop_batch = nullptr;
     DevBuf d_topo4, d_pedits, d_pinfo; // d_topo4: the generator's tables of the resident topologies, gen_table_stride each
     uint32_t gen_table_stride = 0;
+    int32_t gen_kmax = 1; // ancestor tables hold 2^0 .. 2^(kmax-1): 2^kmax exceeds any depth of a tree of these taxa
     PinBuf h_pinfo, h_topo;
     std::vector<uint16_t> gen_tab16;
     std::vector<int32_t> gen_tab32;

@@ -166,6 +166,23 @@ struct GenArgs
 static_assert(sizeof(GenArgs) <= 4000, "GenArgs travels as a kernel argument");
 hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
 
+// rebuild the generator's tables of the picked candidates' chains on the device (one workgroup per pick)
+constexpr uint32_t REBUILD_THREADS = 1024;
+constexpr uint32_t REBUILD_MAX_NODES = (MAX_LDS_BYTES - 16) / 16; // four int32 arrays in LDS; larger trees keep the host path
+struct RebuildArgs
+{
+    void *tables;            // all chains' slots
+    uint32_t table_stride, idx_bytes;
+    int32_t n, nb, K;
+    uint32_t leaf_order_len;
+    const uint32_t *pick;    // batch positions of the picked candidates
+    const CandDesc *cands;   // their descriptors (flags carry the chain)
+    const ProposalInfo *info;
+    const lvbgpu_edit_dev *edits;
+    uint32_t stride_e;
+};
+hipError_t launch_rebuild_tables(const RebuildArgs &args, uint32_t k, hipStream_t stream);
+
 // what lvbgpu_chains_commit needs on the host of every picked candidate, written straight into pinned memory:
 // out + j * out_stride: [ProposalInfo][n_edits rewrites]; then *flag = seq (released after the data)
 hipError_t launch_gather_picks(const uint32_t *pick, uint32_t k, const ProposalInfo *info, const lvbgpu_edit_dev *edits,

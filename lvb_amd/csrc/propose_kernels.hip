@@ -593,6 +593,130 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
         generate_one(t, g, sg, bl, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tables of a tree after an accepted device move, rebuilt ON the device (lvbgpu_chains_commit): one workgroup
+// per picked chain applies the candidate's rewrites to left / right in that chain's table slot and derives everything
+// else again - parents; leaves below, by letting every leaf count itself into its ancestors; depth, 2^k-th
+// ancestors, preorder number and first-leaf position from ONE walk of each node along its own root-ward path (no
+// level-by-level rounds: a barrier of 16 waves costs as much as a path).  No host work and no
+// upload per accepted move; with R chains accepting in one step that was most of the step.
+template <typename IdxT>
+__global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const RebuildArgs g)
+{
+    extern __shared__ int32_t lds_i32[];
+    const uint32_t j = blockIdx.x;
+    const uint32_t cand = g.pick[j];
+    const uint32_t chain = g.cands[cand].flags >> CAND_CHAIN_SHIFT;
+    IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
+    const int32_t n = g.n, nb = g.nb, K = g.K;
+    IdxT *t_parent = tab, *t_left = tab + nb, *t_right = tab + 2 * (size_t)nb, *t_nleaf = tab + 3 * (size_t)nb,
+         *t_depth = tab + 4 * (size_t)nb, *t_tin = tab + 5 * (size_t)nb, *t_first = tab + 6 * (size_t)nb,
+         *t_order = tab + 7 * (size_t)nb, *t_up = tab + 7 * (size_t)nb + g.leaf_order_len;
+    int32_t *left = lds_i32, *right = left + nb, *parent = right + nb, *nleaf = parent + nb, *shared = nleaf + nb; // shared[0] root
+    const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
+    for (int32_t v = tid; v < nb; v += nt)
+    {
+        left[v] = (int32_t)t_left[v];
+        right[v] = (int32_t)t_right[v];
+        parent[v] = (int32_t)t_parent[v];
+    }
+    __syncthreads();
+    // the root is the one node that is its own parent (device moves never re-root)
+    for (int32_t v = tid; v < nb; v += nt)
+        if (parent[v] == v)
+            shared[0] = v;
+    const ProposalInfo pi = g.info[cand];
+    const lvbgpu_edit_dev *ed = g.edits + (size_t)cand * g.stride_e;
+    for (int32_t i = tid; i < pi.n_edits; i += nt)
+    {
+        const lvbgpu_edit_dev e = ed[i];
+        left[e.node] = e.left;
+        right[e.node] = e.right;
+    }
+    __syncthreads();
+    const int32_t root = shared[0];
+    auto has_children = [&](int32_t v) { return v >= n || v == root; };
+    for (int32_t v = tid; v < nb; v += nt)
+    {
+        if (has_children(v))
+        {
+            parent[left[v]] = v;
+            parent[right[v]] = v;
+        }
+        nleaf[v] = has_children(v) ? 0 : 1;
+    }
+    __syncthreads();
+    // leaves below: every leaf counts itself into each of its ancestors (LDS atomics; no level-by-level rounds)
+    for (int32_t v = tid; v < nb; v += nt)
+        if (!has_children(v))
+            for (int32_t x = v; x != root;)
+            {
+                x = parent[x];
+                atomicAdd(&nleaf[x], 1);
+            }
+    __syncthreads();
+    // everything else is a function of the node's own path to the root: its length is the depth, the ancestors met at
+    // distances 1, 2, 4, .. are the lifting table's entries (the root beyond), and the preorder number (left subtree
+    // first) and the position of the first leaf below are sums along it - stepping up from a right child skips its left
+    // sister's whole subtree, from a left child only the parent
+    for (int32_t v = tid; v < nb; v += nt)
+    {
+        int32_t tv = 0, fv = 0, d = 0, filled = 0;
+        for (int32_t x = v; x != root;)
+        {
+            const int32_t p = parent[x];
+            if (right[p] == x)
+            {
+                const int32_t ls = nleaf[left[p]];
+                tv += 2 * ls;
+                fv += ls;
+            }
+            else
+                tv += 1;
+            x = p;
+            d++;
+            if ((d & (d - 1)) == 0 && filled < K)
+                t_up[(size_t)filled++ * nb + v] = (IdxT)x; // d = 2^filled
+        }
+        for (; filled < K; filled++)
+            t_up[(size_t)filled * nb + v] = (IdxT)root;
+        t_parent[v] = (IdxT)parent[v];
+        t_left[v] = (IdxT)(has_children(v) ? left[v] : 0);
+        t_right[v] = (IdxT)(has_children(v) ? right[v] : 0);
+        t_nleaf[v] = (IdxT)nleaf[v];
+        t_depth[v] = (IdxT)d;
+        t_tin[v] = (IdxT)tv;
+        t_first[v] = (IdxT)fv;
+        if (!has_children(v))
+            t_order[fv] = (IdxT)v;
+    }
+}
+
+hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t stream)
+{
+    if (k == 0)
+        return hipSuccess;
+    const size_t lds = ((size_t)4 * g.nb + 4) * sizeof(int32_t);
+    if (lds > MAX_LDS_BYTES)
+        return hipErrorInvalidValue; // the caller keeps the host path for trees this large
+    static bool raised_on[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised_on[dev])
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<uint16_t>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<int32_t>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        raised_on[dev] = true;
+    }
+    if (g.idx_bytes == 2)
+        hipLaunchKernelGGL(rebuild_tables_kernel<uint16_t>, dim3(k), dim3(REBUILD_THREADS), lds, stream, g);
+    else
+        hipLaunchKernelGGL(rebuild_tables_kernel<int32_t>, dim3(k), dim3(REBUILD_THREADS), lds, stream, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
 {
     if (args.nseg == 0 || args.nseg > MAX_GEN_SEGS)
