@@ -77,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--anneal-seconds", type=float, default=4.0,
                     help="run the batched SA host end to end for this long and report best-length-vs-wallclock (0 = skip)")
     ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
-    ap.add_argument("--anneal-chains", type=int, default=16, help="independent chains stepped together on the GPU")
+    ap.add_argument("--anneal-chains", type=int, default=32, help="independent chains stepped together on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 and uniform-alignment legs")
     ap.add_argument("--headline-only", action="store_true",

@@ -178,6 +178,12 @@ typedef struct
     uint64_t seed;
 } lvbgpu_chain_draw;
 int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out);
+/* the same in two halves, so that the host can work on one batch while the device works on another: _submit enqueues
+ * everything up to the lengths' read-back and returns at once, _collect waits for THAT batch alone and hands the
+ * lengths over.  Two batches may be in flight, in slots 0 and 1 (the plain call uses slot 0).  Chains of batches in
+ * flight at the same time must differ.  lvbgpu_chains_commit picks from the batch collected last. */
+int lvbgpu_chains_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws);
+int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out);
 /* accept candidate `b` (index within its chain's draw of the LAST lvbgpu_chains_propose_score /
  * lvbgpu_propose_score* call) for each listed chain, at most one per chain: the candidates' own device-built
  * programs are walked in commit form (one launch for all picks), and the chains' topologies follow (the moves'
@@ -188,6 +194,14 @@ typedef struct
     int32_t chain, b;
 } lvbgpu_chain_pick;
 int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_pick *picks);
+/* re-root the listed chains (distinct) at the given leaves in one commit walk: arbreroot (TreeOperations.c:639-656)
+ * for several chains at once; what lvbgpu_select_chain + lvbgpu_commit(rewrites along the old-root .. new-root path,
+ * new_root, NULL) does chain by chain.  Asynchronous (a re-root does not change the length). */
+typedef struct
+{
+    int32_t chain, new_root;
+} lvbgpu_chain_root;
+int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_root *reqs);
 /* the rewrites of pick j of the LAST lvbgpu_chains_commit (for a host that mirrors the topologies): already on the
  * host, no device access */
 int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits);

@@ -76,7 +76,10 @@ SIGNATURES = {
                                             _i64p]),
     "lvbgpu_proposal_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _i32p]),
     "lvbgpu_chains_propose_score": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, _i64p]),
+    "lvbgpu_chains_submit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lvbgpu_chains_collect": (C.c_int, [C.c_void_p, C.c_int32, _i64p]),
     "lvbgpu_chains_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "lvbgpu_chains_reroot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "lvbgpu_chains_picked_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_proposal_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
@@ -226,16 +229,37 @@ class FitchContext:
     def select_chain(self, chain: int) -> None:
         self._chk(self.lib.lvbgpu_select_chain(self.h, int(chain)))
 
-    def chains_propose_score(self, draws) -> list[np.ndarray]:
-        """draws: (chain, count, kind, seed[, mix_a, mix_b]) per chain -> the lengths, one array per draw."""
+    @staticmethod
+    def _draws(draws) -> np.ndarray:
         d = np.zeros(len(draws), dtype=DRAW_DTYPE)
         for i, row in enumerate(draws):
             d[i]["chain"], d[i]["count"], d[i]["kind"], d[i]["seed"] = row[0], row[1], row[2], row[3]
             if len(row) > 4:
                 d[i]["mix_a"], d[i]["mix_b"] = row[4], row[5]
+        return d
+
+    def chains_propose_score(self, draws) -> list[np.ndarray]:
+        """draws: (chain, count, kind, seed[, mix_a, mix_b]) per chain -> the lengths, one array per draw."""
+        d = self._draws(draws)
         out = np.zeros(int(d["count"].sum()), dtype=np.int64)
         self._chk(self.lib.lvbgpu_chains_propose_score(self.h, len(d), d.ctypes.data, out))
         return np.split(out, np.cumsum(d["count"])[:-1])
+
+    def chains_submit(self, slot: int, draws) -> np.ndarray:
+        """Asynchronous half: enqueue the batch in `slot` (0 or 1); -> the counts, for chains_collect."""
+        d = self._draws(draws)
+        self._chk(self.lib.lvbgpu_chains_submit(self.h, int(slot), len(d), d.ctypes.data))
+        return d["count"].copy()
+
+    def chains_collect(self, slot: int, counts) -> list[np.ndarray]:
+        out = np.zeros(int(np.sum(counts)), dtype=np.int64)
+        self._chk(self.lib.lvbgpu_chains_collect(self.h, int(slot), out))
+        return np.split(out, np.cumsum(counts)[:-1])
+
+    def chains_reroot(self, reqs) -> None:
+        """reqs: (chain, new_root_leaf) - re-root those chains in one commit walk."""
+        p = np.array([tuple(int(v) for v in row) for row in reqs], dtype=PICK_DTYPE)
+        self._chk(self.lib.lvbgpu_chains_reroot(self.h, len(p), p.ctypes.data))
 
     def chains_commit(self, picks) -> None:
         """picks: (chain, b) - candidate b of that chain's draw in the last chains_propose_score call."""

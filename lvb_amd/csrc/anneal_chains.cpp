@@ -97,21 +97,24 @@ struct ChainRun
             probs[i] = counter[i] / total;
     }
 
-    // arbreroot (TreeOperations.c:639-656): a random leaf other than the current root, as a commit of the rewrites
-    // along the old-root..new-root path; the length does not change (it is root-independent), nothing is read back
-    int reroot()
+    // arbreroot (TreeOperations.c:639-656): a random leaf other than the current root.  Only the leaf is drawn here; the
+    // driver re-roots all chains that ask for it in one commit walk before it submits the step (lvbgpu_chains_reroot)
+    int32_t pending_root = -1;
+    void ask_reroot()
     {
         int32_t nr;
         do
             nr = (int32_t)tree->rng.below((uint32_t)tree->topo.n);
         while (nr == tree->topo.root);
+        pending_root = nr;
+    }
+    // the library has re-rooted the chain: follow on the host's own topology
+    int rerooted()
+    {
         std::vector<Edit> ed;
-        reroot_edits(tree->topo, nr, ed);
-        int r = lvbgpu_select_chain(ctx, chain);
-        if (r == LVBGPU_OK)
-            r = lvbgpu_commit(ctx, (int32_t)ed.size(), reinterpret_cast<const lvbgpu_edit *>(ed.data()), nr, nullptr);
-        if (r == LVBGPU_OK)
-            r = lvbhost_tree_apply(tree, reinterpret_cast<const lvbgpu_edit *>(ed.data()), (int32_t)ed.size(), nr);
+        reroot_edits(tree->topo, pending_root, ed);
+        const int r = lvbhost_tree_apply(tree, reinterpret_cast<const lvbgpu_edit *>(ed.data()), (int32_t)ed.size(), pending_root);
+        pending_root = -1;
         res->reroots++;
         return r;
     }
@@ -140,9 +143,7 @@ struct ChainRun
             const int sample = 100; // StartingTemperature.c:86; iter runs 0..sample inclusive
             if (st_iter % 1000 == 0 && !st_rerooted) // REROOT_INTERVAL: once per temperature (116-117)
             {
-                rc = reroot();
-                if (rc != LVBGPU_OK)
-                    return false;
+                ask_reroot();
                 st_rerooted = true;
             }
             B = std::min(std::max(1, std::min(p.batch, 64)), sample + 1 - st_iter);
@@ -159,9 +160,7 @@ struct ChainRun
                 const int64_t to_tick = p.reroot_interval - (current_iter % p.reroot_interval);
                 if (to_tick == 1) // the reference re-roots when the incremented counter hits a multiple (Solve.c:238-242)
                 {
-                    rc = reroot();
-                    if (rc != LVBGPU_OK)
-                        return false;
+                    ask_reroot();
                     room = std::min<int64_t>(room, p.reroot_interval);
                 }
                 else
@@ -428,10 +427,27 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
     };
     log_point();
 
-    std::vector<lvbgpu_chain_draw> draws;
-    std::vector<int32_t> who;
-    std::vector<int64_t> lens;
+    // The chains can be stepped as two groups taking turns (LVBHOST_CHAIN_GROUPS=2): while the device draws and scores
+    // one group's candidates, the host consumes the other group's lengths, picks, commits and plans.  Measured on
+    // MI355X it LOSES (R = 16: 8.0 -> 6.5 M candidates/s, R = 32: 9.0 -> 8.2): a step is mostly fixed device latency
+    // (generator, walk, commit walk one after the other), and two half-sized groups pay it twice.  One group is the
+    // default.  Which group a chain is in changes nothing for the chain.
+    struct Flight
+    {
+        std::vector<lvbgpu_chain_draw> draws;
+        std::vector<int32_t> who;
+        std::vector<int64_t> lens;
+        size_t total = 0;
+        bool active = false;
+    };
+    static const int want_groups = [] {
+        const char *e = getenv("LVBHOST_CHAIN_GROUPS");
+        return e && atoi(e) == 2 ? 2 : 1;
+    }();
+    const int ngroups = R >= 2 ? want_groups : 1;
+    Flight flight[2];
     std::vector<lvbgpu_chain_pick> picks;
+    std::vector<lvbgpu_chain_root> roots;
     std::vector<int32_t> picked;
     int64_t steps = 0;
     double dev_seconds = 0.0;
@@ -439,72 +455,112 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
     const bool lockstep = params[0].sync_every > 0;
     if (lockstep && params[0].max_device_steps <= 0)
         return LVBGPU_E_ARG;
-    for (;;)
-    {
-        draws.clear();
-        who.clear();
-        size_t total = 0;
+
+    // plan the group's chains and enqueue their candidates (nothing if every chain of the group is done)
+    auto submit_group = [&](int g) -> int {
+        Flight &f = flight[g];
+        f.draws.clear();
+        f.who.clear();
+        f.total = 0;
+        f.active = false;
         auto tp = Clock::now();
         for (ChainRun &r : runs)
         {
+            if (r.chain % ngroups != g)
+                continue;
             lvbgpu_chain_draw d{};
             if (r.plan(d))
             {
-                draws.push_back(d);
-                who.push_back(r.chain);
-                total += (size_t)d.count;
+                f.draws.push_back(d);
+                f.who.push_back(r.chain);
+                f.total += (size_t)d.count;
             }
             else if (r.rc != LVBGPU_OK)
                 return r.rc;
         }
-        t_plan += since(tp);
-        if (draws.empty() && !lockstep)
-            break;
-        if (!draws.empty())
+        // the chains whose re-root tick has come: all of them in one commit walk, before their candidates are drawn
+        roots.clear();
+        for (int32_t c : f.who)
+            if (runs[(size_t)c].pending_root >= 0)
+                roots.push_back({c, runs[(size_t)c].pending_root});
+        if (!roots.empty())
         {
-            lens.resize(total);
-            auto td = Clock::now();
-            rc = lvbgpu_chains_propose_score(ctx, (int32_t)draws.size(), draws.data(), lens.data());
-            dev_seconds += since(td);
-            t_score += since(td);
-            if (rc != LVBGPU_OK)
-                return rc;
-            picks.clear();
-            picked.clear();
-            size_t off = 0;
-            tp = Clock::now();
-            for (size_t i = 0; i < draws.size(); i++)
-            {
-                ChainRun &r = runs[(size_t)who[i]];
-                const int b = r.consume(lens.data() + off);
-                off += (size_t)draws[i].count;
-                if (b >= 0)
-                {
-                    picks.push_back({r.chain, b});
-                    picked.push_back(r.chain);
-                }
-            }
-            t_consume += since(tp);
-            if (!picks.empty())
-            {
-                td = Clock::now();
-                rc = lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
-                dev_seconds += since(td);
-                t_commit += since(td);
-                if (rc != LVBGPU_OK)
-                    return rc;
-                tp = Clock::now();
-                for (size_t j = 0; j < picked.size(); j++)
-                {
-                    const int32_t c = picked[j];
-                    (void)runs[(size_t)c].after_commit((int32_t)j);
-                    if (runs[(size_t)c].rc != LVBGPU_OK)
-                        return runs[(size_t)c].rc;
-                }
-                t_after += since(tp);
-            }
-            log_point(); // R comparisons: nothing next to a device step
+            int rr = lvbgpu_chains_reroot(ctx, (int32_t)roots.size(), roots.data());
+            for (size_t i = 0; i < roots.size() && rr == LVBGPU_OK; i++)
+                rr = runs[(size_t)roots[i].chain].rerooted();
+            if (rr != LVBGPU_OK)
+                return rr;
         }
+        t_plan += since(tp);
+        if (f.draws.empty())
+            return LVBGPU_OK;
+        f.lens.resize(f.total);
+        auto td = Clock::now();
+        const int r = lvbgpu_chains_submit(ctx, g, (int32_t)f.draws.size(), f.draws.data());
+        dev_seconds += since(td);
+        t_score += since(td);
+        f.active = r == LVBGPU_OK;
+        return r;
+    };
+    // the group's lengths are back (or are waited for): consume, commit the accepted moves, finish those proposals
+    auto finish_group = [&](int g, bool discard) -> int {
+        Flight &f = flight[g];
+        if (!f.active)
+            return LVBGPU_OK;
+        f.active = false;
+        auto td = Clock::now();
+        int r = lvbgpu_chains_collect(ctx, g, f.lens.data());
+        dev_seconds += since(td);
+        t_score += since(td);
+        if (r != LVBGPU_OK || discard)
+            return r;
+        picks.clear();
+        picked.clear();
+        size_t off = 0;
+        auto tp = Clock::now();
+        for (size_t i = 0; i < f.draws.size(); i++)
+        {
+            ChainRun &cr = runs[(size_t)f.who[i]];
+            const int b = cr.consume(f.lens.data() + off);
+            off += (size_t)f.draws[i].count;
+            if (b >= 0)
+            {
+                picks.push_back({cr.chain, b});
+                picked.push_back(cr.chain);
+            }
+        }
+        t_consume += since(tp);
+        if (!picks.empty())
+        {
+            td = Clock::now();
+            r = lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
+            dev_seconds += since(td);
+            t_commit += since(td);
+            if (r != LVBGPU_OK)
+                return r;
+            tp = Clock::now();
+            for (size_t j = 0; j < picked.size(); j++)
+            {
+                ChainRun &cr = runs[(size_t)picked[j]];
+                (void)cr.after_commit((int32_t)j);
+                if (cr.rc != LVBGPU_OK)
+                    return cr.rc;
+            }
+            t_after += since(tp);
+        }
+        log_point(); // R comparisons: nothing next to a device step
+        return LVBGPU_OK;
+    };
+
+    for (int g = 0; g < ngroups && rc == LVBGPU_OK; g++)
+        rc = submit_group(g);
+    for (int g = 0; rc == LVBGPU_OK; g = (g + 1) % ngroups)
+    {
+        if (!lockstep && !flight[0].active && !flight[1].active)
+            break;
+        rc = finish_group(g, false);
+        if (rc != LVBGPU_OK)
+            break;
         steps++;
         bool stop = false;
         if (params[0].max_seconds > 0 && since(wall0) >= params[0].max_seconds)
@@ -516,17 +572,27 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
             stop = steps >= params[0].max_device_steps;
             if (steps % params[0].sync_every == 0 || stop)
             {
-                int64_t g = global_best;
-                rc = lvbgpu_allreduce_min(ctx, &g, nullptr);
+                int64_t gb = global_best;
+                rc = lvbgpu_allreduce_min(ctx, &gb, nullptr);
                 if (rc != LVBGPU_OK)
-                    return rc;
+                    break;
                 for (ChainRun &r : runs)
-                    r.res->global_best_length = g;
+                    r.res->global_best_length = gb;
             }
         }
         if (stop)
             break;
+        rc = submit_group(g);
     }
+    // leave nothing in flight
+    for (int g = 0; g < ngroups; g++)
+    {
+        const int r = finish_group(g, true);
+        if (rc == LVBGPU_OK)
+            rc = r;
+    }
+    if (rc != LVBGPU_OK)
+        return rc;
     const double secs = since(wall0);
     if (getenv("LVBHOST_PROFILE"))
         fprintf(stderr, "[anneal_chains] R=%d steps=%lld  per step (us): plan %.1f  propose_score %.1f  consume %.1f  commit %.1f  "

@@ -265,8 +265,13 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     delete ctx->pool;
     ctx->pool = nullptr;
     ctx->d_topo4.release();
-    ctx->d_pedits.release();
-    ctx->d_pinfo.release();
+    for (lvbgpu_ctx::PropSlot &ps : ctx->pslot)
+    {
+        ps.d_pedits.release();
+        ps.d_pinfo.release();
+        if (ps.done_ev)
+            (void)hipEventDestroy(ps.done_ev);
+    }
     ctx->h_pinfo.release();
     ctx->h_topo.release();
     ctx->d_done.release();
@@ -281,7 +286,7 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->h_step.release();
     ctx->d_tmp_changes.release();
     for (lvbgpu_batch *rb : {ctx->step_batch[0], ctx->step_batch[1], ctx->step_batch[2], ctx->step_batch[3], ctx->full_batch,
-                             ctx->prop_batch})
+                             ctx->pslot[0].batch, ctx->pslot[1].batch})
         if (rb)
         {
             rb->ctx = nullptr;
@@ -562,8 +567,12 @@ extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
     ctx->cur_length = 0;
     ctx->cur_length_stale = false;
     ctx->d_topo_version = ~0ull;
-    ctx->p_B = 0;
-    ctx->p_segs.clear();
+    for (lvbgpu_ctx::PropSlot &ps : ctx->pslot)
+    {
+        ps.p_B = 0;
+        ps.segs.clear();
+        ps.in_flight = false;
+    }
     ctx->tmp_changes_zeroed_cap = 0;
     return LVBGPU_OK;
 }
@@ -576,7 +585,7 @@ extern "C" int lvbgpu_select_chain(lvbgpu_ctx *ctx, int32_t chain)
     {
         park_chain(ctx);
         unpark_chain(ctx, chain);
-        ctx->p_B = 0; // lvbgpu_proposal_edits names candidates of the selected chain's last batch only
+        ctx->pslot[0].p_B = 0; // lvbgpu_proposal_edits names candidates of the selected chain's last batch only
     }
     return LVBGPU_OK;
 }

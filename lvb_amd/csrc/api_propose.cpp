@@ -189,10 +189,15 @@ const char *move_defect(const Topology &t, const lvbgpu_move &m)
 
 // one generator launch + one walk over the candidates of k chains (draws[i].chain distinct, all with a resident
 // tree); lengths_out holds the segments one after the other.  `moves` (host-named moves): k == 1 only.
-int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out, const lvbgpu_move *moves)
+// Two halves: submit (everything up to the lengths' read-back is enqueued; returns at once) and collect (waits for
+// that batch alone and hands the lengths over).  Two batches may be in flight, in slots 0 and 1.
+int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws, const lvbgpu_move *moves)
 {
-    if (!ctx || k < 1 || k > (int32_t)MAX_GEN_SEGS || !draws || !lengths_out || (moves && k != 1))
+    if (!ctx || slot < 0 || slot >= lvbgpu_ctx::PROP_SLOTS || k < 1 || k > (int32_t)MAX_GEN_SEGS || !draws || (moves && k != 1))
         return LVBGPU_E_ARG;
+    lvbgpu_ctx::PropSlot &ps = ctx->pslot[slot];
+    if (ps.in_flight)
+        return ctx->fail(LVBGPU_E_STATE, "that slot's batch has not been collected yet");
     if (ctx->n < 5)
         return ctx->fail(LVBGPU_E_ARG, "rearrangements need at least 5 taxa");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -225,21 +230,23 @@ int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int
     int rc = prepare_tables(ctx, chains.data(), k);
     if (rc != LVBGPU_OK)
         return rc;
-    if (!ctx->prop_batch)
+    if (!ps.batch)
     {
-        ctx->prop_batch = new (std::nothrow) lvbgpu_batch();
-        if (!ctx->prop_batch)
+        ps.batch = new (std::nothrow) lvbgpu_batch();
+        if (!ps.batch)
             return LVBGPU_E_NOMEM;
     }
-    lvbgpu_batch *bt = ctx->prop_batch;
+    if (!ps.done_ev)
+        HIPCHK(ctx, hipEventCreateWithFlags(&ps.done_ev, hipEventDisableTiming));
+    lvbgpu_batch *bt = ps.batch;
     const size_t o_t = align16((size_t)B * sizeof(CandDesc));
     const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
     const size_t bytes = o_d + align16((size_t)B * stride_t * 4);
     HIPCHK(ctx, bt->d_prog.reserve(bytes));
     HIPCHK(ctx, bt->d_len.reserve((size_t)B * 8));
     HIPCHK(ctx, bt->h_len.reserve((size_t)B * 8));
-    HIPCHK(ctx, ctx->d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
-    HIPCHK(ctx, ctx->d_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
+    HIPCHK(ctx, ps.d_pedits.reserve((size_t)B * stride_e * sizeof(lvbgpu_edit_dev)));
+    HIPCHK(ctx, ps.d_pinfo.reserve((size_t)B * sizeof(ProposalInfo)));
     bt->ctx = ctx;
     bt->B = B;
     bt->off_toks = o_t;
@@ -251,8 +258,9 @@ int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int
     bt->stats.max_stack = 1; // at most one sibling set waits while the other path is walked
     ctx->p_stride_t = stride_t;
     ctx->p_stride_e = stride_e;
-    ctx->p_B = 0;
-    ctx->p_segs.clear();
+    ps.p_B = 0;
+    ps.B = B;
+    ps.segs.clear();
     const lvbgpu_move_dev *d_moves = nullptr;
     if (moves)
     {
@@ -309,9 +317,9 @@ int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int
     ga.stride_e = stride_e;
     ga.toks = (uint32_t *)((char *)bt->d_prog.p + o_t);
     ga.dsts = (int32_t *)((char *)bt->d_prog.p + o_d);
-    ga.edits = (lvbgpu_edit_dev *)ctx->d_pedits.p;
+    ga.edits = (lvbgpu_edit_dev *)ps.d_pedits.p;
     ga.cands = (CandDesc *)bt->d_prog.p;
-    ga.info = (ProposalInfo *)ctx->d_pinfo.p;
+    ga.info = (ProposalInfo *)ps.d_pinfo.p;
     ga.len_out = (unsigned long long *)bt->d_len.p;
     ga.moves = d_moves;
     ga.nseg = (uint32_t)k;
@@ -333,7 +341,7 @@ int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int
         sg.root = cs.topo.root;
         sg.chain = (uint16_t)d.chain;
         sg.K = (uint16_t)cs.gen_K;
-        ctx->p_segs.push_back({d.chain, (int32_t)start, d.count, cs.topo_version});
+        ps.segs.push_back({d.chain, (int32_t)start, d.count, cs.topo_version});
         start += (uint32_t)d.count;
     }
     HIPCHK(ctx, launch_propose(ga, ctx->stream));
@@ -341,14 +349,41 @@ int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
     {
-        ctx->p_segs.clear();
+        ps.segs.clear();
         return rc;
     }
     // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
     // when) the caller wants that candidate (lvbgpu_proposal_edits) or accepts it (lvbgpu_chains_commit)
     HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, wait_for_step(ctx, B));
-    const int64_t *len = (const int64_t *)bt->h_len.p;
+    HIPCHK(ctx, hipEventRecord(ps.done_ev, ctx->stream));
+    ps.in_flight = true;
+    if (k == 1 && draws[0].chain == guard.sel)
+        ps.p_B = B; // lvbgpu_proposal_edits may name its candidates (slot 0, once collected)
+    return LVBGPU_OK;
+}
+
+int propose_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
+{
+    if (!ctx || slot < 0 || slot >= lvbgpu_ctx::PROP_SLOTS || !lengths_out)
+        return LVBGPU_E_ARG;
+    lvbgpu_ctx::PropSlot &ps = ctx->pslot[slot];
+    if (!ps.in_flight)
+        return ctx->fail(LVBGPU_E_STATE, "nothing was submitted in that slot");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ps.in_flight = false;
+    // this batch alone: whatever was enqueued behind it (the other slot's batch, commits) is not waited for
+    if (ps.B > SPIN_WAIT_MAX_B)
+        HIPCHK(ctx, hipEventSynchronize(ps.done_ev));
+    else
+    {
+        hipError_t q;
+        while ((q = hipEventQuery(ps.done_ev)) == hipErrorNotReady)
+            ;
+        HIPCHK(ctx, q);
+    }
+    ctx->last_slot = slot;
+    const int32_t B = ps.B;
+    const int64_t *len = (const int64_t *)ps.batch->h_len.p;
     for (int32_t b = 0; b < B; b++)
     {
         if (len[b] >= PROPOSAL_OVERFLOW_LENGTH)
@@ -359,14 +394,25 @@ int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int
         lengths_out[b] = len[b];
         if (len[b] <= 0)
         {
-            ctx->p_segs.clear();
+            ps.segs.clear();
+            ps.p_B = 0;
             return ctx->fail(LVBGPU_E_ZEROLEN, "assertion failed: changes > 0 (device-built candidate " + std::to_string(b) +
                                                    " of " + std::to_string(B) + " scored " + std::to_string(len[b]) + ")");
         }
     }
-    if (k == 1 && draws[0].chain == guard.sel)
-        ctx->p_B = B; // lvbgpu_proposal_edits may name its candidates
     return LVBGPU_OK;
+}
+
+int propose_core(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out, const lvbgpu_move *moves)
+{
+    if (!lengths_out)
+        return LVBGPU_E_ARG;
+    if (ctx && ctx->pslot[0].in_flight)
+        return ctx->fail(LVBGPU_E_STATE, "slot 0 holds a submitted batch: collect it first");
+    int rc = propose_submit(ctx, 0, k, draws, moves);
+    if (rc == LVBGPU_OK)
+        rc = propose_collect(ctx, 0, lengths_out);
+    return rc;
 }
 
 // the single-tree forms: the selected chain, one segment
@@ -412,16 +458,27 @@ extern "C" int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvb
     return propose_core(ctx, k, draws, lengths_out, nullptr);
 }
 
+extern "C" int lvbgpu_chains_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws)
+{
+    return propose_submit(ctx, slot, k, draws, nullptr);
+}
+
+extern "C" int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
+{
+    return propose_collect(ctx, slot, lengths_out);
+}
+
 extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_pick *picks)
 {
     if (!ctx || k < 1 || k > MAX_CHAINS || !picks)
         return LVBGPU_E_ARG;
-    if (ctx->p_segs.empty() || !ctx->prop_batch)
-        return ctx->fail(LVBGPU_E_STATE, "no device batch to pick from: call lvbgpu_chains_propose_score first");
+    lvbgpu_ctx::PropSlot &ps = ctx->pslot[ctx->last_slot];
+    if (ps.segs.empty() || !ps.batch || ps.in_flight)
+        return ctx->fail(LVBGPU_E_STATE, "no collected device batch to pick from: call lvbgpu_chains_propose_score first");
     ctx->last_pick_count = 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     AllParked guard(ctx);
-    lvbgpu_batch *bt = ctx->prop_batch;
+    lvbgpu_batch *bt = ps.batch;
     // where each pick sits in the batch; nothing may have changed that chain's tree since it was drawn
     std::vector<uint32_t> where((size_t)k);
     uint64_t seen = 0;
@@ -429,7 +486,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     {
         const lvbgpu_chain_pick &pk = picks[j];
         const lvbgpu_ctx::PSeg *seg = nullptr;
-        for (const lvbgpu_ctx::PSeg &sgm : ctx->p_segs)
+        for (const lvbgpu_ctx::PSeg &sgm : ps.segs)
             if (sgm.chain == pk.chain)
                 seg = &sgm;
         if (!seg || pk.b < 0 || pk.b >= seg->count || ((seen >> pk.chain) & 1u))
@@ -467,7 +524,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     // 1. what the host needs to follow the moves (so that it can work while the walk runs)
     //    (on the side stream: descriptors and rewrites are complete - the batch's lengths have been read - and nothing
     //    here touches state sets, so it runs beside the commit walk)
-    HIPCHK(ctx, launch_gather_picks(h_picks, (uint32_t)k, (const ProposalInfo *)ctx->d_pinfo.p, (const lvbgpu_edit_dev *)ctx->d_pedits.p,
+    HIPCHK(ctx, launch_gather_picks(h_picks, (uint32_t)k, (const ProposalInfo *)ps.d_pinfo.p, (const lvbgpu_edit_dev *)ps.d_pedits.p,
                                     ctx->p_stride_e, h + o_out, out_stride, flag, seq, done + MAX_CHAINS, ctx->side_stream));
     // 1b. the generator's tables of the picked chains follow their moves on the device (they describe the trees the
     //     candidates were drawn from: the picks were checked against the chains' versions above)
@@ -486,8 +543,8 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         ra.leaf_order_len = (uint32_t)ctx->n;
         ra.pick = h_picks;
         ra.cands = (const CandDesc *)bt->d_prog.p;
-        ra.info = (const ProposalInfo *)ctx->d_pinfo.p;
-        ra.edits = (const lvbgpu_edit_dev *)ctx->d_pedits.p;
+        ra.info = (const ProposalInfo *)ps.d_pinfo.p;
+        ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
         ra.stride_e = ctx->p_stride_e;
         HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream));
         HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
@@ -545,6 +602,151 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     return LVBGPU_OK;
 }
 
+// Re-root several chains in ONE commit walk (arbreroot, TreeOperations.c:639-656, as rewrites along the old-root ..
+// new-root path): what lvbgpu_select_chain + lvbgpu_commit(edits, new_root, NULL) does chain by chain - R chains
+// re-rooting every 1000 proposals each were a third of a step's device time that way.  The generator's tables follow
+// on the device.  Asynchronous: a re-root does not change the length.
+extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_root *reqs)
+{
+    if (!ctx || k < 1 || k > MAX_CHAINS || !reqs)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    AllParked guard(ctx);
+    uint64_t seen = 0;
+    std::vector<std::vector<Edit>> edits((size_t)k);
+    Packed pk;
+    Program prog;
+    for (int32_t j = 0; j < k; j++)
+    {
+        const lvbgpu_chain_root &rq = reqs[j];
+        if (rq.chain < 0 || rq.chain >= ctx->nchains || ((seen >> rq.chain) & 1u))
+            return ctx->fail(LVBGPU_E_ARG, "re-root " + std::to_string(j) + ": chain out of range or listed twice");
+        seen |= 1ull << rq.chain;
+        ChainSlot &cs = ctx->parked[(size_t)rq.chain];
+        if (!cs.have_tree)
+            return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+        const Topology &t = cs.topo;
+        if (rq.new_root < 0 || rq.new_root >= t.n || rq.new_root == t.root)
+            return ctx->fail(LVBGPU_E_TOPOLOGY, "re-root " + std::to_string(j) + ": the new root must be another leaf");
+        // every node on the way up takes (its old parent, its old sister); the old root becomes an ordinary leaf
+        std::vector<Edit> &ed = edits[(size_t)j];
+        for (int32_t c = rq.new_root; c != t.root; c = t.parent[c])
+        {
+            const int32_t p = t.parent[c];
+            ed.push_back({c, p, t.left[p] == c ? t.right[p] : t.left[p]});
+        }
+        ed.push_back({t.root, UNSET, UNSET});
+        const size_t tok0 = prog.toks.size(), dst0 = prog.dsts.size();
+        std::string why;
+        prog.max_stack = 0;
+        if (!ctx->pb.build_candidate(cs.topo, ed.data(), (int32_t)ed.size(), rq.new_root, prog, &why))
+            return ctx->fail(LVBGPU_E_TOPOLOGY, "re-root " + std::to_string(j) + ": " + why);
+        pk.add(prog, tok0, dst0, 0, (uint32_t)rq.chain << CAND_CHAIN_SHIFT);
+        pk.max_stack = std::max(pk.max_stack, prog.max_stack);
+    }
+    int rc = check_depth(ctx, pk.max_stack);
+    if (rc != LVBGPU_OK)
+        return rc;
+    // one pinned slot: [descriptors][tokens][destinations][what the table rebuild needs][all rewrites]
+    size_t n_all_edits = 0;
+    for (const auto &e : edits)
+        n_all_edits += e.size();
+    const size_t o_t = align16((size_t)k * sizeof(CandDesc));
+    const size_t o_d = o_t + align16(prog.toks.size() * 4);
+    const size_t o_x = o_d + align16(prog.dsts.size() * 4);
+    const size_t o_e = o_x + align16((size_t)k * sizeof(RebuildExt));
+    const size_t total = o_e + align16(n_all_edits * sizeof(lvbgpu_edit_dev));
+    const int slot = ctx->pick_slot;
+    ctx->pick_slot = (slot + 1) % lvbgpu_ctx::PICK_SLOTS;
+    if (!ctx->pick_ev[slot])
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pick_ev[slot], hipEventDisableTiming));
+    else
+        HIPCHK(ctx, hipEventSynchronize(ctx->pick_ev[slot]));
+    const size_t slot_min = 64 + align16((size_t)MAX_CHAINS * 4) + (size_t)MAX_CHAINS * 16; // never below what a pick needs first
+    HIPCHK(ctx, ctx->h_pick[slot].reserve(std::max(total, slot_min)));
+    char *h = (char *)ctx->h_pick[slot].p;
+    memcpy(h, pk.cands.data(), (size_t)k * sizeof(CandDesc));
+    memcpy(h + o_t, prog.toks.data(), prog.toks.size() * 4);
+    memcpy(h + o_d, prog.dsts.data(), prog.dsts.size() * 4);
+    RebuildExt *ext = (RebuildExt *)(h + o_x);
+    lvbgpu_edit_dev *all = (lvbgpu_edit_dev *)(h + o_e);
+    size_t off = 0;
+    for (int32_t j = 0; j < k; j++)
+    {
+        ext[j] = {reqs[j].chain, reqs[j].new_root, (int32_t)off, (int32_t)edits[(size_t)j].size()};
+        memcpy(all + off, edits[(size_t)j].data(), edits[(size_t)j].size() * sizeof(lvbgpu_edit_dev));
+        off += edits[(size_t)j].size();
+    }
+    static_assert(sizeof(Edit) == sizeof(lvbgpu_edit_dev), "edit layout");
+    // the tables follow on the device when they describe the trees as they are now
+    bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
+    for (int32_t j = 0; j < k && tables_on_device; j++)
+        tables_on_device = ctx->parked[(size_t)reqs[j].chain].d_topo_version == ctx->parked[(size_t)reqs[j].chain].topo_version;
+    if (tables_on_device)
+    {
+        RebuildArgs ra{};
+        ra.tables = ctx->d_topo4.p;
+        ra.table_stride = ctx->gen_table_stride;
+        ra.idx_bytes = ctx->gen_idx_bytes;
+        ra.n = (int32_t)ctx->n;
+        ra.nb = ctx->nb;
+        ra.K = ctx->gen_kmax;
+        ra.leaf_order_len = (uint32_t)ctx->n;
+        ra.ext = ext;
+        ra.ext_edits = all;
+        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
+        ctx->side_pending = true;
+    }
+    // the commit walk: programs read where they lie while that is little, else copied first
+    const uint32_t ngroups = choose_groups((uint32_t)k, ctx->ntiles, ctx->target_waves);
+    const bool in_place = ctx->direct_steps && o_x * ngroups <= DIRECT_READ_MAX_BYTES;
+    const void *progp = h;
+    if (!in_place)
+    {
+        HIPCHK(ctx, ctx->d_commit[0].reserve(o_x));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_commit[0].p, h, o_x, hipMemcpyHostToDevice, ctx->stream));
+        progp = ctx->d_commit[0].p;
+    }
+    const size_t old_done = ctx->d_done.cap;
+    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
+    if (ctx->d_done.cap != old_done)
+    {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
+    if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
+    {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
+        ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
+    }
+    HIPCHK(ctx, ctx->d_len.reserve(8));
+    WalkArgs a = resident_args(ctx, progp, o_t, o_d, ctx->d_len.p, (uint32_t)k, pk.max_stack);
+    a.s_all_out = (unsigned long long *)ctx->d_scalars;
+    a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
+    a.tmp_stride = (uint32_t)(ctx->nb + 1);
+    a.done_count = (uint32_t *)ctx->d_done.p;
+    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->pick_ev[slot], ctx->stream));
+    // the host's topologies follow
+    for (int32_t j = 0; j < k; j++)
+    {
+        ChainSlot &cs = ctx->parked[(size_t)reqs[j].chain];
+        std::string why;
+        if (!ctx->pb.apply_edits(cs.topo, edits[(size_t)j].data(), (int32_t)edits[(size_t)j].size(), reqs[j].new_root, &why))
+        {
+            cs.have_tree = false;
+            return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+        }
+        cs.topo_version = ++ctx->version_counter;
+        cs.cur_length_stale = true;
+        if (tables_on_device)
+            cs.d_topo_version = cs.topo_version;
+    }
+    return LVBGPU_OK;
+}
+
 extern "C" int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits)
 {
     if (!ctx || !edits || !n_edits || j < 0)
@@ -566,14 +768,15 @@ extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *ed
 {
     if (!ctx || !edits || !n_edits)
         return LVBGPU_E_ARG;
-    if (ctx->p_B <= 0 || b < 0 || b >= ctx->p_B)
+    lvbgpu_ctx::PropSlot &ps = ctx->pslot[0];
+    if (ps.p_B <= 0 || ps.in_flight || b < 0 || b >= ps.p_B)
         return ctx->fail(LVBGPU_E_STATE, "no device batch holds that candidate: call lvbgpu_propose_score first");
     if (ctx->d_topo_version != ctx->topo_version)
         return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since that batch was drawn");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // this candidate's descriptor, then its edits
     HIPCHK(ctx, ctx->h_pinfo.reserve(sizeof(ProposalInfo)));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinfo.p, (const ProposalInfo *)ctx->d_pinfo.p + b, sizeof(ProposalInfo),
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinfo.p, (const ProposalInfo *)ps.d_pinfo.p + b, sizeof(ProposalInfo),
                                hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const ProposalInfo pi = *(const ProposalInfo *)ctx->h_pinfo.p;
@@ -582,7 +785,7 @@ extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *ed
     if (pi.n_edits > cap)
         return ctx->fail(LVBGPU_E_ARG, "edit buffer too small");
     static_assert(sizeof(lvbgpu_edit) == sizeof(lvbgpu_edit_dev), "edit layout");
-    HIPCHK(ctx, hipMemcpyAsync(edits, (const lvbgpu_edit_dev *)ctx->d_pedits.p + (size_t)b * ctx->p_stride_e,
+    HIPCHK(ctx, hipMemcpyAsync(edits, (const lvbgpu_edit_dev *)ps.d_pedits.p + (size_t)b * ctx->p_stride_e,
                                (size_t)pi.n_edits * sizeof(lvbgpu_edit), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *n_edits = pi.n_edits;
@@ -603,14 +806,15 @@ extern "C" int lvbgpu_proposal_stats(lvbgpu_ctx *ctx, lvbgpu_batch_stats *out)
 {
     if (!ctx || !out)
         return LVBGPU_E_ARG;
+    lvbgpu_ctx::PropSlot &ps = ctx->pslot[ctx->last_slot];
     int64_t total = 0;
-    for (const lvbgpu_ctx::PSeg &sgm : ctx->p_segs)
+    for (const lvbgpu_ctx::PSeg &sgm : ps.segs)
         total += sgm.count;
-    if (total <= 0 || !ctx->prop_batch)
+    if (total <= 0 || !ps.batch || ps.in_flight)
         return ctx->fail(LVBGPU_E_STATE, "no device batch: call lvbgpu_propose_score first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<ProposalInfo> info((size_t)total);
-    HIPCHK(ctx, hipMemcpyAsync(info.data(), ctx->d_pinfo.p, info.size() * sizeof(ProposalInfo), hipMemcpyDeviceToHost,
+    HIPCHK(ctx, hipMemcpyAsync(info.data(), ps.d_pinfo.p, info.size() * sizeof(ProposalInfo), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     lvbgpu_batch_stats st{};

@@ -195,8 +195,26 @@ struct lvbgpu_ctx
     bool pipeline_steps = true; // env LVBGPU_PIPELINE=0: one build, one launch per lvbgpu_score_batch
     lvbgpu_batch *full_batch = nullptr; // recycled by lvbgpu_score_full_batch
     // device-side proposals (lvbgpu_propose_score)
-    lvbgpu_batch *prop_batch = nullptr;
-    DevBuf d_topo4, d_pedits, d_pinfo; // d_topo4: the generator's tables of the resident topologies, gen_table_stride each
+    // device-built batches: two may be in flight (lvbgpu_chains_submit / _collect), the plain calls use slot 0
+    struct PSeg
+    {
+        int32_t chain, start, count;
+        uint64_t version; // that chain's tree when the candidates were drawn
+    };
+    struct PropSlot
+    {
+        lvbgpu_batch *batch = nullptr;
+        DevBuf d_pedits, d_pinfo;   // the candidates' rewrites and descriptors
+        std::vector<PSeg> segs;     // the segments of the batch (lvbgpu_chains_commit picks from them)
+        int32_t p_B = 0;            // candidates lvbgpu_proposal_edits may name (single chain, selected; 0: none)
+        int32_t B = 0;
+        hipEvent_t done_ev = nullptr; // after the lengths' read-back
+        bool in_flight = false;
+    };
+    static constexpr int PROP_SLOTS = 2;
+    PropSlot pslot[PROP_SLOTS];
+    int last_slot = 0;              // the batch lvbgpu_chains_commit picks from: the one collected last
+    DevBuf d_topo4; // the generator's tables of the resident topologies, gen_table_stride each
     uint32_t gen_table_stride = 0;
     int32_t gen_kmax = 1; // ancestor tables hold 2^0 .. 2^(kmax-1): 2^kmax exceeds any depth of a tree of these taxa
     PinBuf h_pinfo, h_topo;
@@ -208,13 +226,6 @@ struct lvbgpu_ctx
     PinBuf h_moves;
     uint64_t d_topo_version = ~0ull;
     uint32_t p_stride_t = 0, p_stride_e = 0;
-    int32_t p_B = 0; // candidates of the last device batch whose candidates lvbgpu_proposal_edits may name (0: none)
-    struct PSeg
-    {
-        int32_t chain, start, count;
-        uint64_t version; // that chain's tree when the candidates were drawn
-    };
-    std::vector<PSeg> p_segs; // the segments of the last device batch (lvbgpu_chains_commit picks from them)
     // lvbgpu_chains_commit: picks / fetched rewrites travel through a small ring of pinned slots
     static constexpr int PICK_SLOTS = 4;
     PinBuf h_pick[PICK_SLOTS];

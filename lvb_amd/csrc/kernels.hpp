@@ -169,6 +169,12 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
 // rebuild the generator's tables of the picked candidates' chains on the device (one workgroup per pick)
 constexpr uint32_t REBUILD_THREADS = 1024;
 constexpr uint32_t REBUILD_MAX_NODES = (MAX_LDS_BYTES - 16) / 16; // four int32 arrays in LDS; larger trees keep the host path
+// a move that is not a candidate of a device batch (a re-root named by the host): its chain, its new root and its
+// rewrites ext_edits[edit_off .. edit_off + n_edits)
+struct RebuildExt
+{
+    int32_t chain, new_root, edit_off, n_edits;
+};
 struct RebuildArgs
 {
     void *tables;            // all chains' slots
@@ -180,6 +186,8 @@ struct RebuildArgs
     const ProposalInfo *info;
     const lvbgpu_edit_dev *edits;
     uint32_t stride_e;
+    const RebuildExt *ext;   // non-null: workgroup j rebuilds for ext[j] instead of a picked candidate
+    const lvbgpu_edit_dev *ext_edits;
 };
 hipError_t launch_rebuild_tables(const RebuildArgs &args, uint32_t k, hipStream_t stream);
 

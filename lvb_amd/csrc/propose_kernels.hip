@@ -605,8 +605,8 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
 {
     extern __shared__ int32_t lds_i32[];
     const uint32_t j = blockIdx.x;
-    const uint32_t cand = g.pick[j];
-    const uint32_t chain = g.cands[cand].flags >> CAND_CHAIN_SHIFT;
+    const uint32_t cand = g.ext ? 0u : g.pick[j];
+    const uint32_t chain = g.ext ? (uint32_t)g.ext[j].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
     IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
     const int32_t n = g.n, nb = g.nb, K = g.K;
     IdxT *t_parent = tab, *t_left = tab + nb, *t_right = tab + 2 * (size_t)nb, *t_nleaf = tab + 3 * (size_t)nb,
@@ -621,13 +621,19 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
         parent[v] = (int32_t)t_parent[v];
     }
     __syncthreads();
-    // the root is the one node that is its own parent (device moves never re-root)
-    for (int32_t v = tid; v < nb; v += nt)
-        if (parent[v] == v)
-            shared[0] = v;
-    const ProposalInfo pi = g.info[cand];
-    const lvbgpu_edit_dev *ed = g.edits + (size_t)cand * g.stride_e;
-    for (int32_t i = tid; i < pi.n_edits; i += nt)
+    // the root: given with a re-root, otherwise the one node that is its own parent (device moves never re-root)
+    if (g.ext)
+    {
+        if (tid == 0)
+            shared[0] = g.ext[j].new_root;
+    }
+    else
+        for (int32_t v = tid; v < nb; v += nt)
+            if (parent[v] == v)
+                shared[0] = v;
+    const int32_t n_edits = g.ext ? g.ext[j].n_edits : g.info[cand].n_edits;
+    const lvbgpu_edit_dev *ed = g.ext ? g.ext_edits + g.ext[j].edit_off : g.edits + (size_t)cand * g.stride_e;
+    for (int32_t i = tid; i < n_edits; i += nt)
     {
         const lvbgpu_edit_dev e = ed[i];
         left[e.node] = e.left;
@@ -645,6 +651,9 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
         }
         nleaf[v] = has_children(v) ? 0 : 1;
     }
+    __syncthreads();
+    if (tid == 0)
+        parent[root] = root; // nobody's child
     __syncthreads();
     // leaves below: every leaf counts itself into each of its ancestors (LDS atomics; no level-by-level rounds)
     for (int32_t v = tid; v < nb; v += nt)

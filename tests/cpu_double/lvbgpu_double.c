@@ -188,3 +188,18 @@ int lvbgpu_chains_picked_edits(lvbgpu_ctx *c, int32_t j, lvbgpu_edit *e, int32_t
     (void)c, (void)j, (void)e, (void)cap, (void)n;
     return LVBGPU_E_NODEVICE;
 }
+int lvbgpu_chains_submit(lvbgpu_ctx *c, int32_t s, int32_t k, const lvbgpu_chain_draw *d)
+{
+    (void)c, (void)s, (void)k, (void)d;
+    return LVBGPU_E_NODEVICE;
+}
+int lvbgpu_chains_collect(lvbgpu_ctx *c, int32_t s, int64_t *l)
+{
+    (void)c, (void)s, (void)l;
+    return LVBGPU_E_NODEVICE;
+}
+int lvbgpu_chains_reroot(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_root *r)
+{
+    (void)c, (void)k, (void)r;
+    return LVBGPU_E_NODEVICE;
+}

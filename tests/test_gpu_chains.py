@@ -192,3 +192,49 @@ def test_a_chains_trajectory_does_not_depend_on_how_many_chains_run_beside_it(mo
     assert all(r["consumed"] == 2500 and r["best_length"] <= r["start_length"] for r in many)
     assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)      # the shared log only ever improves
     assert log[-1][1] == min(r["best_length"] for r in many)
+
+
+def test_rerooting_several_chains_at_once_equals_rerooting_them_one_by_one(mods):
+    """lvbgpu_chains_reroot: one commit walk for all, tables rebuilt on the device; same state as a commit of the
+    re-root rewrites chain by chain, and the neighbourhoods drawn afterwards are the same."""
+    api, host = mods
+    n, m, R = 30, 900, 5
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 15))
+    multi, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
+    trees = [host.HostTree(n, seed=200 + c) for c in range(R)]
+    for ctx in (multi, ref):
+        ctx.set_chains(R)
+        for c in range(R):
+            ctx.select_chain(c)
+            trees[c].upload(ctx)
+    rng = np.random.default_rng(4)
+    for step in range(8):
+        # draw first, so that the device holds current tables for every chain (the rebuild-in-place case)
+        got = multi.chains_propose_score([(c, 9, -1, 50 * step + c) for c in range(R)])
+        who = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
+        reqs = []
+        for c in who:
+            nr = int((trees[c].root + 1 + rng.integers(0, n - 1)) % n)
+            reqs.append((c, nr))
+            ed = trees[c].reroot_edits(nr)
+            ref.select_chain(c)
+            length = ref.current_length()
+            assert ref.commit(ed, root=nr) == length          # a re-root keeps the length
+            trees[c].apply(ed, nr)
+        multi.chains_reroot(reqs)
+        for c in range(R):
+            multi.select_chain(c)
+            ref.select_chain(c)
+            assert multi.current_length() == ref.current_length()
+            pm, pr = multi.topology(), ref.topology()
+            assert all(np.array_equal(a, b) for a, b in zip(pm[:3], pr[:3])) and pm[3] == pr[3] == trees[c].root
+            assert np.array_equal(multi.changes(), ref.changes())
+            assert np.array_equal(multi.all_sets(), ref.all_sets())
+            seed = 900 + 10 * step + c
+            assert np.array_equal(multi.propose_score(25, -1, seed), ref.propose_score(25, -1, seed))
+    with pytest.raises(api.LvbGpuError):
+        multi.chains_reroot([(0, trees[0].root)])              # already the root
+    with pytest.raises(api.LvbGpuError):
+        multi.chains_reroot([(0, n + 2)])                      # not a leaf
+    multi.close()
+    ref.close()
