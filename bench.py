@@ -176,26 +176,48 @@ def random_walk(ctx, tree, kind: int, moves: int) -> int:
     return length
 
 
-def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, seed0: int, reduce_best=None, settle: int = 0):
+def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, seed0: int, reduce_best=None, settle: int = 0,
+                      depth: int = 2):
     """The metric's step, `steps` times: draw + program + score B neighbours on the GPU, lengths on the host.
     -> dict(elapsed_s [max over ranks], launch_ms [mean walk duration, HIP events], best, stats).
+    depth 2 (default): two batches in flight (lvbgpu_chains_submit / _collect) - while the host reads step i's
+    lengths, step i+1 is already on the device and step i+2's neighbours are being drawn beside its walk; every step
+    still ends with its B lengths on the host.  depth 1: one batch at a time (lvbgpu_propose_score), a step's latency.
     settle: untimed steps run as part of the SETUP, before the `warmup` steps: a fresh process pays two one-off
     runtime stalls of 1 and 8 ms somewhere in its first ~350 steps (tools/stall_probe.py: queue resources being
     grown, never again afterwards), which would otherwise land in a timed region of a few milliseconds."""
-    for i in range(settle):
-        ctx.propose_score(B, kind, seed0 - 100000 - i)
-    for i in range(warmup):
-        ctx.propose_score(B, kind, seed0 - 1 - i)
+    from lvb_amd import api
+    lib, h = ctx.lib, ctx.h
+    draw = np.zeros(1, dtype=api.DRAW_DTYPE)
+    draw[0]["chain"], draw[0]["count"], draw[0]["kind"] = 0, B, kind
+    outs = [np.zeros(B, dtype=np.int64), np.zeros(B, dtype=np.int64)]
+
+    def submit(slot, seed):
+        draw[0]["seed"] = seed & 0xFFFFFFFFFFFFFFFF
+        ctx._chk(lib.lvbgpu_chains_submit(h, slot, 1, draw.ctypes.data))
+
+    def run(n, first_seed):
+        """n pipelined steps; -> best length seen"""
+        best = np.iinfo(np.int64).max
+        for j in range(min(depth, n)):
+            submit(j % 2, first_seed + j)
+        for i in range(n):
+            slot = i % 2 if depth > 1 else 0
+            ctx._chk(lib.lvbgpu_chains_collect(h, slot, outs[slot]))
+            best = min(best, int(outs[slot].min()))
+            if i + depth < n:
+                submit(slot, first_seed + i + depth)
+        return best
+
+    run(settle, (seed0 - 100000) & 0x7FFFFFFF)
+    run(warmup, (seed0 - 1000) & 0x7FFFFFFF)
     ctx.synchronize()
     ranks.barrier()
     ctx.walk_timing(WALK_TIMING_EVERY)   # a pair of events costs the step ~20 us: sample
-    best = np.iinfo(np.int64).max
     gc_was = gc.isenabled()
     gc.disable()                         # a collection inside a few-millisecond region would be most of it
     t0 = time.perf_counter()
-    for i in range(steps):
-        lens = ctx.propose_score(B, kind, seed0 + i)
-        best = min(best, int(lens.min()))
+    best = run(steps, seed0)
     t_steps = time.perf_counter() - t0
     best_global = reduce_best(best) if reduce_best else best
     ctx.synchronize()
@@ -462,8 +484,9 @@ def rank_main(args) -> None:
             "workload": f"{args.taxa} taxa x {args.sites} sites synthetic DNA "
                         f"({'tree-like, 10% substitutions' if args.dist == 'tree' else 'i.i.d. uniform'}), "
                         f"{args.move.upper()} neighbourhood, incremental getplen semantics, B={B} candidates per step; "
-                        f"a step = submit -> lengths on the host (lvbgpu_propose_score: neighbours drawn, programmed "
-                        f"and scored on the GPU); start tree + {args.walk} accepted moves",
+                        f"a step = submit -> lengths on the host (neighbours drawn, programmed and scored on the GPU, "
+                        f"B lengths read back; two steps in flight: lvbgpu_chains_submit / _collect); "
+                        f"start tree + {args.walk} accepted moves",
             "taxa": args.taxa, "sites_after_constant_cut": len(rows[0]), "nwords": ctx.nwords,
             "batch": B, "move": args.move, "mean_dirty_nodes": round(head["mean_dirty"], 2),
             "parallelism": f"{world} independent restart(s), one per GPU; best length min-reduced over RCCL"
@@ -475,6 +498,10 @@ def rank_main(args) -> None:
     }
     steps_side = max(20, min(args.steps, 100))
     if not args.headline_only:
+        one = submit_to_lengths(ctx, ranks, B, kind, steps_side, 5, 3000, depth=1)
+        out["one_at_a_time"] = {"value": one["scored_per_step"] * steps_side / one["elapsed_s"], "unit": "trees/s",
+                                "ms_per_step": 1e3 * one["elapsed_s"] / steps_side, "walk_ms": one["launch_ms"],
+                                "what": "the same step with ONE batch in flight (lvbgpu_propose_score): a step's latency"}
         out["kernel_only"] = kernel_only(ctx, tree, B, kind, args.nbatches, steps_side, min(args.warmup, 10))
 
     extras = rank == 0 and world == 1 and not args.headline_only

@@ -180,8 +180,10 @@ typedef struct
 int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out);
 /* the same in two halves, so that the host can work on one batch while the device works on another: _submit enqueues
  * everything up to the lengths' read-back and returns at once, _collect waits for THAT batch alone and hands the
- * lengths over.  Two batches may be in flight, in slots 0 and 1 (the plain call uses slot 0).  Chains of batches in
- * flight at the same time must differ.  lvbgpu_chains_commit picks from the batch collected last. */
+ * lengths over.  Two batches may be in flight, in slots 0 and 1 (the plain call uses slot 0); the second one's
+ * neighbours are drawn while the first one is being scored.  A chain may be in both as long as its tree does not
+ * change in between: a commit makes the other batch's candidates of that chain stale (picking them is
+ * LVBGPU_E_STATE).  lvbgpu_chains_commit picks from the batch collected last. */
 int lvbgpu_chains_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws);
 int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out);
 /* accept candidate `b` (index within its chain's draw of the LAST lvbgpu_chains_propose_score /

@@ -76,8 +76,10 @@ static uint32_t fill_tables(const Topology &t, IdxT *out, size_t cap_elems, int3
 // bring the device tables of the listed chains (all parked) up to date: the stale ones are rebuilt on the host
 // threads, each into its own pinned staging slot, and uploaded.  A staging slot is rewritten only after the step
 // that followed its last upload has been waited for, so no upload can still be reading it.
-int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
+int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k, bool *uploaded = nullptr)
 {
+    if (uploaded)
+        *uploaded = false;
     const int32_t nb = ctx->nb;
     ctx->gen_idx_bytes = nb <= 65535 ? 2u : 4u;
     int32_t kmax = 1;
@@ -105,6 +107,8 @@ int prepare_tables(lvbgpu_ctx *ctx, const int32_t *chains, int32_t k)
             stale.push_back(chains[i]);
     if (stale.empty())
         return LVBGPU_OK;
+    if (uploaded)
+        *uploaded = true;
     std::vector<uint32_t> bytes(stale.size(), 0);
     auto build = [&](int32_t i) {
         ChainSlot &cs = ctx->parked[(size_t)stale[(size_t)i]];
@@ -222,12 +226,8 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     if ((uint64_t)total * stride_t >= (1ull << 32) || (uint64_t)total * ctx->ntiles >= (1ull << 31))
         return ctx->fail(LVBGPU_E_ARG, "batch too large");
     const int32_t B = (int32_t)total;
-    if (ctx->side_pending) // tables rebuilt on the side stream after the last accepted moves: before anything reads them
-    {
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
-        ctx->side_pending = false;
-    }
-    int rc = prepare_tables(ctx, chains.data(), k);
+    bool uploaded = false;
+    int rc = prepare_tables(ctx, chains.data(), k, &uploaded);
     if (rc != LVBGPU_OK)
         return rc;
     if (!ps.batch)
@@ -344,7 +344,29 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         ps.segs.push_back({d.chain, (int32_t)start, d.count, cs.topo_version});
         start += (uint32_t)d.count;
     }
-    HIPCHK(ctx, launch_propose(ga, ctx->stream));
+    // While the other slot's batch is on the device this batch's generator COULD run beside that batch's walk, on the
+    // side stream (it writes this slot's buffers only).  Measured (B = 4096): the walk then takes 100 us instead of 88
+    // (the generator's workgroups hold LDS and wave slots) and the step gains nothing over simply queueing behind it -
+    // what two batches in flight buy is the host's share of a step, and that they buy either way.  LVBGPU_GEN_BESIDE=1
+    // turns it on for experiments.
+    static const bool allow_beside = [] {
+        const char *e = getenv("LVBGPU_GEN_BESIDE");
+        return e && e[0] == '1';
+    }();
+    const bool beside = allow_beside && ctx->pslot[1 - slot].in_flight && !uploaded && !moves;
+    if (beside)
+    {
+        HIPCHK(ctx, launch_propose(ga, ctx->side_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
+        ctx->side_pending = true;
+    }
+    if (ctx->side_pending) // the generator above, or tables rebuilt after the last accepted moves: before the walk / generator
+    {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
+        ctx->side_pending = false;
+    }
+    if (!beside)
+        HIPCHK(ctx, launch_propose(ga, ctx->stream));
     bt->len_zeroed = true; // by the generator
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)

@@ -238,3 +238,40 @@ def test_rerooting_several_chains_at_once_equals_rerooting_them_one_by_one(mods)
         multi.chains_reroot([(0, n + 2)])                      # not a leaf
     multi.close()
     ref.close()
+
+
+def test_two_batches_in_flight_give_what_one_at_a_time_gives(mods):
+    """lvbgpu_chains_submit / _collect: slots 0 and 1 in flight together (the second batch's generator runs beside the
+    first one's walk); lengths equal lvbgpu_propose_score with the same seeds; a commit from one batch makes the other
+    batch's candidates of that chain stale."""
+    api, host = mods
+    n, m, B = 120, 9000, 700
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 33))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=34)
+    tree.upload(ctx)
+    want = [ctx.propose_score(B, -1, 500 + i) for i in range(9)]
+    counts = ctx.chains_submit(0, [(0, B, -1, 500)])
+    ctx.chains_submit(1, [(0, B, -1, 501)])
+    with pytest.raises(api.LvbGpuError) as ei:
+        ctx.chains_submit(1, [(0, B, -1, 777)])        # that slot is still in flight
+    assert ei.value.status == -5
+    for i in range(9):
+        got = ctx.chains_collect(i % 2, counts)[0]
+        assert np.array_equal(got, want[i]), i
+        if i + 2 < 9:
+            ctx.chains_submit(i % 2, [(0, B, -1, 500 + i + 2)])
+    with pytest.raises(api.LvbGpuError):
+        ctx.chains_collect(0, counts)                   # nothing in flight there any more
+    # picks come from the batch collected last; the other batch goes stale with the commit
+    ctx.chains_submit(0, [(0, 50, 1, 1)])
+    ctx.chains_submit(1, [(0, 50, 1, 2)])
+    a = ctx.chains_collect(0, [50])[0]
+    b = ctx.chains_collect(1, [50])[0]
+    ctx.chains_commit([(0, int(np.argmin(b)))])         # from slot 1 (collected last)
+    assert ctx.current_length() == b.min()
+    ctx.chains_submit(0, [(0, 50, 1, 3)])
+    c = ctx.chains_collect(0, [50])[0]
+    ctx.chains_commit([(0, int(np.argmin(c)))])
+    assert ctx.current_length() == c.min()
+    ctx.close()
