@@ -137,11 +137,13 @@ struct OffVec
 // narrow form - offsets in 16-byte units, 32 bits, the shift folded into the address add - saves three
 // instructions per token: 2.3 % of the launch (the loop sits within 7 % of what the L2 -> CU path delivers,
 // instruction count is the second-order term: DESIGN.md section 3).
-// PERSIST (big scoring launches): the grid is what the chip holds at once and every wave walks many items, one after
-// the other - an item's descriptor and first 64 tokens are requested while the item before it is being walked.  A wave
-// that is born for ONE item spends a third of its life on the three dependent round trips before its first combine
-// (descriptor -> tokens -> rows); here they hide behind the previous item's walk, and there is no launch ramp per item.
-template <bool COMMIT, bool WIDE, bool PERSIST>
+// ITEMS: how many items (tile group x candidate) a wave walks, one after the other (1; 2 is an experiment,
+// LVBGPU_PAIR=1).  A wave's time is 1.9 us + 0.22 us per token (6.9 us at 23 tokens, 13.9 us at 55: same batch size,
+// trees of different depth).  With two items the second one's descriptor and tokens are requested together with the
+// first one's, before anything is walked, so that its three dependent round trips (descriptor -> tokens -> rows) hide
+// behind the first item's walk.  It measured 2-5 % SLOWER: with eight waves per SIMD those round trips were hidden
+// already, the fixed part is work (and ring fill / drain), not waiting.
+template <bool COMMIT, bool WIDE, int ITEMS>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(COMMIT ? 4 : 8))) void fitch_walk(const WalkArgs a)
 {
     extern __shared__ uint4 lds_stack[]; // operand stack: [wave][level][lane]
@@ -149,27 +151,13 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // XCD-aware mapping: hardware deals consecutive block ids round-robin over the 8 XCDs; XCD x gets the x-th
-    // contiguous eighth of the tile-major item list.  gridDim.x % 8 == 0.
+    // XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs; give
+    // XCD x the x-th contiguous eighth of the tile-major item list.  gridDim.x % 8 == 0.
     const uint32_t nblk = gridDim.x;
-    uint32_t item, item_end, item_step;
-    if constexpr (PERSIST)
-    {
-        // the XCD's waves take its items round-robin: with the batch laid out longest program first inside each
-        // eighth, every wave gets one item of every length band
-        const uint32_t per_xcd = (a.nitems + 7u) >> 3;
-        const uint32_t x = blockIdx.x & 7u;
-        item = x * per_xcd + (blockIdx.x >> 3) * WALK_WAVES + wave;
-        item_end = (x + 1u) * per_xcd < a.nitems ? (x + 1u) * per_xcd : a.nitems;
-        item_step = (nblk >> 3) * WALK_WAVES;
-    }
-    else
-    {
-        const uint32_t pos = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-        item = pos * WALK_WAVES + wave;
-        item_end = a.nitems;
-        item_step = 0x40000000u; // one item per wave
-    }
+    const uint32_t pos = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const uint32_t item0 = (pos * WALK_WAVES + wave) * (uint32_t)ITEMS;
+    if (item0 >= a.nitems)
+        return;
     // an item = (tile group, candidate): the wave walks the candidate's program once per tile of
     // its group, so descriptor/token fetches and the final reduction are paid once per group
     // (no division: a wave's fixed cost is scalar work too)
@@ -182,15 +170,9 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             cnd -= a.B;
         }
     };
-    // PERSIST pipeline: descriptor words of item i+1 (lane k holds word k) and tokens of item i (lane k holds token k)
-    // are in flight while item i-1 is walked.  The requests are unconditional (past the wave's last item they name
-    // that item again) so that exactly two of them are outstanding at every item's start and the waits can be counted.
-    [[maybe_unused]] uint32_t cdw_next = 0, tok_cur = 0, cdw_cur = 0;
-    auto desc_word = [&](uint32_t it) -> uint32_t {
-        uint32_t g, c;
-        split(it, g, c);
-        return reinterpret_cast<const uint32_t *>(a.cands + c)[lane & 7u];
-    };
+    // ITEMS > 1: every item's descriptor (lane k holds word k) and first 64 tokens (lane k holds token k), all
+    // requested before the first item is walked
+    [[maybe_unused]] uint32_t cdw[ITEMS], tokf[ITEMS];
     auto unpack = [&](uint32_t w) -> CandDesc {
         CandDesc d;
         d.tok_off = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
@@ -203,25 +185,28 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
         d.nfresh = (uint32_t)__builtin_amdgcn_readlane((int)w, 7);
         return d;
     };
-    // tokens of the item whose descriptor words are w: lane k token k, lanes past the program read token 0 (harmless:
-    // every use is masked by the token count)
-    auto first_tokens = [&](uint32_t w) -> uint32_t {
-        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)w, 0), nt = (uint32_t)__builtin_amdgcn_readlane((int)w, 1);
-        return (a.toks + off)[lane < nt ? lane : 0u];
-    };
-    auto clamp_item = [&](uint32_t it) { return it < item_end ? it : item_end - 1u; };
-    if constexpr (PERSIST)
+    if constexpr (ITEMS > 1)
     {
-        if (item < item_end)
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
         {
-            cdw_cur = desc_word(item);
-            tok_cur = first_tokens(cdw_cur);
-            cdw_next = desc_word(clamp_item(item + item_step));
+            uint32_t g, c;
+            split(item0 + (uint32_t)k < a.nitems ? item0 + (uint32_t)k : a.nitems - 1u, g, c);
+            cdw[k] = reinterpret_cast<const uint32_t *>(a.cands + c)[lane & 7u];
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+        {
+            // lanes past the program read token 0 (harmless: every use is masked by the token count)
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)cdw[k], 0), nt = (uint32_t)__builtin_amdgcn_readlane((int)cdw[k], 1);
+            tokf[k] = (a.toks + off)[lane < nt ? lane : 0u];
         }
     }
-    for (;; item += item_step)
+#pragma unroll
+    for (int k_item = 0; k_item < ITEMS; k_item++)
     {
-    if (item >= item_end)
+    const uint32_t item = item0 + (uint32_t)k_item;
+    if (item >= a.nitems)
         return;
     uint32_t group, cand;
     split(item, group, cand);
@@ -229,17 +214,11 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
 
     CandDesc cd;
-    [[maybe_unused]] uint32_t tok_first = 0; // PERSIST: this item's first 64 tokens, requested one item ago
-    if constexpr (PERSIST)
+    [[maybe_unused]] uint32_t tok_first = 0; // ITEMS > 1: this item's first 64 tokens
+    if constexpr (ITEMS > 1)
     {
-        cd = unpack(cdw_cur);
-        tok_first = tok_cur;
-        // next item: its descriptor has arrived (requested one item ago); ask for its tokens and for the descriptor of
-        // the item after it.  Both requests are older than every row load of this item, so the ring's counted waits
-        // see them complete first.
-        cdw_cur = cdw_next;
-        tok_cur = first_tokens(cdw_cur);
-        cdw_next = desc_word(clamp_item(item + 2u * item_step));
+        cd = unpack(cdw[k_item]);
+        tok_first = tokf[k_item];
     }
     else
         cd = a.cands[a.pick ? a.pick[cand] : cand];
@@ -366,7 +345,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
             // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
             uint32_t mytok;
-            if (PERSIST && c0 == 0u)
+            if (ITEMS > 1 && c0 == 0u)
                 mytok = lane < cnt ? tok_first : 0u;
             else
                 mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
@@ -538,7 +517,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                     __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
-            return; // (never a PERSIST launch)
+            return; // (ITEMS == 1 always here)
         }
     }
     if (lane == 0 && !(COMMIT && a.tmp_changes)) // a fused commit's length is S_all + the root slot
@@ -617,8 +596,6 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             }
         }
     }
-    if constexpr (!PERSIST)
-        return; // one item per wave: no loop for the compiler to keep
     } // items of this wave
 }
 
@@ -927,40 +904,38 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         return e && e[0] == '1';
     }();
     const bool wide = force_wide || (uint64_t)args.nrows * args.in_stride4 >= (1ull << 32);
-    // experiment, LVBGPU_PERSIST=1: big scoring launches as a grid the chip holds at once (256 CUs x 8 workgroups of 4
-    // waves at 32 waves per CU), every wave walking its share of the items one after the other (PERSIST);
-    // LVBGPU_PERSIST_BLOCKS sets the workgroups per CU
-    static const int persist_per_cu = [] {
-        const char *e = getenv("LVBGPU_PERSIST");
-        if (!e || e[0] != '1') // off unless asked for: measured slower than one wave per item
-            return 0;
-        const char *b = getenv("LVBGPU_PERSIST_BLOCKS");
-        const int v = b ? atoi(b) : 8;
-        return v < 1 ? 1 : (v > 16 ? 16 : v);
+    // experiment, LVBGPU_PAIR=1: big scoring launches walk two items per wave (ITEMS = 2).  Measured on MI355X it does
+    // not pay (B = 4096: 93.5 vs 89.2 us, B = 16 384: 319 vs 314 us): the fixed 1.9 us per wave is not exposed latency -
+    // eight waves per SIMD cover one another's round trips - so one item per wave stays the default.
+    static const bool allow_pair = [] {
+        const char *e = getenv("LVBGPU_PAIR");
+        return e && e[0] == '1';
     }();
-    const uint32_t persist_blocks = 256u * (uint32_t)persist_per_cu;
-    const bool persist = !commit && !a.host_len && !a.pick && persist_per_cu > 0 && nblk >= 4u * persist_blocks;
-    if (persist)
-        nblk = persist_blocks;
+    const bool pair = allow_pair && !commit && !a.host_len && !a.pick && a.nitems >= PAIR_MIN_ITEMS;
+    if (pair)
+    {
+        nblk = ((a.nitems + 1u) / 2u + WALK_WAVES - 1) / WALK_WAVES;
+        nblk = (nblk + 7u) & ~7u;
+    }
     const dim3 grid(nblk), block(WALK_THREADS);
     if (commit)
     {
         if (wide)
-            hipLaunchKernelGGL((fitch_walk<true, true, false>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<true, true, 1>), grid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((fitch_walk<true, false, false>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<true, false, 1>), grid, block, lds, stream, a);
     }
-    else if (persist)
+    else if (pair)
     {
         if (wide)
-            hipLaunchKernelGGL((fitch_walk<false, true, true>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<false, true, 2>), grid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((fitch_walk<false, false, true>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<false, false, 2>), grid, block, lds, stream, a);
     }
     else if (wide)
-        hipLaunchKernelGGL((fitch_walk<false, true, false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((fitch_walk<false, true, 1>), grid, block, lds, stream, a);
     else
-        hipLaunchKernelGGL((fitch_walk<false, false, false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((fitch_walk<false, false, 1>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
@@ -978,12 +953,12 @@ hipError_t launch_gather_picks(const uint32_t *pick, uint32_t k, const ProposalI
 hipError_t raise_lds_limit()
 {
     // whole-tree programs may want more than the default 64 KiB of dynamic LDS
-    for (const void *f : {reinterpret_cast<const void *>(&fitch_walk<true, true, false>),
-                          reinterpret_cast<const void *>(&fitch_walk<true, false, false>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, true, false>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, false, false>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, true, true>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, false, true>)})
+    for (const void *f : {reinterpret_cast<const void *>(&fitch_walk<true, true, 1>),
+                          reinterpret_cast<const void *>(&fitch_walk<true, false, 1>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, true, 1>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, false, 1>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, true, 2>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, false, 2>)})
     {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         if (e != hipSuccess)

@@ -19,6 +19,7 @@ constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
 
 constexpr uint32_t TARGET_WAVES = 65536;          // aim for at least this many (group, candidate) waves per launch
 constexpr uint32_t MAX_TILES_PER_WAVE = 8;
+constexpr uint32_t PAIR_MIN_ITEMS = 32768;        // scoring launches of at least this many items walk two items per wave
 
 // "length" the device generator gives a candidate it could not represent (per-candidate buffers
 // too short, no admissible move): the host turns anything this large into INT64_MAX
