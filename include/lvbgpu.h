@@ -274,6 +274,13 @@ int lvbgpu_comm_unique_id(void *id128);
 int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const void *id128);
 int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value /* in: local best, out: global best */,
                          int32_t *argmin_rank /* may be NULL */);
+/* the other sharding of the path (the reference's OpenMP site slices, TreeEvaluation.c:95-97): rank r
+ * of k creates its context from columns [m r / k, m (r + 1) / k) of the alignment (cut at multiples of 2048 sites for
+ * whole tiles); every rank scores the SAME candidates on its slice, and since a length is a sum over sites the
+ * candidates' lengths are the sums of the ranks' values: values[count] in, sums out (one RCCL sum per step).  For one
+ * chain on an alignment too large for one GPU to score fast enough; restarts (lvbgpu_allreduce_min) remain the
+ * primary way to use several GPUs. */
+int lvbgpu_allreduce_sum(lvbgpu_ctx *ctx, int64_t *values, int32_t count);
 int lvbgpu_comm_destroy(lvbgpu_ctx *ctx);
 
 #ifdef __cplusplus

@@ -96,6 +96,7 @@ SIGNATURES = {
     "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lvbgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lvbgpu_allreduce_min": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "lvbgpu_allreduce_sum": (C.c_int, [C.c_void_p, _i64p, C.c_int32]),
     "lvbgpu_comm_destroy": (C.c_int, [C.c_void_p]),
 }
 
@@ -416,11 +417,26 @@ class FitchContext:
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self.lib.lvbgpu_comm_init(self.h, nranks, rank, buf))
 
+    def allreduce_sum(self, values) -> np.ndarray:
+        """Site-axis sharding: per-candidate partial lengths in, their sums over the ranks out."""
+        v = np.ascontiguousarray(values, dtype=np.int64).copy()
+        self._chk(self.lib.lvbgpu_allreduce_sum(self.h, v, len(v)))
+        return v
+
     def allreduce_min(self, value: int) -> tuple[int, int]:
         v = C.c_int64(value)
         who = C.c_int32()
         self._chk(self.lib.lvbgpu_allreduce_min(self.h, C.byref(v), C.byref(who)))
         return v.value, who.value
+
+
+def site_slice(m: int, rank: int, world: int, tile_sites: int = 2048) -> tuple[int, int]:
+    """Columns [lo, hi) of an m-site alignment that rank `rank` of `world` scores when the SITE axis is sharded
+    (lvbgpu_allreduce_sum): whole tiles of 2048 sites, dealt as evenly as they go."""
+    tiles = (m + tile_sites - 1) // tile_sites
+    lo = tiles * rank // world * tile_sites
+    hi = tiles * (rank + 1) // world * tile_sites
+    return min(lo, m), min(hi, m)
 
 
 def comm_available() -> bool:

@@ -41,6 +41,7 @@ bool load_rccl(std::string *why)
 }
 constexpr int NCCL_INT64 = 4; // ncclInt64
 constexpr int NCCL_MIN = 3;   // ncclMin
+constexpr int NCCL_SUM = 0;   // ncclSum
 } // namespace lvbgpu_detail
 
 extern "C" int lvbgpu_comm_available(void)
@@ -87,7 +88,7 @@ extern "C" int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const voi
                          std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
     ctx->comm_rank = rank;
     ctx->comm_size = nranks;
-    HIPCHK(ctx, ctx->d_comm.reserve(16));
+    HIPCHK(ctx, ctx->d_comm.reserve(4096));
     return LVBGPU_OK;
 }
 
@@ -111,6 +112,27 @@ extern "C" int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value, int32_t *ar
     *value = vals[0];
     if (argmin_rank)
         *argmin_rank = (int32_t)(vals[1] & 0xFFFF);
+    return LVBGPU_OK;
+}
+
+// The second way the path shards (the reference's OpenMP slices, TreeEvaluation.c:95-97, 166-179): the
+// SITE axis.  A length is a sum over sites, so when rank r's context holds columns [m r / k, m (r + 1) / k) of the
+// alignment, a candidate's length is the sum of the ranks' lengths for it: one RCCL sum over B 64-bit values per step.
+extern "C" int lvbgpu_allreduce_sum(lvbgpu_ctx *ctx, int64_t *values, int32_t count)
+{
+    if (!ctx || !values || count < 1)
+        return LVBGPU_E_ARG;
+    if (!ctx->comm)
+        return ctx->fail(LVBGPU_E_STATE, "no communicator: call lvbgpu_comm_init first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->d_comm.reserve((size_t)count * 8));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm.p, values, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int r = g_rccl.AllReduce(ctx->d_comm.p, ctx->d_comm.p, (size_t)count, NCCL_INT64, NCCL_SUM, ctx->comm, ctx->stream);
+    if (r != 0)
+        return ctx->fail(LVBGPU_E_COMM,
+                         std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    HIPCHK(ctx, hipMemcpyAsync(values, ctx->d_comm.p, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return LVBGPU_OK;
 }
 

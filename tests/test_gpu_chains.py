@@ -275,3 +275,37 @@ def test_two_batches_in_flight_give_what_one_at_a_time_gives(mods):
     ctx.chains_commit([(0, int(np.argmin(c)))])
     assert ctx.current_length() == c.min()
     ctx.close()
+
+
+def test_site_axis_shards_add_up(mods):
+    """SURVEY.md 8(e), second sharding: contexts over column slices of the alignment score the same candidates and the
+    slices' lengths add up to the whole alignment's (here: three slices on one GPU, then the RCCL sum with one rank)."""
+    api, host = mods
+    n, m = 50, 9000
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 61))
+    m = len(rows[0])
+    whole = api.FitchContext(text_rows=rows)
+    parts = []
+    for r in range(3):
+        lo, hi = api.site_slice(m, r, 3)
+        assert lo % 2048 == 0 and (hi % 2048 == 0 or hi == m) and lo < hi
+        parts.append(api.FitchContext(text_rows=[row[lo:hi] for row in rows]))
+    assert api.site_slice(m, 0, 3)[0] == 0 and api.site_slice(m, 2, 3)[1] == m
+    tree = host.HostTree(n, seed=62)
+    total = tree.upload(whole)
+    assert sum(tree.upload(p) for p in parts) == total
+    for step in range(6):
+        cands = [tree.propose(k % 3) for k in range(64)]
+        want = whole.score_batch(cands)
+        got = sum(p.score_batch(cands) for p in parts)
+        assert np.array_equal(got, want)
+        pick = cands[int(np.argmin(want))]
+        assert sum(p.commit(pick) for p in parts) == whole.commit(pick)
+        tree.apply(pick)
+    uid = api.comm_unique_id()
+    parts[0].comm_init(1, 0, uid)
+    v = parts[0].score_batch(cands)
+    assert np.array_equal(parts[0].allreduce_sum(v), v)       # one rank: the sum is the value
+    for p in parts:
+        p.close()
+    whole.close()
