@@ -505,11 +505,6 @@ def rank_main(args) -> None:
         out["kernel_only"] = kernel_only(ctx, tree, B, kind, args.nbatches, steps_side, min(args.warmup, 10))
 
     extras = rank == 0 and world == 1 and not args.headline_only
-    if extras and not args.no_cpu_baseline and args.dist == "tree":
-        cb = cpu_reference_on_tree(rows, kind, args.cpu_seconds, fresh_arrays, length,
-                                   (args.taxa, args.sites, args.seed, args.dist))
-        out["cpu_baseline"] = cb if cb is not None else cpu_port_baseline(rows, kind, args.cpu_seconds, tree)
-
     if extras and not args.no_shapes:
         shapes = {}
         for b in (256, 1024):
@@ -544,9 +539,7 @@ def rank_main(args) -> None:
             "roofline": roofline_block(ctx, B, m["alg_bytes"], m["launch_ms"], m["mean_dirty"], load_traffic(args, True), 10),
             "kernel_only": kernel_only(ctx, mtree, B, kind, args.nbatches, steps_side, 5),
         }
-        if not args.no_cpu_baseline and args.dist == "tree":
-            mw["cpu_baseline"] = cpu_reference_on_tree(rows, kind, args.cpu_seconds, tree_arrays_of(mtree), mlen,
-                                                       (args.taxa, args.sites, args.seed, args.dist), all_cores=False)
+        mixed_arrays, mixed_len = tree_arrays_of(mtree), mlen
         out["mixed_walk"] = mw
         # back to the headline tree for the annealing leg
         tree.upload(ctx)
@@ -597,6 +590,16 @@ def rank_main(args) -> None:
         for t in atrees:
             t.close()
         actx.close()
+    # LVB's own CPU path last: 32 reference processes at once leave the host's CPU quota throttled for a while, which
+    # the legs above (host threads beside the GPU) would feel
+    if extras and not args.no_cpu_baseline and args.dist == "tree":
+        cb = cpu_reference_on_tree(rows, kind, args.cpu_seconds, fresh_arrays, length,
+                                   (args.taxa, args.sites, args.seed, args.dist))
+        out["cpu_baseline"] = cb if cb is not None else cpu_port_baseline(rows, kind, args.cpu_seconds, tree)
+
+    if extras and not args.no_cpu_baseline and args.dist == "tree" and "mixed_walk" in out:
+        out["mixed_walk"]["cpu_baseline"] = cpu_reference_on_tree(rows, kind, args.cpu_seconds, mixed_arrays, mixed_len,
+                                                                  (args.taxa, args.sites, args.seed, args.dist), all_cores=False)
     tree.close()
     ctx.close()
     ranks.close()
