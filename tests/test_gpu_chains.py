@@ -304,7 +304,7 @@ def test_site_axis_shards_add_up(mods):
         tree.apply(pick)
     uid = api.comm_unique_id()
     parts[0].comm_init(1, 0, uid)
-    v = parts[0].score_batch(cands)
+    v = parts[0].score_batch([tree.propose(1) for _ in range(40)])
     assert np.array_equal(parts[0].allreduce_sum(v), v)       # one rank: the sum is the value
     for p in parts:
         p.close()
