@@ -154,7 +154,11 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     // XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs; give
     // XCD x the x-th contiguous eighth of the tile-major item list.  gridDim.x % 8 == 0.
     const uint32_t nblk = gridDim.x;
-    const uint32_t pos = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    // a.flip: every other launch walks each XCD's share of the tile-major list from its far end.  A tree block beyond
+    // the XCD L2s (cfg5: 401 MB) is then re-read starting with the tiles the previous launch touched LAST, which are
+    // the ones still in the 256 MiB Infinity Cache (walking the same way every time would find none of it there).
+    const uint32_t in_xcd = a.flip ? (nblk >> 3) - 1u - (blockIdx.x >> 3) : (blockIdx.x >> 3);
+    const uint32_t pos = (blockIdx.x & 7u) * (nblk >> 3) + in_xcd;
     const uint32_t item0 = (pos * WALK_WAVES + wave) * (uint32_t)ITEMS;
     if (item0 >= a.nitems)
         return;
@@ -865,6 +869,15 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         args.nitems >= (1u << 31))
         return hipErrorInvalidValue;
     WalkArgs a = args;
+    // alternate the direction of big scoring launches whose rows do not fit the L2s (LVBGPU_FLIP=0: never)
+    static const bool allow_flip = [] {
+        const char *e = getenv("LVBGPU_FLIP");
+        return !(e && e[0] == '0');
+    }();
+    static uint32_t flip_counter = 0;
+    a.flip = 0;
+    if (allow_flip && !commit && (uint64_t)args.nrows * args.in_stride4 * 16u > FLIP_MIN_BYTES)
+        a.flip = (flip_counter++) & 1u;
     a.tiles_per = a.ntiles / a.ngroups;
     a.tiles_rem = a.ntiles % a.ngroups;
     // floor(2^32 / B): mulhi(item, inv_B) is floor(item / B) or one less for item < 2^31 (the kernel

@@ -19,7 +19,8 @@ constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
 
 constexpr uint32_t TARGET_WAVES = 65536;          // aim for at least this many (group, candidate) waves per launch
 constexpr uint32_t MAX_TILES_PER_WAVE = 8;
-constexpr uint32_t PAIR_MIN_ITEMS = 32768;        // scoring launches of at least this many items walk two items per wave
+constexpr uint32_t PAIR_MIN_ITEMS = 32768;
+constexpr uint64_t FLIP_MIN_BYTES = 64ull << 20;  // tree blocks beyond this alternate the direction of scoring launches        // scoring launches of at least this many items walk two items per wave
 
 // "length" the device generator gives a candidate it could not represent (per-candidate buffers
 // too short, no admissible move): the host turns anything this large into INT64_MAX
@@ -84,6 +85,7 @@ struct WalkArgs
     // settles that candidate.  A single commit is j = 0, tmp_stride irrelevant.
     const uint32_t *pick;
     uint32_t tmp_stride;
+    uint32_t flip; // walk each XCD's share of the items from its far end (filled by launch_walk)
     // COMMIT: produced sets and their counts wait in LDS, this many per wave, and go out in bursts (filled by
     // launch_walk, >= 1 for COMMIT).  A store or atomic inside the chain makes every wait for a
     // row a full drain of the memory counter (reads and writes return out of order with respect to each other),
