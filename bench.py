@@ -411,6 +411,8 @@ def load_traffic(args, mixed: bool):
 
 def rank_main(args) -> None:
     from lvb_amd.launch import Ranks
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # read when RCCL is first initialised: a failing CommInitRank says why
     ranks = Ranks()                       # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     rank, world = ranks.rank, ranks.world
     if world != args.gpus:
@@ -435,7 +437,6 @@ def rank_main(args) -> None:
         # RCCL communicator of the scoring library itself (not torch's).  Its init is collective, so the
         # ranks first agree (through torch) that every one of them can take part: a rank that cannot must not
         # leave the others waiting inside ncclCommInitRank.
-        os.environ.setdefault("NCCL_DEBUG", "WARN")   # a failing ncclCommInitRank says why on stderr
         if ranks.sum_over_ranks(int(api.comm_available())) == world:
             uid = None
             if rank == 0:
@@ -602,6 +603,7 @@ def rank_main(args) -> None:
                                                                   (args.taxa, args.sites, args.seed, args.dist), all_cores=False)
     tree.close()
     ctx.close()
+    ranks.barrier()   # rank 0 has more legs than the others: nobody tears the process group down under it
     ranks.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
