@@ -3,6 +3,7 @@ the best trees.  Mirrors the reference program's flow (Main.c:60-155) and result
 host (batched SA over the device scorer); it is a convenience around the library, not a port of the CLI.
 
   python -m lvb_amd.search -i alignment.phy [-s seed] [-a 0|1] [-o outtree] [--batch B] [--device D]
+  python -m lvb_amd.search -i alignment.phy --chains 32         # 32 restarts stepped together on one GPU
   python -m lvb_amd.search -i alignment.phy -s seed --exact     # the reference's own trajectory (-a 0|1|2)
   python -m torch.distributed.run --nproc-per-node 8 -m lvb_amd.search -i alignment.phy   # one restart per GPU
 
@@ -19,6 +20,65 @@ import sys
 import time
 
 from . import api, host
+
+
+def run_chains(path: str, seed: int = 1, chains: int = 16, algorithm: int = 1, batch: int = 4096, device: int = 0,
+               out: str | None = "outtree", max_seconds: float = 0.0, cooling: int = 0, verbose: bool = True,
+               fmt: str = "phylip") -> dict:
+    """`chains` independent restarts stepped together on ONE GPU (lvbhost_anneal_chains): every device step draws,
+    scores and commits for all of them.  The trees written are the distinct topologies of the best length over all
+    chains."""
+    t0 = time.perf_counter()
+    names, rows = host.read_alignment(path, fmt)
+    n, m_read = len(rows), len(rows[0])
+    if n < 5:
+        raise ValueError("The data matrix must have at least 5 sequences.")  # Wrapper.c:54 (MIN_N)
+    rows, min_len = host.prepare_alignment(rows)
+    ctx = api.FitchContext(text_rows=rows, device=device)
+    trees = [host.HostTree(n, seed=seed * 1000 + c) for c in range(chains)]
+    params = []
+    for c in range(chains):
+        p = host.anneal_defaults()
+        p.seed = seed * 1000 + c + 1
+        p.algorithm, p.cooling_schedule, p.batch = algorithm, cooling, batch
+        p.min_len_tree, p.max_seconds, p.t0, p.log_cap = min_len, max_seconds, 0.0, 4096
+        params.append(p)
+    per_chain, log = host.anneal_chains(ctx, trees, params)
+    best = min(r["best_length"] for r in per_chain)
+    seen, newick = set(), []
+    for r, t in zip(per_chain, trees):
+        if r["best_length"] != best:
+            continue
+        for bt in t.best_trees():
+            key = bt.canonical()               # exact, rooting-independent identity: one line per topology
+            if key not in seen:
+                seen.add(key)
+                newick.append(host.newick(bt, names))
+    if out:
+        with open(out, "w") as f:
+            f.writelines(newick)
+    res = dict(chains=chains, best_length=best, best_lengths=[r["best_length"] for r in per_chain],
+               consumed=sum(r["consumed"] for r in per_chain), scored=sum(r["scored"] for r in per_chain),
+               topologies=len(newick), frozen=sum(r["frozen"] for r in per_chain), taxa=n, sites_read=m_read,
+               sites_used=len(rows[0]), min_len_tree=min_len, wall_seconds=time.perf_counter() - t0, log=log, outtree=out,
+               newick=newick)
+    if verbose:
+        ci = min_len / best
+        print("\nSearch Results:")
+        print(f"  Chains on this GPU:       {chains}  ({res['frozen']} frozen)")
+        print(f"  Rearrangements evaluated: {res['consumed']}")
+        print(f"  Candidates scored (GPU):  {res['scored']}")
+        print(f"  Topologies recovered:     {res['topologies']}")
+        print(f"  Tree score:               {best}")
+        print(f"  Consistency index:        {ci:.2f}")
+        print(f"  Homoplasy index:          {1 - ci:.2f}")
+        print(f"  Total runtime (seconds):  {res['wall_seconds']:.2f}")
+        if out:
+            print(f"\nAll topologies written to '{out}'")
+    for t in trees:
+        t.close()
+    ctx.close()
+    return res
 
 
 def run(path: str, seed: int = 1, algorithm: int = 1, batch: int = 4096, device: int = 0, out: str | None = "outtree",
@@ -151,6 +211,7 @@ def main(argv=None) -> int:
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--host-proposals", action="store_true", help="draw neighbours on the host instead of the GPU")
+    ap.add_argument("--chains", type=int, default=1, help="independent restarts stepped together on this GPU (1 .. 64)")
     ap.add_argument("--exact", action="store_true", help="reproduce the reference program's run for this seed")
     ap.add_argument("-N", dest="max_trees", type=int, default=0)
     a = ap.parse_args(argv)
@@ -166,6 +227,9 @@ def main(argv=None) -> int:
         if ranks.world > 1:
             run_restarts(ranks, a.infile, a.seed, a.out, **kw)
             ranks.close()
+        elif a.chains > 1:
+            run_chains(a.infile, a.seed, a.chains, algorithm=a.algorithm, batch=a.batch, device=a.device, out=a.out,
+                       max_seconds=a.max_seconds, cooling=0 if a.cooling == "g" else 1, fmt=a.fmt)
         else:
             run(a.infile, a.seed, device=a.device, out=a.out, **kw)
     except (api.LvbGpuError, ValueError, OSError) as exc:

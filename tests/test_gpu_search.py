@@ -31,7 +31,21 @@ def test_search_reaches_reference_optimum(tmp_path, phy, score, topologies, on_d
     if topologies is not None:
         assert res["topologies"] == topologies
     lines = out.read_text().splitlines()
-    assert len(lines) == min(res["topologies"], 1024) and all(l.startswith("(") and l.endswith(");") for l in lines)
+    assert len(lines) == res["topologies"] and all(l.startswith("(") and l.endswith(");") for l in lines)
+
+
+@pytest.mark.parametrize("phy,score", [("test_treelength_6_thread_2.phy", 1628), ("test_treelength_7_thread_2.phy", 1006)])
+def test_chains_on_one_gpu_reach_the_reference_optimum(tmp_path, phy, score):
+    """`--chains R`: R restarts stepped together; the best over the chains is the reference's known optimum and the
+    output holds each distinct best topology once."""
+    from lvb_amd import search
+    out = tmp_path / "outtree"
+    res = search.run_chains(str(GOLD / "ref_tests" / phy), seed=77, chains=6, batch=64, out=str(out), max_seconds=60,
+                            verbose=False)
+    assert res["best_length"] == score and min(res["best_lengths"]) == score, res["best_lengths"]
+    lines = out.read_text().splitlines()
+    assert len(lines) == res["topologies"] >= 1 and len(set(lines)) == len(lines)
+    assert all(l.startswith("(") and l.endswith(");") for l in lines)
 
 
 def test_two_restarts_share_one_gpu_and_the_best_one_writes_the_trees(tmp_path):
