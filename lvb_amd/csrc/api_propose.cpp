@@ -226,6 +226,11 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     if ((uint64_t)total * stride_t >= (1ull << 32) || (uint64_t)total * ctx->ntiles >= (1ull << 31))
         return ctx->fail(LVBGPU_E_ARG, "batch too large");
     const int32_t B = (int32_t)total;
+    if (ctx->side_pending) // tables being rebuilt on the side stream: before an upload below could be overtaken by them,
+    {                      // and before the generator reads them
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
+        ctx->side_pending = false;
+    }
     bool uploaded = false;
     int rc = prepare_tables(ctx, chains.data(), k, &uploaded);
     if (rc != LVBGPU_OK)
@@ -360,7 +365,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
         ctx->side_pending = true;
     }
-    if (ctx->side_pending) // the generator above, or tables rebuilt after the last accepted moves: before the walk / generator
+    if (ctx->side_pending) // the generator above: before the walk
     {
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
         ctx->side_pending = false;

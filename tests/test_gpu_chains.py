@@ -309,3 +309,87 @@ def test_site_axis_shards_add_up(mods):
     for p in parts:
         p.close()
     whole.close()
+
+
+def test_random_operations_over_chains_against_the_cpu_oracle(mods):
+    """A random mix of everything that can change a chain - picks from multi-chain batches, batched re-roots, commits of
+    host-built rewrites, device moves through the single-tree calls - with every chain checked against the CPU ORACLE
+    after each operation: full evaluation of the topology the library reports == the resident length, per-node changes
+    and node sets; and the next device-drawn neighbourhood scores what the oracle scores."""
+    from oracle import binding as ob
+    from tests import helpers
+    api, host = mods
+    n, m, R = 26, 520, 4
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 101))
+    enc = ob.encode_rows(rows)
+    ctx = api.FitchContext(text_rows=rows)
+    ctx.set_chains(R)
+    for c in range(R):
+        ctx.select_chain(c)
+        host.HostTree(n, seed=300 + c).upload(ctx)
+
+    def oracle_of(c):
+        ctx.select_chain(c)
+        _, l, r, root = ctx.topology()
+        l64, r64 = l.astype(np.int64), r.astype(np.int64)
+        t = ob.OracleTree(n, enc.shape[1], enc)
+        t.set_topology(helpers.parents_of(l64, r64), l64, r64, root)
+        return t, l, r, root
+
+    def check(c):
+        t, l, r, root = oracle_of(c)
+        assert ctx.current_length() == t.getplen(), c
+        assert np.array_equal(ctx.changes()[n:], t.changes()[n:])
+        assert np.array_equal(ctx.all_sets(), t.all_sets())
+        return t, l, r, root
+
+    rng = np.random.default_rng(12)
+    for step in range(36):
+        op = int(rng.integers(0, 4))
+        if op == 0:      # one step over a random subset of chains, some of them accept
+            active = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
+            draws = [(c, int(rng.integers(2, 40)), -1, 10_000 + 97 * step + c) for c in active]
+            lens = ctx.chains_propose_score(draws)
+            picks = [(c, int(rng.integers(0, cnt))) for (c, cnt, _, _), _ in zip(draws, lens) if rng.random() < 0.7]
+            want = {c: int(l[b]) for (c, b), l in ((p, lens[[d[0] for d in draws].index(p[0])]) for p in picks)}
+            if picks:
+                ctx.chains_commit(picks)
+            for c, b in picks:
+                ctx.select_chain(c)
+                assert ctx.current_length() == want[c]
+        elif op == 1:    # batched re-roots
+            who = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
+            reqs = []
+            for c in who:
+                ctx.select_chain(c)
+                root = ctx.topology()[3]
+                reqs.append((c, int((root + 1 + rng.integers(0, n - 1)) % n)))
+            ctx.chains_reroot(reqs)
+        elif op == 2:    # a host-built move committed through the single-tree call
+            c = int(rng.integers(0, R))
+            _, l, r, root = oracle_of(c)
+            ht = host.HostTree(left=l, right=r, root=root, seed=500 + step)
+            ctx.select_chain(c)
+            ctx.commit(ht.propose(int(rng.integers(0, 3))))
+        else:            # a device move through the single-tree calls
+            c = int(rng.integers(0, R))
+            ctx.select_chain(c)
+            lens = ctx.propose_score(12, -1, 777 + step)
+            b = int(rng.integers(0, 12))
+            edits, _ = ctx.proposal_edits(b)
+            assert ctx.commit(edits) == lens[b]
+        for c in range(R):
+            cur, l, r, root = check(c)
+            # the next neighbourhood of this chain, drawn on the device, against the oracle's incremental getplen
+            lens = ctx.propose_score(6, -1, 31 * step + c)
+            for b in range(6):
+                edits, _ = ctx.proposal_edits(b)
+                ht = host.HostTree(left=l, right=r, root=root)
+                prog = ht.program(mode=0, edits=edits)
+                nl, nr = helpers.apply_edits(l, r, edits)
+                cand = ob.OracleTree(n, enc.shape[1])
+                cand.copy_from(cur)
+                cand.set_topology(helpers.parents_of(nl, nr), nl, nr, root)
+                cand.mark_dirty([d for d in prog["dsts"] if d >= 0])
+                assert int(lens[b]) == cand.getplen(), (step, c, b)
+    ctx.close()
