@@ -327,6 +327,12 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     ga.info = (ProposalInfo *)ps.d_pinfo.p;
     ga.len_out = (unsigned long long *)bt->d_len.p;
     ga.moves = d_moves;
+    static const bool gen_profile = getenv("LVBGPU_GEN_PROFILE") != nullptr;
+    if (gen_profile)
+    {
+        HIPCHK(ctx, ctx->d_gen_prof.reserve(256 * 8 * 8));
+        ga.prof = (unsigned long long *)ctx->d_gen_prof.p;
+    }
     ga.nseg = (uint32_t)k;
     uint32_t start = 0;
     for (int32_t i = 0; i < k; i++)
@@ -483,6 +489,17 @@ extern "C" int lvbgpu_propose_score_mixed(lvbgpu_ctx *ctx, int32_t B, double p_n
 extern "C" int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_draw *draws, int64_t *lengths_out)
 {
     return propose_core(ctx, k, draws, lengths_out, nullptr);
+}
+
+// diagnostic (LVBGPU_GEN_PROFILE set): the clock stamps the last generator launch left for its first 256 candidates
+extern "C" int lvbgpu_debug_generator_stamps(lvbgpu_ctx *ctx, unsigned long long *out2048)
+{
+    if (!ctx || !out2048 || !ctx->d_gen_prof.p)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out2048, ctx->d_gen_prof.p, 256 * 8 * 8, hipMemcpyDeviceToHost));
+    return LVBGPU_OK;
 }
 
 extern "C" int lvbgpu_chains_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws)

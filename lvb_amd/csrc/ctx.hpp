@@ -214,6 +214,7 @@ struct lvbgpu_ctx
     static constexpr int PROP_SLOTS = 2;
     PropSlot pslot[PROP_SLOTS];
     int last_slot = 0;              // the batch lvbgpu_chains_commit picks from: the one collected last
+    DevBuf d_gen_prof; // LVBGPU_GEN_PROFILE: clock stamps of the generator (diagnostic)
     DevBuf d_topo4; // the generator's tables of the resident topologies, gen_table_stride each
     uint32_t gen_table_stride = 0;
     int32_t gen_kmax = 1; // ancestor tables hold 2^0 .. 2^(kmax-1): 2^kmax exceeds any depth of a tree of these taxa

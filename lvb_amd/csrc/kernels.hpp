@@ -132,7 +132,8 @@ struct ProposalInfo
 // a subtree is the interval [tin, tin + 2 nleaf - 1)); leaf_order = the non-root leaves in preorder and
 // first_leaf[v] the position of v's first one; up[k][v] = the 2^k-th ancestor of v, the root beyond it.
 // Built by the host when the resident topology changes (api_propose.cpp), padded to 16 bytes.
-constexpr uint32_t GEN_WAVES = 4;
+constexpr uint32_t GEN_WAVES = 16; // one copy of the tables into LDS serves 16 candidates at a time (4 waves: 72 % of a
+                                    // candidate's time was its workgroup's copy - a thousand workgroups reading the same 34 KB)
 constexpr uint32_t GEN_THREADS = 64 * GEN_WAVES;
 constexpr uint32_t MAX_GEN_SEGS = 64; // = MAX_CHAINS: one segment of a launch per resident tree
 // one run of candidates of ONE resident tree inside a generator launch
@@ -162,6 +163,7 @@ struct GenArgs
     ProposalInfo *info;
     unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
     const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
+    unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
     int32_t use_lds;              // filled by launch_propose
     uint32_t nseg;
     GenSeg seg[MAX_GEN_SEGS];

@@ -60,11 +60,25 @@ struct DevRng
     }
 };
 
-// the tables of one topology (GenTables in kernels.hpp gives the layout), in LDS or in global memory
+// the tables of one topology (GenArgs in kernels.hpp gives the layout), in LDS or in global memory.  The pointers
+// carry their address space: through generic pointers every table read is a FLAT load (the vector memory pipe decides
+// at run time where the address lies: ~90 wait cycles each, 87 of them per candidate), with LDS pointers it is a
+// ds_read (generator 19 -> 10 us at B = 4096).
+template <typename IdxT, bool IN_LDS>
+struct TabPtr
+{
+    using type = const __attribute__((address_space(1))) IdxT *;
+};
 template <typename IdxT>
+struct TabPtr<IdxT, true>
+{
+    using type = const __attribute__((address_space(3))) IdxT *;
+};
+template <typename IdxT, bool IN_LDS>
 struct Tab
 {
-    const IdxT *parent, *left, *right, *nleaf, *depth, *tin, *first_leaf, *leaf_order, *up;
+    using P = typename TabPtr<IdxT, IN_LDS>::type;
+    P parent, left, right, nleaf, depth, tin, first_leaf, leaf_order, up;
     int32_t n, nb, root, K;
 
     __device__ int32_t par(int32_t v) const { return (int32_t)parent[v]; }
@@ -116,7 +130,11 @@ struct Tab
         a = anc(a, (uint32_t)(da - db));
         if (a == b)
             return a;
-        for (int32_t i = K - 1; i >= 0; i--)
+        // both are db below the root now: a jump of 2^i > db lands on the root for both, nothing to learn from it
+        int32_t top = 31 - __builtin_clz((uint32_t)db | 1u);
+        if (top > K - 1)
+            top = K - 1;
+        for (int32_t i = top; i >= 0; i--)
         {
             const int32_t ua = (int32_t)up[(size_t)i * nb + a], ub = (int32_t)up[(size_t)i * nb + b];
             if (ua != ub)
@@ -137,10 +155,10 @@ struct GenOut
     uint32_t ntok, ndst, nedit, nfresh, cap_e;
 };
 
-template <typename IdxT>
+template <typename IdxT, bool IN_LDS>
 struct Gen
 {
-    const Tab<IdxT> &t;
+    const Tab<IdxT, IN_LDS> &t;
     GenOut o;
     uint32_t lane;
 
@@ -219,16 +237,22 @@ struct Gen
 // threshold mix_a, SPR below mix_b, else TBR, both scaled to 2^32 (reference -a 1, Solve.c:262-283)
 // bl: the candidate's index within its segment (what the draw is a function of, with the segment's seed);
 // b = sg.start + bl: its slot in the batch
-template <typename IdxT>
-__device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const GenSeg &sg, const uint32_t bl, const uint32_t lane)
+template <typename IdxT, bool IN_LDS>
+__device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const GenSeg &sg, const uint32_t bl, const uint32_t lane)
 {
     const int32_t n = t.n, nb = t.nb, root = t.root;
     const uint32_t b = sg.start + bl;
     const uint64_t seed = ((uint64_t)sg.seed_hi << 32) | sg.seed_lo;
     const DevRng rng{seed ^ ((uint64_t)(bl + 1u) * 0xD1B54A32D192ED03ull)};
-    Gen<IdxT> e{t, GenOut{g.toks + (size_t)b * g.stride_t, g.dsts + (size_t)b * g.stride_t, g.edits + (size_t)b * g.stride_e, 0, 0,
+    Gen<IdxT, IN_LDS> e{t, GenOut{g.toks + (size_t)b * g.stride_t, g.dsts + (size_t)b * g.stride_t, g.edits + (size_t)b * g.stride_e, 0, 0,
                           0, 0, g.stride_e},
                 lane};
+    // LVBGPU_GEN_PROFILE (tools/gen_profile.py): where a candidate's time goes, clock stamps of the first 256 candidates
+    auto stamp = [&](uint32_t k) {
+        if (g.prof && b < 256u && lane == 0)
+            g.prof[b * 8u + k] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     int32_t kind = sg.kind_all;
     if (sg.kind_all == -1)
         kind = (int32_t)(bl % 3u);
@@ -318,6 +342,7 @@ __device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const GenSeg 
             unusable = true; // no admissible move found: emit nothing usable
         else
         {
+            stamp(1); // drawn
             const int32_t dp = t.par(dest);
             pi.a = src;
             pi.b = dest;
@@ -423,6 +448,7 @@ __device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const GenSeg 
                     }
                     e.edit(sp, dest, top);
                 }
+                stamp(2); // rewrites (and the TBR subtree chain) out
                 // ---- the program.  d(v) = depth below the root; a root-ward path of y has d(y) nodes (the root is
                 // not one of them).  Three shapes (TreeOperations.c:302, 330-334: both root-ward paths are dirty):
                 const int32_t oc_dp = dp == root ? -1 : t.other(dp, dest); // dp's clean child once sp has taken dest's place
@@ -503,6 +529,7 @@ __device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const GenSeg 
         }
     }
 
+    stamp(3); // program out
     const bool overflow = unusable || e.o.nedit > e.o.cap_e;
     if (lane == 0)
     {
@@ -529,14 +556,16 @@ __device__ void generate_one(const Tab<IdxT> &t, const GenArgs &g, const GenSeg 
         pi.ncomb = (int32_t)e.o.ndst;
         g.info[b] = pi;
     }
+    stamp(4);
 }
 
 } // namespace
 
-template <typename IdxT>
+template <typename IdxT, bool IN_LDS>
 __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 {
     extern __shared__ uint4 lds_tables[];
+    const uint64_t t_enter = g.prof ? __builtin_readcyclecounter() : 0ull;
     // which segment (resident tree) this workgroup works for: its first workgroup is seg[s].blk_start
     uint32_t s = 0;
     while (s + 1u < g.nseg && blockIdx.x >= g.seg[s + 1u].blk_start)
@@ -545,24 +574,27 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
     const uint32_t blk_local = blockIdx.x - sg.blk_start;
     const uint32_t seg_blocks = (s + 1u < g.nseg ? g.seg[s + 1u].blk_start : gridDim.x) - sg.blk_start;
     const char *tables = reinterpret_cast<const char *>(g.tables) + sg.table_off;
-    const IdxT *tab = reinterpret_cast<const IdxT *>(tables);
-    if (g.use_lds)
+    using P = typename TabPtr<IdxT, IN_LDS>::type;
+    P tab;
+    if constexpr (IN_LDS)
     {
-        // one coalesced copy per workgroup; everything after it is LDS latency instead of L2 latency
+        // one coalesced copy per workgroup; everything after it is LDS latency instead of L2 latency (1024 threads x 4
+        // loads of 16 bytes in flight: the 34 KB of a 500-taxon tree are one round trip)
         const uint4 *src4 = reinterpret_cast<const uint4 *>(tables);
         const uint32_t n16 = sg.table_bytes / 16u;
-        for (uint32_t i0 = 0; i0 < n16; i0 += 4u * GEN_THREADS)
+        constexpr uint32_t DEPTH = 4;
+        for (uint32_t i0 = 0; i0 < n16; i0 += DEPTH * GEN_THREADS)
         {
-            uint4 v[4];
+            uint4 v[DEPTH];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; u++)
+            for (uint32_t u = 0; u < DEPTH; u++)
             {
                 const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
                 if (i < n16)
                     v[u] = src4[i];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; u++)
+            for (uint32_t u = 0; u < DEPTH; u++)
             {
                 const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
                 if (i < n16)
@@ -570,10 +602,12 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
             }
         }
         __syncthreads();
-        tab = reinterpret_cast<const IdxT *>(lds_tables);
+        tab = (P)lds_tables; // C-style: a generic pointer known to lie in LDS becomes an LDS pointer
     }
+    else
+        tab = (P)tables;
     const size_t nb = (size_t)g.nb;
-    Tab<IdxT> t;
+    Tab<IdxT, IN_LDS> t;
     t.parent = tab;
     t.left = tab + nb;
     t.right = tab + 2 * nb;
@@ -589,6 +623,11 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
     t.K = (int32_t)sg.K;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (g.prof && lane == 0 && sg.start + blk_local * GEN_WAVES + wave < 256u)
+    {
+        g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 5u] = t_enter;
+        g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 6u] = __builtin_readcyclecounter();
+    }
     for (uint32_t bl = blk_local * GEN_WAVES + wave; bl < sg.count; bl += seg_blocks * GEN_WAVES)
         generate_one(t, g, sg, bl, lane);
 }
@@ -741,10 +780,10 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
     {
         if (!asked_on[dev])
         {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<uint16_t>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<uint16_t, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<int32_t>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<int32_t, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
             raised_on[dev] = e;
             asked_on[dev] = true;
@@ -766,7 +805,7 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
     const size_t lds = g.use_lds ? widest : 0;
     // one candidate per wave while the chip has room; beyond that waves take several.  Every segment gets
     // workgroups in proportion to its candidates (at least one)
-    const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_max / std::max<size_t>(lds, 1))) : 8u;
+    const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(2, lds_max / std::max<size_t>(lds, 1))) : 2u;
     const uint32_t budget = 256u * per_cu;
     const uint32_t want_all = (total + GEN_WAVES - 1) / GEN_WAVES;
     uint32_t nblk = 0;
@@ -780,9 +819,16 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
     }
     const dim3 grid(nblk), block(GEN_THREADS);
     if (g.idx_bytes == 2)
-        hipLaunchKernelGGL(propose_kernel<uint16_t>, grid, block, lds, stream, g);
+    {
+        if (g.use_lds)
+            hipLaunchKernelGGL((propose_kernel<uint16_t, true>), grid, block, lds, stream, g);
+        else
+            hipLaunchKernelGGL((propose_kernel<uint16_t, false>), grid, block, lds, stream, g);
+    }
+    else if (g.use_lds)
+        hipLaunchKernelGGL((propose_kernel<int32_t, true>), grid, block, lds, stream, g);
     else
-        hipLaunchKernelGGL(propose_kernel<int32_t>, grid, block, lds, stream, g);
+        hipLaunchKernelGGL((propose_kernel<int32_t, false>), grid, block, lds, stream, g);
     return hipGetLastError();
 }
 
