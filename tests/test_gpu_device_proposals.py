@@ -190,3 +190,41 @@ def test_batches_that_grow_and_shrink_keep_their_length_slots_clean(mods):
         lens = ctx.propose_score(B, -1, 5 * B)
         assert lens.min() > 0 and np.array_equal(lens, ctx.propose_score(B, -1, 5 * B)), B
     ctx.close()
+
+
+def test_device_moves_on_a_caterpillar(mods):
+    """The deepest tree there is (every internal node has a leaf child): root-ward paths of more than 64 nodes (several
+    lane-parallel trips per path run), TBR re-rootings along the whole spine, destinations mostly inside the pruned
+    subtree (long rejection runs).  Every device move replays on the host and scores what the host-built program scores;
+    accepted moves keep the device's own tables (rebuilt on the device) in step."""
+    api, host = mods
+    n, m = 150, 2100
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 19))
+    left, right = np.full(2 * n - 3, -1, np.int32), np.full(2 * n - 3, -1, np.int32)
+    # root leaf 0 holds (1, n); internal node n + i holds (leaf i + 2, n + i + 1); the last one two leaves
+    left[0], right[0] = 1, n
+    for i in range(n - 3):
+        v = n + i
+        left[v] = i + 2
+        right[v] = v + 1 if i < n - 4 else n - 1
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(left=left, right=right, root=0, seed=3)
+    tree.upload(ctx)
+    for round_ in range(4):
+        B = 600
+        lens = ctx.propose_score(B, -1, 40 + round_)
+        assert (lens < np.iinfo(np.int64).max).all()
+        cands = []
+        for b in range(0, B, 5):
+            edits, info = ctx.proposal_edits(b)
+            assert helpers.edit_key(edits) == helpers.edit_key(_replay(tree, info, api)), (round_, b, info)
+            cands.append(edits)
+        assert np.array_equal(ctx.score_batch(cands), lens[::5])
+        # accept through the multi-chain path (device-side table rebuild), then draw again from the new tree
+        draws = ctx.chains_propose_score([(0, 64, -1, 900 + round_)])[0]
+        b = int(np.argmin(draws))
+        ctx.chains_commit([(0, b)])
+        assert ctx.current_length() == draws[b]
+        _, l, r, root = ctx.topology()
+        tree = host.HostTree(left=l, right=r, root=root, seed=4 + round_)
+    ctx.close()
