@@ -88,6 +88,7 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     // (row offsets are 64-bit in the kernels: the tree block is limited by HBM, not by index width)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
@@ -256,6 +257,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream)
+        (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->d_rows)
         (void)hipFree(ctx->d_rows);
     if (ctx->d_changes)
@@ -271,6 +274,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         ps.d_pinfo.release();
         if (ps.done_ev)
             (void)hipEventDestroy(ps.done_ev);
+        if (ps.walk_ev)
+            (void)hipEventDestroy(ps.walk_ev);
     }
     ctx->h_pinfo.release();
     ctx->h_topo.release();
@@ -323,6 +328,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipEventDestroy(ctx->side_ev);
     if (ctx->side_stream)
         (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -526,6 +533,7 @@ extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
     HIPCHK(ctx, hipStreamSynchronize(ctx->side_stream));
     ctx->side_pending = false;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     if ((uint64_t)(ctx->n + (long)nchains * (ctx->n - 3)) >= (uint64_t)MAX_ROWS)
         return ctx->fail(LVBGPU_E_ARG, "too many rows for the token format");
     // new blocks: leaf rows move over, every tree slot starts empty (all-ones rows, no resident tree)

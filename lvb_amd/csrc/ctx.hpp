@@ -149,6 +149,7 @@ struct lvbgpu_ctx
     // side stream: what follows an accepted device move but does not touch state sets (the rewrites' way to the host,
     // the generator's tables) runs beside the commit walk; side_ev orders the next generator launch after it
     hipStream_t side_stream = nullptr;
+    hipStream_t copy_stream = nullptr; // read-backs of device-built batches' lengths: beside the next batch, not before it
     hipEvent_t side_ev = nullptr;
     bool side_pending = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -208,7 +209,8 @@ struct lvbgpu_ctx
         std::vector<PSeg> segs;     // the segments of the batch (lvbgpu_chains_commit picks from them)
         int32_t p_B = 0;            // candidates lvbgpu_proposal_edits may name (single chain, selected; 0: none)
         int32_t B = 0;
-        hipEvent_t done_ev = nullptr; // after the lengths' read-back
+        hipEvent_t done_ev = nullptr; // after the lengths' read-back (on the copy stream)
+        hipEvent_t walk_ev = nullptr; // after the walk (on the main stream): what the read-back waits for
         bool in_flight = false;
     };
     static constexpr int PROP_SLOTS = 2;
