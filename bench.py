@@ -21,7 +21,7 @@ Beside it, in the same JSON line:
                 CPU reference timed on that very tree
   cpu_baseline  LVB's own CPU path (the compiled reference, oracle/_ref) on the SAME tree and neighbourhood
                 as the headline leg, one core and all cores
-  shapes        B = 256 / 1024 and the i.i.d.-uniform alignment (SURVEY.md 8d "U")
+  shapes        B = 256 / 1024 / 16 384 and the i.i.d.-uniform alignment (SURVEY.md 8d "U")
   anneal        best-length-vs-wallclock of the batched SA host
 
 For N > 1 every rank is an independent restart (own seed, own start tree, own candidates) on its own GPU; the
@@ -79,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
     ap.add_argument("--anneal-chains", type=int, default=32, help="independent chains stepped together on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 and uniform-alignment legs")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 / 16 384 and uniform-alignment legs")
     ap.add_argument("--headline-only", action="store_true",
                     help="the timed region and its roofline only (profiling runs: every scoring walk of the process is "
                          "then one of the headline's device-built batches)")
@@ -331,6 +331,74 @@ def cpu_reference_on_tree(rows, kind: int, budget_s: float, tree_arrays, expect_
     return out
 
 
+def cpu_reference_anneal(rows, seconds: float, seed: int, gpu_log):
+    """The second half of the metric for LVB's own CPU path: the reference PROGRAM (oracle/_ref/lvb_ref, the reference
+    compiled here, its default schedule and all the threads it takes) annealing the same alignment for a bounded time.
+    Its progress log has one line per 50 000 rearrangements (LVB.h:98), too coarse for a sample of seconds, so its
+    per-rearrangement record (-v: changeAccepted.tsv, Solve.c:467) is polled instead: (wall clock, rearrangements,
+    current length).  `gpu_seconds_to_same_length` = when the GPU chains' best length first got as low as the
+    reference's after its whole sample."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = ROOT / "oracle" / "_ref" / "lvb_ref"
+    if not exe.exists() or seconds <= 0:
+        return None
+    td = Path(tempfile.mkdtemp(prefix="lvbref_sa_"))
+    try:
+        with open(td / "infile", "w") as f:
+            f.write(f"{len(rows)} {len(rows[0])}\n")
+            for i, r in enumerate(rows):
+                f.write(f"t{i:<9d}{r.decode()}\n")
+        t0 = time.perf_counter()
+        with open(td / "stdout.txt", "w") as so:
+            p = subprocess.Popen([str(exe), "-v", "-i", "infile", "-s", str(seed)], cwd=td, stdout=so, stderr=subprocess.STDOUT)
+        curve, rec = [], td / "changeAccepted.tsv"
+
+        def last_record():
+            try:
+                with open(rec, "rb") as f:
+                    f.seek(0, 2)
+                    f.seek(max(0, f.tell() - 4096))
+                    lines = [ln for ln in f.read().split(b"\n")[1:-1] if ln.count(b"\t") == 5]  # whole lines only
+                it, _, _, length, _, _ = lines[-1].split(b"\t")
+                return int(it), int(length)
+            except (OSError, IndexError, ValueError):
+                return None
+        try:
+            while p.poll() is None and time.perf_counter() - t0 < seconds:
+                time.sleep(0.5)
+                got = last_record()
+                if got and (not curve or got[0] != curve[-1][1]):
+                    curve.append([round(time.perf_counter() - t0, 2), got[0], got[1]])
+        finally:
+            if p.poll() is None:
+                p.terminate()
+                try:
+                    p.wait(5)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        took = time.perf_counter() - t0
+        threads = None
+        for ln in open(td / "stdout.txt", errors="replace"):
+            if "PThreads:" in ln:
+                threads = int(ln.split(":")[1])
+        if not curve:
+            return {"kind": "reference", "seconds": round(took, 2), "threads": threads, "note": "no rearrangement recorded in the sample"}
+        out = {
+            "kind": "reference", "program": "oracle/_ref/lvb_ref -v -i infile -s %d (defaults: SEQ-TNS, geometric cooling)" % seed,
+            "seconds": round(took, 2), "threads": threads, "rearrangements": curve[-1][1], "length": curve[-1][2],
+            "rearrangements_per_s": round(curve[-1][1] / max(curve[-1][0], 1e-9), 1),
+            "length_vs_wallclock": curve[:: max(1, len(curve) // 8)] + curve[-1:],
+        }
+        hit = next((t for t, b in gpu_log if b <= curve[-1][2]), None)
+        out["gpu_seconds_to_same_length"] = None if hit is None else round(hit, 4)
+        return out
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def cpu_all_cores(kind: int, seconds: float, tree_arrays, taxa_sites_seed):
     """One reference process per host core at the same time (the reference is non-reentrant), each
     scoring random neighbours of the same tree."""
@@ -508,10 +576,11 @@ def rank_main(args) -> None:
     extras = rank == 0 and world == 1 and not args.headline_only
     if extras and not args.no_shapes:
         shapes = {}
-        for b in (256, 1024):
-            r = submit_to_lengths(ctx, ranks, b, kind, steps_side, 5, 5000)
-            shapes[f"B{b}"] = {"value": r["scored_per_step"] * steps_side / r["elapsed_s"], "unit": "trees/s",
-                               "ms_per_step": 1e3 * r["elapsed_s"] / steps_side, "walk_ms": r["launch_ms"],
+        for b in (256, 1024, 16384):
+            r = submit_to_lengths(ctx, ranks, b, kind, steps_side if b <= 4096 else max(20, steps_side // 2), 5, 5000)
+            nst = steps_side if b <= 4096 else max(20, steps_side // 2)
+            shapes[f"B{b}"] = {"value": r["scored_per_step"] * nst / r["elapsed_s"], "unit": "trees/s",
+                               "ms_per_step": 1e3 * r["elapsed_s"] / nst, "walk_ms": r["launch_ms"],
                                "mean_dirty_nodes": round(r["mean_dirty"], 2)}
         if args.dist == "tree":
             # SURVEY.md 8(d) "U": i.i.d. uniform cells (almost every combine is a union), same start tree
@@ -563,6 +632,7 @@ def rank_main(args) -> None:
         actx = api.FitchContext(text_rows=rows, device=ranks.device)
         atrees = [host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100 + c) for c in range(R)]
         res, log = host.anneal_chains(actx, atrees, [params_for(c) for c in range(R)])
+        anneal_log = list(log)
         keep = log[:: max(1, len(log) // 12)] + log[-1:]
         secs = max(r["seconds"] for r in res)
         tot = lambda k: sum(r[k] for r in res)
@@ -597,6 +667,9 @@ def rank_main(args) -> None:
         cb = cpu_reference_on_tree(rows, kind, args.cpu_seconds, fresh_arrays, length,
                                    (args.taxa, args.sites, args.seed, args.dist))
         out["cpu_baseline"] = cb if cb is not None else cpu_port_baseline(rows, kind, args.cpu_seconds, tree)
+
+    if extras and not args.no_cpu_baseline and args.dist == "tree" and "anneal" in out:
+        out["anneal"]["reference_cpu"] = cpu_reference_anneal(rows, min(2.5 * args.cpu_seconds, 30.0), args.seed, anneal_log)
 
     if extras and not args.no_cpu_baseline and args.dist == "tree" and "mixed_walk" in out:
         out["mixed_walk"]["cpu_baseline"] = cpu_reference_on_tree(rows, kind, args.cpu_seconds, mixed_arrays, mixed_len,
