@@ -352,7 +352,10 @@ def cpu_reference_anneal(rows, seconds: float, seed: int, gpu_log):
                 f.write(f"t{i:<9d}{r.decode()}\n")
         t0 = time.perf_counter()
         with open(td / "stdout.txt", "w") as so:
-            p = subprocess.Popen([str(exe), "-v", "-i", "infile", "-s", str(seed)], cwd=td, stdout=so, stderr=subprocess.STDOUT)
+            # -p 4: left to itself the program starts one thread per hardware thread of the HOST (256 on the GPU box, of
+            # which the job may use a few) and does 97 rearrangements/s; 1, 2, 4 threads give 290-330/s
+            p = subprocess.Popen([str(exe), "-v", "-i", "infile", "-s", str(seed), "-p", "4"], cwd=td, stdout=so,
+                                 stderr=subprocess.STDOUT)
         curve, rec = [], td / "changeAccepted.tsv"
 
         def last_record():
@@ -387,7 +390,7 @@ def cpu_reference_anneal(rows, seconds: float, seed: int, gpu_log):
         if not curve:
             return {"kind": "reference", "seconds": round(took, 2), "threads": threads, "note": "no rearrangement recorded in the sample"}
         out = {
-            "kind": "reference", "program": "oracle/_ref/lvb_ref -v -i infile -s %d (defaults: SEQ-TNS, geometric cooling)" % seed,
+            "kind": "reference", "program": "oracle/_ref/lvb_ref -v -i infile -s %d -p 4 (defaults otherwise: SEQ-TNS, geometric cooling)" % seed,
             "seconds": round(took, 2), "threads": threads, "rearrangements": curve[-1][1], "length": curve[-1][2],
             "rearrangements_per_s": round(curve[-1][1] / max(curve[-1][0], 1e-9), 1),
             "length_vs_wallclock": curve[:: max(1, len(curve) // 8)] + curve[-1:],
