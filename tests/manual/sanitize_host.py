@@ -41,3 +41,36 @@ for f, fmt in (("stock_100x1000.fas", "fasta"), ("stock_100x1000.nex", "nexus"),
     except ValueError as exc:
         print(f, 'rejected:', str(exc).splitlines()[0])
 print('readers ok')
+# the readers on damaged input: every format's stock file with random bytes changed, lines dropped, doubled or cut,
+# and the file truncated - the parser may refuse (ValueError) but must not read or write out of bounds
+import random, tempfile, os
+rnd = random.Random(5)
+tried = refused = 0
+with tempfile.TemporaryDirectory() as td:
+    for f, fmt in (("stock_100x1000.fas", "fasta"), ("stock_100x1000.nex", "nexus"), ("stock_100x1000.aln", "clustal"),
+                   ("lib_phylip_interleaved.phy", "phylip")):
+        data = (GOLD / 'ref_tests' / f).read_bytes()
+        for k in range(150):
+            b = bytearray(data)
+            how = k % 5
+            if how == 0:
+                for _ in range(rnd.randint(1, 30)):
+                    b[rnd.randrange(len(b))] = rnd.choice(b"ACGT-?N;:>#\n\t 0123456789[]'\"=()")
+            elif how == 1:
+                b = b[:rnd.randrange(1, len(b))]
+            else:
+                lines = bytes(b).split(b"\n")
+                i = rnd.randrange(len(lines))
+                if how == 2: del lines[i]
+                elif how == 3: lines.insert(i, lines[i])
+                else: lines[i] = lines[i][:rnd.randrange(0, len(lines[i]) + 1)]
+                b = bytearray(b"\n".join(lines))
+            path = os.path.join(td, "damaged")
+            with open(path, "wb") as fh: fh.write(bytes(b))
+            tried += 1
+            try:
+                names, rows = host.read_alignment(path, fmt, lib)
+                assert len({len(r) for r in rows}) == 1 and len(names) == len(rows)
+            except ValueError:
+                refused += 1
+print(f'damaged files: {tried} tried, {refused} refused, none crashed')
