@@ -369,9 +369,9 @@ def reference_search(ctx_handle, params: RefSearchParams, lib=None) -> tuple[dic
     return {k: getattr(res, k) for k, _ in RefSearchResult._fields_}, HostTree(handle=h, lib=lib)
 
 
-def anneal_defaults() -> AnnealParams:
+def anneal_defaults(lib=None) -> AnnealParams:
     p = AnnealParams()
-    load_library().lvbhost_anneal_defaults(C.byref(p))
+    (lib or load_library()).lvbhost_anneal_defaults(C.byref(p))
     return p
 
 
@@ -388,9 +388,10 @@ def anneal(ctx: api.FitchContext, tree: HostTree, params: AnnealParams):
     return out, log
 
 
-def anneal_chains(ctx: api.FitchContext, trees: list[HostTree], params: list[AnnealParams]):
-    """R chains stepped together on one GPU -> ([result dict per chain], [(seconds, best over all chains), ...])."""
-    lib = load_library()
+def anneal_chains(ctx, trees: list[HostTree], params: list[AnnealParams], lib=None):
+    """R chains stepped together on one GPU -> ([result dict per chain], [(seconds, best over all chains), ...]).
+    ctx: an api.FitchContext (or, with `lib`, the raw handle of whatever that library's lvbgpu_* calls expect)."""
+    lib = lib or load_library()
     R = len(trees)
     cap = max(int(params[0].log_cap), 0)
     secs = np.zeros(max(cap, 1), dtype=np.float64)
@@ -399,7 +400,12 @@ def anneal_chains(ctx: api.FitchContext, trees: list[HostTree], params: list[Ann
     pars = (AnnealParams * R)(*params)
     res = (AnnealResult * R)()
     nlog = C.c_int32()
-    ctx._chk(lib.lvbhost_anneal_chains(ctx.h, R, handles, pars, res, secs.ctypes.data, best.ctypes.data, C.byref(nlog)))
+    rc = lib.lvbhost_anneal_chains(getattr(ctx, "h", ctx), R, handles, pars, res, secs.ctypes.data, best.ctypes.data,
+                                   C.byref(nlog))
+    if hasattr(ctx, "_chk"):
+        ctx._chk(rc)
+    elif rc != 0:
+        raise api.LvbGpuError(rc, "lvbhost_anneal_chains")
     out = [{k: getattr(res[c], k) for k, _ in AnnealResult._fields_} for c in range(R)]
     return out, [(float(secs[i]), int(best[i])) for i in range(nlog.value)]
 

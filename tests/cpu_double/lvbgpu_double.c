@@ -40,10 +40,14 @@ lvbgpu_ctx *lvbgpu_double_new(long n, long nwords, const uint64_t *enc)
     return c;
 }
 
+static void chains_follow_selected(lvbgpu_ctx *c); /* the selected chain's tree changed through a single-tree call */
+static void chains_release(lvbgpu_ctx *c);
+
 void lvbgpu_double_free(lvbgpu_ctx *c)
 {
     if (!c)
         return;
+    chains_release(c);
     free(c->enc);
     free(c->cur);
     free(c->cand);
@@ -73,6 +77,7 @@ int lvbgpu_set_tree(lvbgpu_ctx *c, const int32_t *left, const int32_t *right, in
     c->root = root;
     c->cur_len = lvbo_getplen(c->cur, c->n, c->nb, c->nwords, c->root, c->todo);
     c->have_tree = 1;
+    chains_follow_selected(c);
     if (length_out)
         *length_out = c->cur_len;
     return LVBGPU_OK;
@@ -126,6 +131,7 @@ int lvbgpu_commit(lvbgpu_ctx *c, int32_t n_edits, const lvbgpu_edit *edits, int3
     long new_root = root >= 0 ? root : c->root;
     c->cur_len = apply_and_score(c, c->cur, n_edits, edits, &new_root);
     c->root = new_root;
+    chains_follow_selected(c);
     if (length_out)
         *length_out = c->cur_len;
     return LVBGPU_OK;
@@ -157,49 +163,371 @@ int lvbgpu_allreduce_min(lvbgpu_ctx *c, int64_t *v, int32_t *r)
     (void)c, (void)v, (void)r;
     return LVBGPU_E_NODEVICE;
 }
-/* several chains per context: device-only as well */
+/* ---- several chains per context -------------------------------------------------------------------------------
+ * The double keeps R trees and draws the neighbours ITSELF, with the host library's own move generators on a mirror
+ * topology per chain (lvbhost_propose after lvbhost_tree_reseed(hash(seed, j)): candidate j of a draw is a function
+ * of (seed, j) and of the chain's tree, as the C-ABI promises - not the moves the device would draw, which the host
+ * loop must not depend on anyway).  Enough for lvbhost_anneal_chains to run on the CPU: its state machines, the
+ * "a chain's trajectory does not depend on R" property, and the sanitizers. */
+#include "../../include/lvbhost.h"
+#include <stdio.h>
+
+#define DBL_MAX_CHAINS 64
+
+typedef struct
+{
+    lvbo_node *cur;
+    long root;
+    int64_t cur_len;
+    int have_tree;
+    lvbhost_tree *mirror;
+    uint64_t version;
+} dbl_chain;
+
+typedef struct
+{
+    int32_t k;                                    /* segments */
+    int32_t chain[DBL_MAX_CHAINS], start[DBL_MAX_CHAINS], count[DBL_MAX_CHAINS];
+    uint64_t version[DBL_MAX_CHAINS];
+    int32_t total;
+    int32_t *off;                                 /* [total + 1] into edits */
+    lvbgpu_edit *edits;
+    size_t edits_cap, off_cap;
+    int64_t *len;
+    int in_flight;
+} dbl_slot;
+
+static struct
+{
+    lvbgpu_ctx *owner;                            /* one multi-chain context at a time is all the tests need */
+    int32_t R, sel;
+    dbl_chain ch[DBL_MAX_CHAINS];
+    dbl_slot slot[2];
+    int last_slot;
+    int32_t npicked;
+    int32_t picked_off[DBL_MAX_CHAINS + 1];
+    lvbgpu_edit *picked;
+    size_t picked_cap;
+    uint64_t versions;
+} G;
+
+static void store_selected(lvbgpu_ctx *c)
+{
+    if (G.owner != c)
+        return;
+    dbl_chain *h = &G.ch[G.sel];
+    h->cur = c->cur;
+    h->root = c->root;
+    h->cur_len = c->cur_len;
+    h->have_tree = c->have_tree;
+}
+
+static void load_selected(lvbgpu_ctx *c)
+{
+    dbl_chain *h = &G.ch[G.sel];
+    c->cur = h->cur;
+    c->root = h->root;
+    c->cur_len = h->cur_len;
+    c->have_tree = h->have_tree;
+}
+
+static void mirror_of_selected(lvbgpu_ctx *c)
+{
+    /* (re)build the selected chain's mirror topology from its node records */
+    dbl_chain *h = &G.ch[G.sel];
+    int32_t *l = (int32_t *)malloc((size_t)c->nb * 4), *r = (int32_t *)malloc((size_t)c->nb * 4);
+    for (long i = 0; i < c->nb; i++)
+    {
+        l[i] = c->cur[i].left >= 0 ? (int32_t)c->cur[i].left : -1;
+        r[i] = c->cur[i].right >= 0 ? (int32_t)c->cur[i].right : -1;
+    }
+    if (h->mirror)
+        lvbhost_tree_free(h->mirror);
+    h->mirror = lvbhost_tree_from_arrays((int32_t)c->n, l, r, (int32_t)c->root, 1);
+    h->version = ++G.versions;
+    free(l);
+    free(r);
+}
+
+static void chains_follow_selected(lvbgpu_ctx *c)
+{
+    if (G.owner != c)
+        return;
+    store_selected(c);
+    mirror_of_selected(c);
+}
+
+void lvbgpu_double_chains_reset(void);
+static void chains_release(lvbgpu_ctx *c)
+{
+    if (G.owner == c)
+        lvbgpu_double_chains_reset();
+}
+
+void lvbgpu_double_chains_reset(void)
+{
+    if (!G.owner)
+        return;
+    lvbgpu_ctx *c = G.owner;
+    store_selected(c);
+    for (int32_t i = 0; i < G.R; i++)
+    {
+        if (i != 0)
+            free(G.ch[i].cur);
+        if (G.ch[i].mirror)
+            lvbhost_tree_free(G.ch[i].mirror);
+    }
+    /* chain 0's tree block is the context's own again */
+    c->cur = G.ch[0].cur;
+    c->root = G.ch[0].root;
+    c->cur_len = G.ch[0].cur_len;
+    c->have_tree = G.ch[0].have_tree;
+    for (int s = 0; s < 2; s++)
+    {
+        free(G.slot[s].off);
+        free(G.slot[s].edits);
+        free(G.slot[s].len);
+    }
+    free(G.picked);
+    memset(&G, 0, sizeof(G));
+}
+
 int lvbgpu_set_chains(lvbgpu_ctx *c, int32_t r)
 {
-    (void)c, (void)r;
-    return LVBGPU_E_NODEVICE;
+    if (!c || r < 1 || r > DBL_MAX_CHAINS)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    if (G.owner)
+        lvbgpu_double_chains_reset();
+    G.owner = c;
+    G.R = r;
+    G.sel = 0;
+    G.ch[0].cur = c->cur;
+    G.ch[0].root = c->root;
+    G.ch[0].cur_len = c->cur_len;
+    G.ch[0].have_tree = c->have_tree;
+    if (c->have_tree)
+        mirror_of_selected(c);
+    for (int32_t i = 1; i < r; i++)
+        G.ch[i].cur = lvbo_treealloc(c->nb, c->nwords);
+    return LVBGPU_OK;
 }
+
 int lvbgpu_select_chain(lvbgpu_ctx *c, int32_t k)
 {
-    (void)c;
-    return k == 0 ? LVBGPU_OK : LVBGPU_E_NODEVICE;
+    if (G.owner != c)
+        return k == 0 ? LVBGPU_OK : LVBGPU_E_ARG;
+    if (k < 0 || k >= G.R)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    store_selected(c);
+    G.sel = k;
+    load_selected(c);
+    return LVBGPU_OK;
 }
-int32_t lvbgpu_chains(const lvbgpu_ctx *c)
+
+int32_t lvbgpu_chains(const lvbgpu_ctx *c) { return G.owner == c ? G.R : 1; }
+
+/* a context that never asked for chains has one (lvbgpu_chains() == 1): the chain calls work on it all the same */
+static void adopt(lvbgpu_ctx *c)
 {
-    (void)c;
-    return 1;
+    if (c && G.owner != c)
+        lvbgpu_set_chains(c, 1);
 }
-int lvbgpu_chains_propose_score(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_draw *d, int64_t *l)
+
+static uint64_t mix64(uint64_t x)
 {
-    (void)c, (void)k, (void)d, (void)l;
-    return LVBGPU_E_NODEVICE;
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
 }
-int lvbgpu_chains_commit(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_pick *p)
-{
-    (void)c, (void)k, (void)p;
-    return LVBGPU_E_NODEVICE;
-}
-int lvbgpu_chains_picked_edits(lvbgpu_ctx *c, int32_t j, lvbgpu_edit *e, int32_t cap, int32_t *n)
-{
-    (void)c, (void)j, (void)e, (void)cap, (void)n;
-    return LVBGPU_E_NODEVICE;
-}
+
 int lvbgpu_chains_submit(lvbgpu_ctx *c, int32_t s, int32_t k, const lvbgpu_chain_draw *d)
 {
-    (void)c, (void)s, (void)k, (void)d;
-    return LVBGPU_E_NODEVICE;
+    adopt(c);
+    if (G.owner != c || s < 0 || s > 1 || k < 1 || k > G.R || !d)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    store_selected(c);
+    dbl_slot *sl = &G.slot[s];
+    if (sl->in_flight)
+        return LVBGPU_E_STATE;
+    int32_t total = 0;
+    for (int32_t i = 0; i < k; i++)
+    {
+        if (d[i].chain < 0 || d[i].chain >= G.R || d[i].count < 1 || !G.ch[d[i].chain].have_tree)
+            return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+        for (int32_t j = 0; j < i; j++)
+            if (d[j].chain == d[i].chain)
+                return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+        total += d[i].count;
+    }
+    if ((size_t)total + 1 > sl->off_cap)
+    {
+        sl->off_cap = (size_t)total + 1;
+        sl->off = (int32_t *)realloc(sl->off, sl->off_cap * 4);
+        sl->len = (int64_t *)realloc(sl->len, sl->off_cap * 8);
+    }
+    sl->k = k;
+    sl->total = total;
+    const int32_t cap = (int32_t)(2 * c->nb + 8);
+    lvbgpu_edit *tmp = (lvbgpu_edit *)malloc((size_t)cap * sizeof(lvbgpu_edit));
+    int32_t at = 0;
+    size_t ne_total = 0;
+    sl->off[0] = 0;
+    for (int32_t i = 0; i < k; i++)
+    {
+        dbl_chain *h = &G.ch[d[i].chain];
+        sl->chain[i] = d[i].chain;
+        sl->start[i] = at;
+        sl->count[i] = d[i].count;
+        sl->version[i] = h->version;
+        for (int32_t j = 0; j < d[i].count; j++, at++)
+        {
+            const uint64_t r = mix64(d[i].seed ^ mix64((uint64_t)j + 1));
+            int kind = d[i].kind;
+            if (kind == -1)
+                kind = j % 3;
+            else if (kind == -2)
+                kind = ((d[i].mix_a + (uint32_t)j) & 1u) ? 1 : 0;
+            else if (kind == -3)
+            {
+                const uint32_t u = (uint32_t)(r >> 32);
+                kind = u < d[i].mix_a ? 0 : (u < d[i].mix_b ? 1 : 2);
+            }
+            lvbhost_tree_reseed(h->mirror, r | 1u);
+            const int ne = lvbhost_propose(h->mirror, kind, tmp, cap);
+            if (ne < 0)
+            {
+                free(tmp);
+                return ne;
+            }
+            if (ne_total + (size_t)ne > sl->edits_cap)
+            {
+                sl->edits_cap = 2 * (ne_total + (size_t)ne) + 64;
+                sl->edits = (lvbgpu_edit *)realloc(sl->edits, sl->edits_cap * sizeof(lvbgpu_edit));
+            }
+            memcpy(sl->edits + ne_total, tmp, (size_t)ne * sizeof(lvbgpu_edit));
+            ne_total += (size_t)ne;
+            sl->off[at + 1] = (int32_t)ne_total;
+            /* score it against the chain's tree */
+            lvbo_treecopy(c->cand, h->cur, c->nb, c->nwords);
+            long root = h->root;
+            const long keep_root = c->root;
+            c->root = h->root; /* apply_and_score compares against the context's root */
+            sl->len[at] = apply_and_score(c, c->cand, ne, tmp, &root);
+            c->root = keep_root;
+        }
+    }
+    free(tmp);
+    sl->in_flight = 1;
+    return LVBGPU_OK;
 }
+
 int lvbgpu_chains_collect(lvbgpu_ctx *c, int32_t s, int64_t *l)
 {
-    (void)c, (void)s, (void)l;
-    return LVBGPU_E_NODEVICE;
+    if (G.owner != c || s < 0 || s > 1 || !l)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    dbl_slot *sl = &G.slot[s];
+    if (!sl->in_flight)
+        return LVBGPU_E_STATE;
+    memcpy(l, sl->len, (size_t)sl->total * 8);
+    sl->in_flight = 0;
+    G.last_slot = s;
+    return LVBGPU_OK;
 }
+
+int lvbgpu_chains_propose_score(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_draw *d, int64_t *l)
+{
+    const int rc = lvbgpu_chains_submit(c, 0, k, d);
+    return rc != LVBGPU_OK ? rc : lvbgpu_chains_collect(c, 0, l);
+}
+
+/* edits (+ a new root) on chain h's tree and on its mirror */
+static int commit_on_chain(lvbgpu_ctx *c, dbl_chain *h, int32_t ne, const lvbgpu_edit *e, long new_root, int64_t expect)
+{
+    const long keep_root = c->root;
+    c->root = h->root;
+    long root = new_root >= 0 ? new_root : h->root;
+    h->cur_len = apply_and_score(c, h->cur, ne, e, &root);
+    c->root = keep_root;
+    h->root = root;
+    h->version = ++G.versions;
+    if (expect >= 0 && h->cur_len != expect)
+        return LVBGPU_E_STATE; /* a candidate's committed length is its scored length */
+    return lvbhost_tree_apply(h->mirror, e, ne, (int32_t)new_root);
+}
+
+int lvbgpu_chains_commit(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_pick *p)
+{
+    adopt(c);
+    if (G.owner != c || k < 1 || k > G.R || !p)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    store_selected(c);
+    dbl_slot *sl = &G.slot[G.last_slot];
+    G.npicked = 0;
+    G.picked_off[0] = 0;
+    for (int32_t j = 0; j < k; j++)
+    {
+        int32_t seg = -1;
+        for (int32_t i = 0; i < sl->k; i++)
+            if (sl->chain[i] == p[j].chain)
+                seg = i;
+        if (seg < 0 || p[j].b < 0 || p[j].b >= sl->count[seg])
+            return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+        dbl_chain *h = &G.ch[p[j].chain];
+        if (h->version != sl->version[seg])
+            return LVBGPU_E_STATE; /* the chain's tree changed since these candidates were drawn */
+        const int32_t at = sl->start[seg] + p[j].b, ne = sl->off[at + 1] - sl->off[at];
+        const size_t need = (size_t)G.picked_off[j] + (size_t)ne;
+        if (need > G.picked_cap)
+        {
+            G.picked_cap = 2 * need + 64;
+            G.picked = (lvbgpu_edit *)realloc(G.picked, G.picked_cap * sizeof(lvbgpu_edit));
+        }
+        memcpy(G.picked + G.picked_off[j], sl->edits + sl->off[at], (size_t)ne * sizeof(lvbgpu_edit));
+        G.picked_off[j + 1] = G.picked_off[j] + ne;
+        G.npicked = j + 1;
+        const int rc = commit_on_chain(c, h, ne, sl->edits + sl->off[at], -1, sl->len[at]);
+        if (rc != LVBGPU_OK)
+            return rc;
+    }
+    load_selected(c);
+    return LVBGPU_OK;
+}
+
+int lvbgpu_chains_picked_edits(lvbgpu_ctx *c, int32_t j, lvbgpu_edit *e, int32_t cap, int32_t *n)
+{
+    if (G.owner != c || j < 0 || j >= G.npicked || !e || !n)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    const int32_t ne = G.picked_off[j + 1] - G.picked_off[j];
+    if (ne > cap)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    memcpy(e, G.picked + G.picked_off[j], (size_t)ne * sizeof(lvbgpu_edit));
+    *n = ne;
+    return LVBGPU_OK;
+}
+
 int lvbgpu_chains_reroot(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_root *r)
 {
-    (void)c, (void)k, (void)r;
-    return LVBGPU_E_NODEVICE;
+    adopt(c);
+    if (G.owner != c || k < 1 || k > G.R || !r)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
+    store_selected(c);
+    const int32_t cap = (int32_t)(2 * c->nb + 8);
+    lvbgpu_edit *tmp = (lvbgpu_edit *)malloc((size_t)cap * sizeof(lvbgpu_edit));
+    int rc = LVBGPU_OK;
+    for (int32_t j = 0; j < k && rc == LVBGPU_OK; j++)
+    {
+        if (r[j].chain < 0 || r[j].chain >= G.R || r[j].new_root < 0 || r[j].new_root >= c->n)
+        {
+            rc = LVBGPU_E_ARG;
+            break;
+        }
+        dbl_chain *h = &G.ch[r[j].chain];
+        const int64_t before = h->cur_len;
+        const int ne = lvbhost_reroot_edits(h->mirror, r[j].new_root, tmp, cap);
+        rc = ne < 0 ? ne : commit_on_chain(c, h, ne, tmp, r[j].new_root, before); /* a re-root keeps the length */
+    }
+    free(tmp);
+    load_selected(c);
+    return rc;
 }
