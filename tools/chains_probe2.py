@@ -1,3 +1,5 @@
+"""anneal_chains at 500 x 50k: R chains for a given time, the chains that did not freeze (and the first two) in detail.
+Usage: chains_probe2.py R seconds"""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
