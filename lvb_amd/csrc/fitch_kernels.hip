@@ -122,6 +122,16 @@ __device__ __forceinline__ uint32_t wave_sum_bits(uint32_t v, uint32_t nbits)
     return total;
 }
 
+// What the waves of a launch hand one another (partial lengths, partial change counts, arrival ticks) is written by
+// agent-scope atomics and read by agent-scope atomic loads: those are performed where all XCDs see them, so the
+// hand-over needs ORDER only - this wave's atomics acknowledged before its tick is sent - and no cache written back or
+// invalidated.  __threadfence() does both (buffer_wbl2 of the XCD's whole L2 + buffer_inv): 3.5 us per wave on an idle
+// chip, 6.5 with freshly written rows in the L2 (MI355X_MICROARCH.md), on every wave of a commit.
+__device__ __forceinline__ void atomics_acknowledged()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // The walk.  COMMIT: store every produced node set to rows_out[dst] and add its change count to
 // changes_out[dst] (accepting a candidate / full evaluation / strict-compat write-back).
@@ -536,12 +546,12 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             unsigned long long *const tmp = a.tmp_changes + (size_t)cand * a.tmp_stride;
             if (lane == 0)
             {
-                __threadfence(); // our partial counts before our tick
+                atomics_acknowledged(); // our partial counts before our tick
                 last = atomicAdd(a.done_count + cand, 1u) == a.ngroups - 1u ? 1u : 0u;
             }
             if (__builtin_amdgcn_readfirstlane(last))
             {
-                __threadfence();
+                // (the tick has returned: every other wave's counts were acknowledged before its own tick was sent)
                 long long delta = 0;               // new - old over the recomputed internal nodes
                 unsigned long long root_changes = 0; // the two root combines (dst < 0)
                 for (uint32_t i = lane; i < cd.ncomb; i += 64u)
@@ -580,12 +590,12 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             uint32_t last = 0;
             if (lane == 0)
             {
-                __threadfence(); // our sum before our count
+                atomics_acknowledged(); // our sum before our count
                 last = atomicAdd(a.done_count, 1u) == a.nitems - 1u ? 1u : 0u;
             }
             if (__builtin_amdgcn_readfirstlane(last))
             {
-                __threadfence(); // every wave's sum before our reads
+                // (every other wave's sum was acknowledged before its count was sent, and ours has returned)
                 for (uint32_t i = lane; i < a.B; i += 64u)
                 {
                     const unsigned long long v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
