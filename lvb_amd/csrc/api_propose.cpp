@@ -582,10 +582,11 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     }
     uint32_t *done = (uint32_t *)ctx->d_done.p;
     // 1. what the host needs to follow the moves (so that it can work while the walk runs)
-    //    (on the side stream: descriptors and rewrites are complete - the batch's lengths have been read - and nothing
-    //    here touches state sets, so it runs beside the commit walk)
+    //    (on a stream of its own: descriptors and rewrites are complete - the batch's lengths have been read - and
+    //    nothing here touches state sets, so it runs beside the commit walk AND beside the table rebuild below; behind
+    //    one another on the side stream they were 7 + 23 us, longer than the commit walk they hide behind)
     HIPCHK(ctx, launch_gather_picks(h_picks, (uint32_t)k, (const ProposalInfo *)ps.d_pinfo.p, (const lvbgpu_edit_dev *)ps.d_pedits.p,
-                                    ctx->p_stride_e, h + o_out, out_stride, flag, seq, done + MAX_CHAINS, ctx->side_stream));
+                                    ctx->p_stride_e, h + o_out, out_stride, flag, seq, done + MAX_CHAINS, ctx->copy_stream));
     // 1b. the generator's tables of the picked chains follow their moves on the device (they describe the trees the
     //     candidates were drawn from: the picks were checked against the chains' versions above)
     bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES;
@@ -634,9 +635,9 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
             break;
         if ((spins & 1023u) == 0)
         {
-            const hipError_t q = hipStreamQuery(ctx->side_stream);
+            const hipError_t q = hipStreamQuery(ctx->copy_stream);
             if (q == hipSuccess)
-                break; // everything the kernels wrote is visible
+                break; // everything the kernel wrote is visible
             if (q != hipErrorNotReady)
                 return ctx->fail_hip(q, "lvbgpu_chains_commit: waiting for the picked moves");
         }
