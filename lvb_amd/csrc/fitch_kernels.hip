@@ -126,7 +126,9 @@ __device__ __forceinline__ uint32_t wave_sum_bits(uint32_t v, uint32_t nbits)
 // agent-scope atomics and read by agent-scope atomic loads: those are performed where all XCDs see them, so the
 // hand-over needs ORDER only - this wave's atomics acknowledged before its tick is sent - and no cache written back or
 // invalidated.  __threadfence() does both (buffer_wbl2 of the XCD's whole L2 + buffer_inv): 3.5 us per wave on an idle
-// chip, 6.5 with freshly written rows in the L2 (MI355X_MICROARCH.md), on every wave of a commit.
+// chip, 6.5 with freshly written rows in the L2 (MI355X_MICROARCH.md), on every wave of a commit.  The same holds for
+// what goes to the HOST before a flag (lengths, picked moves): written with system-scope atomic stores, which are
+// written through - once acknowledged they are in no cache of this chip, and the flag is sent after that.
 __device__ __forceinline__ void atomics_acknowledged()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -523,12 +525,12 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             if (lane == 0)
             {
                 __hip_atomic_store(a.host_len + cand, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __threadfence_system();
+                atomics_acknowledged(); // (a system-scope store is written through: acknowledged = out of every cache)
                 if (atomicAdd(a.done_count, 1u) == a.nitems - 1u)
                 {
                     __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __threadfence_system();
-                    __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    atomics_acknowledged();
+                    __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
             return; // (ITEMS == 1 always here)
@@ -604,9 +606,9 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                 }
                 if (lane == 0)
                     __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence_system(); // the wave's stores (all lanes) before the flag
+                atomics_acknowledged(); // the wave's stores (all lanes: one counter per wave) before the flag
                 if (lane == 0)
-                    __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -625,19 +627,24 @@ __global__ __launch_bounds__(64) void gather_picks_kernel(const uint32_t *pick, 
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     const uint32_t g = pick[j];
     const ProposalInfo pi = info[g];
-    char *dst = out + (size_t)j * out_stride;
-    if (lane == 0)
-        *reinterpret_cast<ProposalInfo *>(dst) = pi;
-    const uint32_t ne = pi.overflow ? 0u : (uint32_t)pi.n_edits;
-    lvbgpu_edit_dev *ed = reinterpret_cast<lvbgpu_edit_dev *>(dst + sizeof(ProposalInfo));
-    for (uint32_t i = lane; i < ne && i < stride_e; i += 64u)
-        ed[i] = edits[(size_t)g * stride_e + i];
-    __threadfence_system();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)j * out_stride);
+    // word by word, as system-scope stores (written through to the host, see atomics_acknowledged)
+    constexpr uint32_t PI_WORDS = sizeof(ProposalInfo) / 4u;
+    static_assert(sizeof(ProposalInfo) % 4u == 0 && sizeof(lvbgpu_edit_dev) == 12, "records are copied word by word");
+    if (lane < PI_WORDS)
+        __hip_atomic_store(dst + lane, reinterpret_cast<const uint32_t *>(info + g)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t ne = pi.overflow ? 0u : (uint32_t)pi.n_edits;
+    if (ne > stride_e)
+        ne = stride_e;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(edits + (size_t)g * stride_e);
+    for (uint32_t i = lane; i < 3u * ne; i += 64u)
+        __hip_atomic_store(dst + PI_WORDS + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    atomics_acknowledged();
     if (lane == 0 && atomicAdd(arrived, 1u) == k - 1u)
     {
         __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();
-        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        atomics_acknowledged();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
