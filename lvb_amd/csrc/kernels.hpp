@@ -17,7 +17,13 @@ constexpr uint32_t WALK_THREADS = 64 * WALK_WAVES;
 constexpr uint32_t TILE_WORDS = 128;              // 64 lanes x 16 B = 128 reference words (2048 sites) per wave tile
 constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
 
-constexpr uint32_t TARGET_WAVES = 65536;          // aim for at least this many (group, candidate) waves per launch
+// One tile per wave until a launch has this many (tile, candidate) waves; only beyond it are tiles grouped (up to
+// MAX_TILES_PER_WAVE per wave).  A wave that walks several tiles puts as many column slices into its XCD's L2 at the
+// same time as it has tiles (the waves of an XCD are at different tiles of their groups): with 5 tiles per wave the
+// slices of 500 x 50k (1 MB each) no longer fit the 4 MB L2 - 2.3 GB of L2 misses per launch instead of 33 MB
+// (tools/l2_probe5.hip), B = 65 536: 1452 -> 1216 us per launch, 2000 x 200k at B = 4096: 621 -> 460 us.  Round 1 aimed
+// for 65 536 waves.
+constexpr uint32_t TARGET_WAVES = 1u << 22;
 constexpr uint32_t MAX_TILES_PER_WAVE = 8;
 constexpr uint32_t PAIR_MIN_ITEMS = 32768;
 constexpr uint64_t FLIP_MIN_BYTES = 64ull << 20;  // tree blocks beyond this alternate the direction of scoring launches        // scoring launches of at least this many items walk two items per wave

@@ -278,12 +278,13 @@ def test_wide_offsets_and_copy_path_steps_match_reference(api):
     the same parity cases run once more in ONE child process with it set.  The same child turns direct steps
     and fused commits off (LVBGPU_DIRECT_STEPS=0): the copy / zeroing-launch forms of a step and of a commit
     stay covered as well, and makes the commit walk write its produced sets out in bursts of 3 (LVBGPU_DEFER_SLOTS)
-    instead of 32, so bursts end in the middle of chains."""
+    instead of 32, so bursts end in the middle of chains, and deals up to eight tiles to a wave (LVBGPU_TARGET_WAVES=40:
+    by default a launch below 4 M waves walks one tile per wave, so nothing else in the suite groups tiles)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LVBGPU_WIDE_OFFSETS="1", LVBGPU_DIRECT_STEPS="0", LVBGPU_DEFER_SLOTS="3")
+    env = dict(os.environ, LVBGPU_WIDE_OFFSETS="1", LVBGPU_DIRECT_STEPS="0", LVBGPU_DEFER_SLOTS="3", LVBGPU_TARGET_WAVES="40")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu",
                         "-q", "-x", "-k", "full_evaluation or incremental_batches or full_batch or golden_vectors",
                         "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
