@@ -24,7 +24,7 @@ def build() -> Path:
     objs = []
     for s in csrcs:
         o = OUT.parent / (s.stem + ".o")
-        subprocess.run(["gcc", "-O2", "-fPIC", "-std=c11", "-c", str(s), "-o", str(o)], check=True)
+        subprocess.run(["gcc", "-O2", "-fPIC", "-std=gnu11", "-c", str(s), "-o", str(o)], check=True)
         objs.append(str(o))
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", f"-I{ROOT / 'include'}",
                     *map(str, srcs), *objs, "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-o", str(OUT)], check=True)

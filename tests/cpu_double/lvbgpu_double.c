@@ -158,10 +158,68 @@ int lvbgpu_score_moves(lvbgpu_ctx *c, int32_t B, const lvbgpu_move *m, int64_t *
     (void)c, (void)B, (void)m, (void)l;
     return LVBGPU_E_NODEVICE;
 }
+/* The min-reduce over ranks, for multi-process tests of the lockstep searches: no RCCL on the CPU, so the ranks meet
+ * in a directory (LVBGPU_DOUBLE_COMM_DIR, with LVBGPU_DOUBLE_RANK / LVBGPU_DOUBLE_WORLD): call number k of rank r
+ * publishes its value as file "<k>_<r>" (written under another name, then renamed) and waits for the other ranks'
+ * files of the same call.  Ranks that make the same sequence of calls pair up; one that makes fewer leaves the others
+ * waiting until the timeout below - which is the failure such a test is after.  Without the variables: one rank. */
+#include <stdio.h>
+#include <time.h>
+#include <unistd.h>
 int lvbgpu_allreduce_min(lvbgpu_ctx *c, int64_t *v, int32_t *r)
 {
-    (void)c, (void)v, (void)r;
-    return LVBGPU_E_NODEVICE;
+    (void)c;
+    static long calls = 0;
+    const char *dir = getenv("LVBGPU_DOUBLE_COMM_DIR");
+    if (!dir)
+    {
+        if (r)
+            *r = 0;
+        return LVBGPU_OK;
+    }
+    const int rank = atoi(getenv("LVBGPU_DOUBLE_RANK")), world = atoi(getenv("LVBGPU_DOUBLE_WORLD"));
+    const long k = calls++;
+    char tmp[512], path[512];
+    snprintf(tmp, sizeof tmp, "%s/tmp_%ld_%d", dir, k, rank);
+    snprintf(path, sizeof path, "%s/%ld_%d", dir, k, rank);
+    FILE *f = fopen(tmp, "w");
+    if (!f)
+        return LVBGPU_E_COMM;
+    fprintf(f, "%lld\n", (long long)*v);
+    fclose(f);
+    if (rename(tmp, path) != 0)
+        return LVBGPU_E_COMM;
+    long long best = 0;
+    int who = -1;
+    const time_t deadline = time(NULL) + 60;
+    for (int j = 0; j < world; j++)
+    {
+        snprintf(path, sizeof path, "%s/%ld_%d", dir, k, j);
+        long long x;
+        for (;;)
+        {
+            f = fopen(path, "r");
+            if (f)
+            {
+                const int got = fscanf(f, "%lld", &x);
+                fclose(f);
+                if (got == 1)
+                    break;
+            }
+            if (time(NULL) > deadline)
+                return LVBGPU_E_COMM; /* a rank never made call k */
+            usleep(200);
+        }
+        if (who < 0 || x < best)
+        {
+            best = x;
+            who = j;
+        }
+    }
+    *v = best;
+    if (r)
+        *r = who;
+    return LVBGPU_OK;
 }
 /* ---- several chains per context -------------------------------------------------------------------------------
  * The double keeps R trees and draws the neighbours ITSELF, with the host library's own move generators on a mirror
@@ -170,7 +228,6 @@ int lvbgpu_allreduce_min(lvbgpu_ctx *c, int64_t *v, int32_t *r)
  * loop must not depend on anyway).  Enough for lvbhost_anneal_chains to run on the CPU: its state machines, the
  * "a chain's trajectory does not depend on R" property, and the sanitizers. */
 #include "../../include/lvbhost.h"
-#include <stdio.h>
 
 #define DBL_MAX_CHAINS 64
 
