@@ -149,13 +149,9 @@ struct OffVec
 // narrow form - offsets in 16-byte units, 32 bits, the shift folded into the address add - saves three
 // instructions per token: 2.3 % of the launch (the loop sits within 7 % of what the L2 -> CU path delivers,
 // instruction count is the second-order term: DESIGN.md section 3).
-// ITEMS: how many items (tile group x candidate) a wave walks, one after the other (1; 2 is an experiment,
-// LVBGPU_PAIR=1).  A wave's time is 1.9 us + 0.22 us per token (6.9 us at 23 tokens, 13.9 us at 55: same batch size,
-// trees of different depth).  With two items the second one's descriptor and tokens are requested together with the
-// first one's, before anything is walked, so that its three dependent round trips (descriptor -> tokens -> rows) hide
-// behind the first item's walk.  It measured 2-5 % SLOWER: with eight waves per SIMD those round trips were hidden
-// already, the fixed part is work (and ring fill / drain), not waiting.
-template <bool COMMIT, bool WIDE, int ITEMS>
+// (Two items per wave with both descriptors and token vectors requested up front was tried and measured 2-5 % slower:
+// profiles/experiments/r02_walk_and_step.md; commit 3b695f1 still has it.)
+template <bool COMMIT, bool WIDE>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(COMMIT ? 4 : 8))) void fitch_walk(const WalkArgs a)
 {
     extern __shared__ uint4 lds_stack[]; // operand stack: [wave][level][lane]
@@ -171,8 +167,8 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     // the ones still in the 256 MiB Infinity Cache (walking the same way every time would find none of it there).
     const uint32_t in_xcd = a.flip ? (nblk >> 3) - 1u - (blockIdx.x >> 3) : (blockIdx.x >> 3);
     const uint32_t pos = (blockIdx.x & 7u) * (nblk >> 3) + in_xcd;
-    const uint32_t item0 = (pos * WALK_WAVES + wave) * (uint32_t)ITEMS;
-    if (item0 >= a.nitems)
+    const uint32_t item = pos * WALK_WAVES + wave;
+    if (item >= a.nitems)
         return;
     // an item = (tile group, candidate): the wave walks the candidate's program once per tile of
     // its group, so descriptor/token fetches and the final reduction are paid once per group
@@ -186,58 +182,12 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             cnd -= a.B;
         }
     };
-    // ITEMS > 1: every item's descriptor (lane k holds word k) and first 64 tokens (lane k holds token k), all
-    // requested before the first item is walked
-    [[maybe_unused]] uint32_t cdw[ITEMS], tokf[ITEMS];
-    auto unpack = [&](uint32_t w) -> CandDesc {
-        CandDesc d;
-        d.tok_off = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
-        d.ntok = (uint32_t)__builtin_amdgcn_readlane((int)w, 1);
-        d.dst_off = (uint32_t)__builtin_amdgcn_readlane((int)w, 2);
-        d.ncomb = (uint32_t)__builtin_amdgcn_readlane((int)w, 3);
-        d.base = (long long)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w, 5) << 32) |
-                             (uint32_t)__builtin_amdgcn_readlane((int)w, 4));
-        d.flags = (uint32_t)__builtin_amdgcn_readlane((int)w, 6);
-        d.nfresh = (uint32_t)__builtin_amdgcn_readlane((int)w, 7);
-        return d;
-    };
-    if constexpr (ITEMS > 1)
-    {
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++)
-        {
-            uint32_t g, c;
-            split(item0 + (uint32_t)k < a.nitems ? item0 + (uint32_t)k : a.nitems - 1u, g, c);
-            cdw[k] = reinterpret_cast<const uint32_t *>(a.cands + c)[lane & 7u];
-        }
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++)
-        {
-            // lanes past the program read token 0 (harmless: every use is masked by the token count)
-            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)cdw[k], 0), nt = (uint32_t)__builtin_amdgcn_readlane((int)cdw[k], 1);
-            tokf[k] = (a.toks + off)[lane < nt ? lane : 0u];
-        }
-    }
-#pragma unroll
-    for (int k_item = 0; k_item < ITEMS; k_item++)
-    {
-    const uint32_t item = item0 + (uint32_t)k_item;
-    if (item >= a.nitems)
-        return;
     uint32_t group, cand;
     split(item, group, cand);
     const uint32_t tile_begin = group * a.tiles_per + (group < a.tiles_rem ? group : a.tiles_rem);
     const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
 
-    CandDesc cd;
-    [[maybe_unused]] uint32_t tok_first = 0; // ITEMS > 1: this item's first 64 tokens
-    if constexpr (ITEMS > 1)
-    {
-        cd = unpack(cdw[k_item]);
-        tok_first = tokf[k_item];
-    }
-    else
-        cd = a.cands[a.pick ? a.pick[cand] : cand];
+    const CandDesc cd = a.cands[a.pick ? a.pick[cand] : cand];
     // which resident tree: node numbers from bias_from on (the internal nodes) move by the chain's row block
     const uint32_t chain = cd.flags >> CAND_CHAIN_SHIFT;
     const uint32_t row_bias = chain * a.chain_rows;
@@ -360,11 +310,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
         {
             const uint32_t cnt = (cd.ntok - c0 < 64u) ? cd.ntok - c0 : 64u;
             // lane k holds token c0+k and that row's offset: one coalesced load + one multiply for 64 tokens
-            uint32_t mytok;
-            if (ITEMS > 1 && c0 == 0u)
-                mytok = lane < cnt ? tok_first : 0u;
-            else
-                mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
+            const uint32_t mytok = (lane < cnt) ? tk[c0 + lane] : 0u;
             // that row's offset: bytes in two vectors (WIDE) or 16-byte units in one
             const uint32_t myrow = biased(mytok & TOK_ROW_MASK);
             const uint64_t myoff64 = WIDE ? (uint64_t)myrow * ((uint64_t)a.in_stride4 << 4)
@@ -533,7 +479,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                     __hip_atomic_store(a.host_flag, a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
-            return; // (ITEMS == 1 always here)
+            return;
         }
     }
     if (lane == 0 && !(COMMIT && a.tmp_changes)) // a fused commit's length is S_all + the root slot
@@ -612,7 +558,6 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             }
         }
     }
-    } // items of this wave
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -934,38 +879,18 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         return e && e[0] == '1';
     }();
     const bool wide = force_wide || (uint64_t)args.nrows * args.in_stride4 >= (1ull << 32);
-    // experiment, LVBGPU_PAIR=1: big scoring launches walk two items per wave (ITEMS = 2).  Measured on MI355X it does
-    // not pay (B = 4096: 93.5 vs 89.2 us, B = 16 384: 319 vs 314 us): the fixed 1.9 us per wave is not exposed latency -
-    // eight waves per SIMD cover one another's round trips - so one item per wave stays the default.
-    static const bool allow_pair = [] {
-        const char *e = getenv("LVBGPU_PAIR");
-        return e && e[0] == '1';
-    }();
-    const bool pair = allow_pair && !commit && !a.host_len && !a.pick && a.nitems >= PAIR_MIN_ITEMS;
-    if (pair)
-    {
-        nblk = ((a.nitems + 1u) / 2u + WALK_WAVES - 1) / WALK_WAVES;
-        nblk = (nblk + 7u) & ~7u;
-    }
     const dim3 grid(nblk), block(WALK_THREADS);
     if (commit)
     {
         if (wide)
-            hipLaunchKernelGGL((fitch_walk<true, true, 1>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<true, true>), grid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((fitch_walk<true, false, 1>), grid, block, lds, stream, a);
-    }
-    else if (pair)
-    {
-        if (wide)
-            hipLaunchKernelGGL((fitch_walk<false, true, 2>), grid, block, lds, stream, a);
-        else
-            hipLaunchKernelGGL((fitch_walk<false, false, 2>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<true, false>), grid, block, lds, stream, a);
     }
     else if (wide)
-        hipLaunchKernelGGL((fitch_walk<false, true, 1>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((fitch_walk<false, true>), grid, block, lds, stream, a);
     else
-        hipLaunchKernelGGL((fitch_walk<false, false, 1>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((fitch_walk<false, false>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
@@ -983,12 +908,10 @@ hipError_t launch_gather_picks(const uint32_t *pick, uint32_t k, const ProposalI
 hipError_t raise_lds_limit()
 {
     // whole-tree programs may want more than the default 64 KiB of dynamic LDS
-    for (const void *f : {reinterpret_cast<const void *>(&fitch_walk<true, true, 1>),
-                          reinterpret_cast<const void *>(&fitch_walk<true, false, 1>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, true, 1>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, false, 1>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, true, 2>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, false, 2>)})
+    for (const void *f : {reinterpret_cast<const void *>(&fitch_walk<true, true>),
+                          reinterpret_cast<const void *>(&fitch_walk<true, false>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, true>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, false>)})
     {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         if (e != hipSuccess)

@@ -25,8 +25,7 @@ constexpr uint32_t MAX_LDS_BYTES = 160 * 1024;    // gfx950: 160 KiB per CU
 // for 65 536 waves.
 constexpr uint32_t TARGET_WAVES = 1u << 22;
 constexpr uint32_t MAX_TILES_PER_WAVE = 8;
-constexpr uint32_t PAIR_MIN_ITEMS = 32768;
-constexpr uint64_t FLIP_MIN_BYTES = 64ull << 20;  // tree blocks beyond this alternate the direction of scoring launches        // scoring launches of at least this many items walk two items per wave
+constexpr uint64_t FLIP_MIN_BYTES = 64ull << 20;  // tree blocks beyond this alternate the direction of scoring launches
 
 // "length" the device generator gives a candidate it could not represent (per-candidate buffers
 // too short, no admissible move): the host turns anything this large into INT64_MAX
