@@ -231,8 +231,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
         ctx->side_pending = false;
     }
-    bool uploaded = false;
-    int rc = prepare_tables(ctx, chains.data(), k, &uploaded);
+    int rc = prepare_tables(ctx, chains.data(), k);
     if (rc != LVBGPU_OK)
         return rc;
     if (!ps.batch)
@@ -357,29 +356,11 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         ps.segs.push_back({d.chain, (int32_t)start, d.count, cs.topo_version});
         start += (uint32_t)d.count;
     }
-    // While the other slot's batch is on the device this batch's generator COULD run beside that batch's walk, on the
-    // side stream (it writes this slot's buffers only).  Measured (B = 4096): the walk then takes 100 us instead of 88
-    // (the generator's workgroups hold LDS and wave slots) and the step gains nothing over simply queueing behind it -
-    // what two batches in flight buy is the host's share of a step, and that they buy either way.  LVBGPU_GEN_BESIDE=1
-    // turns it on for experiments.
-    static const bool allow_beside = [] {
-        const char *e = getenv("LVBGPU_GEN_BESIDE");
-        return e && e[0] == '1';
-    }();
-    const bool beside = allow_beside && ctx->pslot[1 - slot].in_flight && !uploaded && !moves;
-    if (beside)
-    {
-        HIPCHK(ctx, launch_propose(ga, ctx->side_stream));
-        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
-        ctx->side_pending = true;
-    }
-    if (ctx->side_pending) // the generator above: before the walk
-    {
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
-        ctx->side_pending = false;
-    }
-    if (!beside)
-        HIPCHK(ctx, launch_propose(ga, ctx->stream));
+    // (While the other slot's batch is on the device this batch's generator COULD run beside that batch's walk, on a
+    // stream of its own: measured at B = 4096 the walk then takes 100 us instead of 88 - the generator's workgroups
+    // hold LDS and wave slots - and the step gains nothing over queueing behind it; with that stream at the lowest
+    // priority a step takes 161 us.  profiles/experiments/r02_walk_and_step.md)
+    HIPCHK(ctx, launch_propose(ga, ctx->stream));
     bt->len_zeroed = true; // by the generator
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
