@@ -276,6 +276,7 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
             (void)hipEventDestroy(ps.done_ev);
         if (ps.walk_ev)
             (void)hipEventDestroy(ps.walk_ev);
+        ps.h_flag.release();
     }
     ctx->h_pinfo.release();
     ctx->h_topo.release();

@@ -362,29 +362,62 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     // priority a step takes 161 us.  profiles/experiments/r02_walk_and_step.md)
     HIPCHK(ctx, launch_propose(ga, ctx->stream));
     bt->len_zeroed = true; // by the generator
+    // Only the lengths come back per step (a move's descriptor and edits are fetched when, and only when, the caller
+    // wants that candidate - lvbgpu_proposal_edits - or accepts it - lvbgpu_chains_commit).  One batch at a time the
+    // walk hands them over itself: watcher waves at the end of its grid store them into the batch's pinned buffer and
+    // release this slot's flag (WalkArgs::watcher) - no copy behind the walk for the step to wait for (B = 4096: 135 ->
+    // 121 us per step).  With the other slot's batch in flight the copy is hidden anyway (it goes to the copy stream,
+    // beside the next batch's generator: in the main stream it held that generator back for 21 us, 34 -> 38.6 M
+    // candidates/s), and the walk stays 1.6 us shorter without its hand-over.  LVBGPU_WATCHER=0: always the copy (A/B
+    // runs); launches of more than WATCH_MAX_GROUPS tile groups keep it too.
+    static const bool allow_watcher = [] {
+        const char *e = getenv("LVBGPU_WATCHER");
+        return !(e && e[0] == '0');
+    }();
+    ps.watched = allow_watcher && !ctx->pslot[1 - slot].in_flight &&
+                 choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves) <= WATCH_MAX_GROUPS;
+    if (ps.watched)
+    {
+        if (!ps.h_flag.p)
+        {
+            HIPCHK(ctx, ps.h_flag.reserve(64));
+            memset(ps.h_flag.p, 0, 64);
+        }
+        const size_t old_done = ctx->d_done.cap;
+        HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 4) * 4));
+        if (ctx->d_done.cap != old_done) // once per context
+        {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        bt->watch_count = (uint32_t *)ctx->d_done.p + MAX_CHAINS + 1 + slot;
+        bt->watch_flag = (uint32_t *)ps.h_flag.p;
+        bt->watch_seq = ++ps.seq == 0xFFFFFFFFu ? (ps.seq = 1) : ps.seq; // 0xFFFFFFFF is the watcher's "gave up"
+    }
+    else
+        bt->watch_flag = nullptr;
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
     {
         ps.segs.clear();
         return rc;
     }
-    // only the lengths come back per step; a move's descriptor and edits are fetched when (and only
-    // when) the caller wants that candidate (lvbgpu_proposal_edits) or accepts it (lvbgpu_chains_commit)
-    // With the other slot's batch in flight the read-back goes to the copy stream, behind the walk: in the main stream
-    // a 32 KB read-back holds the NEXT batch's generator back for 21 us (the copy's own latency), a sixth of a step
-    // (32 -> 38.6 M candidates/s).  One batch at a time it stays in the main stream: nothing is queued behind it, and the
-    // hop to another stream costs the step 13 us (measured: an annealing step of one chain 64 -> 76 us).
-    if (ctx->pslot[1 - slot].in_flight)
+    if (!ps.watched)
     {
-        HIPCHK(ctx, hipEventRecord(ps.walk_ev, ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ps.walk_ev, 0));
-        HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIPCHK(ctx, hipEventRecord(ps.done_ev, ctx->copy_stream));
-    }
-    else
-    {
-        HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipEventRecord(ps.done_ev, ctx->stream));
+        // the copy: beside the next batch's generator when the other slot's batch is in flight, else in the main stream
+        // (the hop to another stream costs a lone step 13 us)
+        if (ctx->pslot[1 - slot].in_flight)
+        {
+            HIPCHK(ctx, hipEventRecord(ps.walk_ev, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ps.walk_ev, 0));
+            HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+            HIPCHK(ctx, hipEventRecord(ps.done_ev, ctx->copy_stream));
+        }
+        else
+        {
+            HIPCHK(ctx, hipMemcpyAsync(bt->h_len.p, bt->d_len.p, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ps.done_ev, ctx->stream));
+        }
     }
     ps.in_flight = true;
     if (k == 1 && draws[0].chain == guard.sel)
@@ -402,7 +435,29 @@ int propose_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ps.in_flight = false;
     // this batch alone: whatever was enqueued behind it (the other slot's batch, commits) is not waited for
-    if (ps.B > SPIN_WAIT_MAX_B)
+    if (ps.watched)
+    {
+        const uint32_t *flag = (const uint32_t *)ps.h_flag.p;
+        uint32_t seen;
+        for (uint32_t spins = 1; (seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE)) != ps.seq && seen != 0xFFFFFFFFu; spins++)
+            if ((spins & 4095u) == 0)
+            {
+                // a stream that has drained (or failed) ends the wait whatever the flag says
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q == hipErrorNotReady)
+                    continue;
+                HIPCHK(ctx, q);
+                seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+                break;
+            }
+        if (seen != ps.seq)
+        {
+            ps.segs.clear();
+            ps.p_B = 0;
+            return ctx->fail(LVBGPU_E_STATE, "the walk's watcher did not hand the lengths over (flag " + std::to_string(seen) + ")");
+        }
+    }
+    else if (ps.B > SPIN_WAIT_MAX_B)
         HIPCHK(ctx, hipEventSynchronize(ps.done_ev));
     else
     {
@@ -555,7 +610,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     memcpy(h_picks, where.data(), (size_t)k * 4);
     const uint32_t seq = ++ctx->pick_seq;
     const size_t old_done = ctx->d_done.cap;
-    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
+    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 4) * 4));
     if (ctx->d_done.cap != old_done) // once per context: both streams below use it
     {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
@@ -751,7 +806,7 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         progp = ctx->d_commit[0].p;
     }
     const size_t old_done = ctx->d_done.cap;
-    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
+    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 4) * 4));
     if (ctx->d_done.cap != old_done)
     {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));

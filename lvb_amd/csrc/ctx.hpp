@@ -211,6 +211,9 @@ struct lvbgpu_ctx
         int32_t B = 0;
         hipEvent_t done_ev = nullptr; // after the lengths' read-back (on the copy stream)
         hipEvent_t walk_ev = nullptr; // after the walk (on the main stream): what the read-back waits for
+        PinBuf h_flag;                // the watcher's word for this slot's batches (kernels.hpp WalkArgs::watcher)
+        uint32_t seq = 0;
+        bool watched = false;         // this batch's lengths come through the watcher, not a copy
         bool in_flight = false;
     };
     static constexpr int PROP_SLOTS = 2;
@@ -306,6 +309,11 @@ struct lvbgpu_batch
     bool direct = false;     // this step's lengths come back through the walk's last wave (no copy, no stream wait)
     bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
     bool launched = false;   // lengths exist (or are on their way)
+    // device-built batches: the walk's watcher workgroup stores the lengths into h_len and releases *watch_flag =
+    // watch_seq (pinned; null: no watcher, the caller copies the lengths back)
+    uint32_t *watch_flag = nullptr;
+    uint32_t *watch_count = nullptr; // device word the watcher waves tick (zero between launches)
+    uint32_t watch_seq = 0;
     bool spans_chains = false; // device-built batch over several chains: every program names its own chain
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)
     int32_t chain = 0;         // ... and which chain's tree that is

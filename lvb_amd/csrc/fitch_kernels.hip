@@ -161,7 +161,47 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
 
     // XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs; give
     // XCD x the x-th contiguous eighth of the tile-major item list.  gridDim.x % 8 == 0.
-    const uint32_t nblk = gridDim.x;
+    // (a watcher launch has eight more blocks than item blocks: the first of them watches, see WalkArgs::watcher)
+    const uint32_t nblk = (!COMMIT && a.watcher) ? gridDim.x - 8u : gridDim.x;
+    if constexpr (!COMMIT)
+        if (a.watcher && blockIdx.x >= nblk)
+        {
+            // all 32 waves of the eight extra blocks watch: wave w takes the 64-candidate chunks w, w + 32, ... (one
+            // wave alone would take B / 64 dependent round trips AFTER the last walking wave: 35 us at B = 4096)
+            constexpr uint32_t WATCHERS = 8u * WALK_WAVES;
+            const uint32_t wid = (blockIdx.x - nblk) * WALK_WAVES + wave;
+            const unsigned long long want = (unsigned long long)a.ngroups;
+            const unsigned long long count_mask = 0xFFFull << WATCH_COUNT_SHIFT;
+            bool gave_up = false;
+            for (uint32_t base = wid * 64u; base < a.B; base += WATCHERS * 64u)
+            {
+                const uint32_t i = base + lane;
+                if (i < a.B)
+                {
+                    unsigned long long v;
+                    uint32_t budget = 1u << 24; // ~ seconds: every walking wave finishes on its own, this is a backstop
+                    while ((((v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & count_mask) >>
+                            WATCH_COUNT_SHIFT) != want &&
+                           --budget)
+                        __builtin_amdgcn_s_sleep(8);
+                    gave_up |= budget == 0u;
+                    __hip_atomic_store(a.host_len + i, v & ~count_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            atomics_acknowledged(); // the wave's stores (all lanes) before its tick
+            const uint32_t bad = __builtin_amdgcn_ballot_w64(gave_up) != 0ull ? 1u << 16 : 0u;
+            if (lane == 0)
+            {
+                const uint32_t seen = atomicAdd(a.done_count, 1u + bad) + 1u + bad;
+                if ((seen & 0xFFFFu) == WATCHERS) // the last watcher: every chunk is on the host
+                {
+                    __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomics_acknowledged();
+                    __hip_atomic_store(a.host_flag, (seen >> 16) ? 0xFFFFFFFFu : a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
     // a.flip: every other launch walks each XCD's share of the tile-major list from its far end.  A tree block beyond
     // the XCD L2s (cfg5: 401 MB) is then re-read starting with the tiles the previous launch touched LAST, which are
     // the ones still in the 256 MiB Infinity Cache (walking the same way every time would find none of it there).
@@ -464,7 +504,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     }
     if constexpr (!COMMIT)
     {
-        if (a.host_len && a.ngroups == 1u)
+        if (a.host_len && !a.watcher && a.ngroups == 1u)
         {
             // direct step, one wave per candidate: `total` is the whole length - straight to the host, and the
             // last wave to tick releases the flag (every wave's store is system-visible before its tick)
@@ -483,7 +523,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
         }
     }
     if (lane == 0 && !(COMMIT && a.tmp_changes)) // a fused commit's length is S_all + the root slot
-        atomicAdd(a.len_out + cand, total);
+        atomicAdd(a.len_out + cand, total + ((!COMMIT && a.watcher) ? 1ull << WATCH_COUNT_SHIFT : 0ull));
 
     if constexpr (COMMIT)
     {
@@ -532,7 +572,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     }
     else
     {
-        if (a.host_len)
+        if (a.host_len && !a.watcher)
         {
             // the launch's last wave hands the lengths to the host itself (threadfence-reduction pattern)
             uint32_t last = 0;
@@ -879,7 +919,9 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         return e && e[0] == '1';
     }();
     const bool wide = force_wide || (uint64_t)args.nrows * args.in_stride4 >= (1ull << 32);
-    const dim3 grid(nblk), block(WALK_THREADS);
+    if (commit || !a.host_len || a.ngroups > WATCH_MAX_GROUPS)
+        a.watcher = 0;
+    const dim3 grid(a.watcher ? nblk + 8u : nblk), block(WALK_THREADS);
     if (commit)
     {
         if (wide)

@@ -35,6 +35,10 @@ constexpr uint32_t CAND_RESIDENT_BASE = 1u;       // base += *s_all - sum(node_c
 // numbers in ONE tree (0..2n-4); the state sets of several resident trees share the leaf rows and keep their internal
 // rows one block after the other, so the walk turns node v of chain c into row v + c * chain_rows for v >= bias_from.
 constexpr uint32_t CAND_CHAIN_SHIFT = 8;
+// watcher launches: bits 48..59 of a length slot count the waves that have added to it (lengths are < 2^47; bit 61 is
+// PROPOSAL_OVERFLOW_LENGTH)
+constexpr uint32_t WATCH_COUNT_SHIFT = 48;
+constexpr uint32_t WATCH_MAX_GROUPS = 2047;
 constexpr int32_t MAX_CHAINS = 64;
 
 struct CandDesc
@@ -80,6 +84,14 @@ struct WalkArgs
     uint32_t *done_count;               // device word, zero between launches
     uint32_t *host_flag;                // pinned host word
     uint32_t step_seq;
+    // watcher (big scoring launches of device-built batches, host_len != null): every wave's one atomic adds its
+    // partial length AND 1 << WATCH_COUNT_SHIFT to its candidate's slot, so the slot itself says how many of the
+    // candidate's ngroups waves have arrived; eight extra workgroups at the END of the grid (dealt last, i.e. into the
+    // launch's tail) wait for every slot to be complete, store the lengths into host_len, and the last of their 32
+    // waves (done_count, zero between launches) releases the flag.  The
+    // walking waves pay nothing for it (no returning atomic, no fence, no counter of their own), and a step needs no
+    // read-back copy behind the walk.
+    uint32_t watcher;
     // fused commits (COMMIT, tmp_changes != null): the waves accumulate combine k's changes in tmp_changes[k]
     // (zero between launches); the last wave to finish moves them into changes_out[], keeps *s_all_out current
     // with the difference to what those nodes held before, and clears tmp_changes and done_count again - no
