@@ -334,7 +334,6 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
     {
         a.host_len = (unsigned long long *)b->h_len.p;
         a.host_flag = b->watch_flag;
-        a.done_count = b->watch_count;
         a.step_seq = b->watch_seq;
         a.watcher = 1; // (launch_walk turns it off again for launches it does not fit)
     }

@@ -380,17 +380,9 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     {
         if (!ps.h_flag.p)
         {
-            HIPCHK(ctx, ps.h_flag.reserve(64));
-            memset(ps.h_flag.p, 0, 64);
+            HIPCHK(ctx, ps.h_flag.reserve(WATCH_WAVES * 4));
+            memset(ps.h_flag.p, 0, WATCH_WAVES * 4);
         }
-        const size_t old_done = ctx->d_done.cap;
-        HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 4) * 4));
-        if (ctx->d_done.cap != old_done) // once per context
-        {
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        bt->watch_count = (uint32_t *)ctx->d_done.p + MAX_CHAINS + 1 + slot;
         bt->watch_flag = (uint32_t *)ps.h_flag.p;
         bt->watch_seq = ++ps.seq == 0xFFFFFFFFu ? (ps.seq = 1) : ps.seq; // 0xFFFFFFFF is the watcher's "gave up"
     }
@@ -438,18 +430,31 @@ int propose_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
     if (ps.watched)
     {
         const uint32_t *flag = (const uint32_t *)ps.h_flag.p;
-        uint32_t seen;
-        for (uint32_t spins = 1; (seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE)) != ps.seq && seen != 0xFFFFFFFFu; spins++)
+        // every watcher wave sets its own word: all of them, in any order (a word still behind is re-read, the ones
+        // before it were seen complete)
+        uint32_t seen = ps.seq, w = 0;
+        for (uint32_t spins = 1; w < WATCH_WAVES; spins++)
+        {
+            seen = __atomic_load_n(flag + w, __ATOMIC_ACQUIRE);
+            if (seen == ps.seq)
+            {
+                w++;
+                continue;
+            }
+            if (seen == 0xFFFFFFFFu)
+                break;
             if ((spins & 4095u) == 0)
             {
-                // a stream that has drained (or failed) ends the wait whatever the flag says
+                // a stream that has drained (or failed) ends the wait whatever the flags say
                 const hipError_t q = hipStreamQuery(ctx->stream);
                 if (q == hipErrorNotReady)
                     continue;
                 HIPCHK(ctx, q);
-                seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
-                break;
+                seen = __atomic_load_n(flag + w, __ATOMIC_ACQUIRE);
+                if (seen != ps.seq)
+                    break;
             }
+        }
         if (seen != ps.seq)
         {
             ps.segs.clear();
@@ -610,7 +615,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     memcpy(h_picks, where.data(), (size_t)k * 4);
     const uint32_t seq = ++ctx->pick_seq;
     const size_t old_done = ctx->d_done.cap;
-    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 4) * 4));
+    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
     if (ctx->d_done.cap != old_done) // once per context: both streams below use it
     {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
@@ -806,7 +811,7 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         progp = ctx->d_commit[0].p;
     }
     const size_t old_done = ctx->d_done.cap;
-    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 4) * 4));
+    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
     if (ctx->d_done.cap != old_done)
     {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));

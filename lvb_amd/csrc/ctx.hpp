@@ -309,10 +309,9 @@ struct lvbgpu_batch
     bool direct = false;     // this step's lengths come back through the walk's last wave (no copy, no stream wait)
     bool in_place = false;   // ... and its programs are read where they lie in ctx->h_pin
     bool launched = false;   // lengths exist (or are on their way)
-    // device-built batches: the walk's watcher workgroup stores the lengths into h_len and releases *watch_flag =
-    // watch_seq (pinned; null: no watcher, the caller copies the lengths back)
+    // device-built batches: the walk's watcher waves store the lengths into h_len and set watch_flag[0 .. WATCH_WAVES)
+    // to watch_seq (pinned; null: no watcher, the caller copies the lengths back)
     uint32_t *watch_flag = nullptr;
-    uint32_t *watch_count = nullptr; // device word the watcher waves tick (zero between launches)
     uint32_t watch_seq = 0;
     bool spans_chains = false; // device-built batch over several chains: every program names its own chain
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)

@@ -151,7 +151,9 @@ struct OffVec
 // instruction count is the second-order term: DESIGN.md section 3).
 // (Two items per wave with both descriptors and token vectors requested up front was tried and measured 2-5 % slower:
 // profiles/experiments/r02_walk_and_step.md; commit 3b695f1 still has it.)
-template <bool COMMIT, bool WIDE>
+// WATCH: the launch has watcher waves (WalkArgs::watcher) - a kernel of its own, so that the plain scoring walk's code
+// is not touched by it (with the watcher as a run-time branch of the one kernel the walk took 92.8 instead of 87.5 us)
+template <bool COMMIT, bool WIDE, bool WATCH = false>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(COMMIT ? 4 : 8))) void fitch_walk(const WalkArgs a)
 {
     extern __shared__ uint4 lds_stack[]; // operand stack: [wave][level][lane]
@@ -162,13 +164,14 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     // XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs; give
     // XCD x the x-th contiguous eighth of the tile-major item list.  gridDim.x % 8 == 0.
     // (a watcher launch has eight more blocks than item blocks: the first of them watches, see WalkArgs::watcher)
-    const uint32_t nblk = (!COMMIT && a.watcher) ? gridDim.x - 8u : gridDim.x;
-    if constexpr (!COMMIT)
-        if (a.watcher && blockIdx.x >= nblk)
+    static_assert(!(COMMIT && WATCH), "scoring launches only");
+    const uint32_t nblk = WATCH ? gridDim.x - 8u : gridDim.x;
+    if constexpr (WATCH)
+        if (blockIdx.x >= nblk)
         {
             // all 32 waves of the eight extra blocks watch: wave w takes the 64-candidate chunks w, w + 32, ... (one
             // wave alone would take B / 64 dependent round trips AFTER the last walking wave: 35 us at B = 4096)
-            constexpr uint32_t WATCHERS = 8u * WALK_WAVES;
+            constexpr uint32_t WATCHERS = WATCH_WAVES;
             const uint32_t wid = (blockIdx.x - nblk) * WALK_WAVES + wave;
             const unsigned long long want = (unsigned long long)a.ngroups;
             const unsigned long long count_mask = 0xFFFull << WATCH_COUNT_SHIFT;
@@ -188,18 +191,11 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                     __hip_atomic_store(a.host_len + i, v & ~count_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
-            atomics_acknowledged(); // the wave's stores (all lanes) before its tick
-            const uint32_t bad = __builtin_amdgcn_ballot_w64(gave_up) != 0ull ? 1u << 16 : 0u;
+            atomics_acknowledged(); // the wave's stores (all lanes) before its flag
+            // every watcher wave has a flag word of its own (the host waits for all 32): no counter for them to meet at
             if (lane == 0)
-            {
-                const uint32_t seen = atomicAdd(a.done_count, 1u + bad) + 1u + bad;
-                if ((seen & 0xFFFFu) == WATCHERS) // the last watcher: every chunk is on the host
-                {
-                    __hip_atomic_store(a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomics_acknowledged();
-                    __hip_atomic_store(a.host_flag, (seen >> 16) ? 0xFFFFFFFFu : a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
+                __hip_atomic_store(a.host_flag + wid, __builtin_amdgcn_ballot_w64(gave_up) != 0ull ? 0xFFFFFFFFu : a.step_seq,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
     // a.flip: every other launch walks each XCD's share of the tile-major list from its far end.  A tree block beyond
@@ -504,7 +500,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     }
     if constexpr (!COMMIT)
     {
-        if (a.host_len && !a.watcher && a.ngroups == 1u)
+        if (!WATCH && a.host_len && a.ngroups == 1u)
         {
             // direct step, one wave per candidate: `total` is the whole length - straight to the host, and the
             // last wave to tick releases the flag (every wave's store is system-visible before its tick)
@@ -523,7 +519,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
         }
     }
     if (lane == 0 && !(COMMIT && a.tmp_changes)) // a fused commit's length is S_all + the root slot
-        atomicAdd(a.len_out + cand, total + ((!COMMIT && a.watcher) ? 1ull << WATCH_COUNT_SHIFT : 0ull));
+        atomicAdd(a.len_out + cand, total + (WATCH ? 1ull << WATCH_COUNT_SHIFT : 0ull));
 
     if constexpr (COMMIT)
     {
@@ -572,7 +568,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     }
     else
     {
-        if (a.host_len && !a.watcher)
+        if (!WATCH && a.host_len)
         {
             // the launch's last wave hands the lengths to the host itself (threadfence-reduction pattern)
             uint32_t last = 0;
@@ -929,6 +925,13 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         else
             hipLaunchKernelGGL((fitch_walk<true, false>), grid, block, lds, stream, a);
     }
+    else if (a.watcher)
+    {
+        if (wide)
+            hipLaunchKernelGGL((fitch_walk<false, true, true>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((fitch_walk<false, false, true>), grid, block, lds, stream, a);
+    }
     else if (wide)
         hipLaunchKernelGGL((fitch_walk<false, true>), grid, block, lds, stream, a);
     else
@@ -953,7 +956,9 @@ hipError_t raise_lds_limit()
     for (const void *f : {reinterpret_cast<const void *>(&fitch_walk<true, true>),
                           reinterpret_cast<const void *>(&fitch_walk<true, false>),
                           reinterpret_cast<const void *>(&fitch_walk<false, true>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, false>)})
+                          reinterpret_cast<const void *>(&fitch_walk<false, false>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, true, true>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, false, true>)})
     {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         if (e != hipSuccess)

@@ -39,6 +39,7 @@ constexpr uint32_t CAND_CHAIN_SHIFT = 8;
 // PROPOSAL_OVERFLOW_LENGTH)
 constexpr uint32_t WATCH_COUNT_SHIFT = 48;
 constexpr uint32_t WATCH_MAX_GROUPS = 2047;
+constexpr uint32_t WATCH_WAVES = 8u * WALK_WAVES; // eight extra workgroups
 constexpr int32_t MAX_CHAINS = 64;
 
 struct CandDesc
@@ -87,8 +88,8 @@ struct WalkArgs
     // watcher (big scoring launches of device-built batches, host_len != null): every wave's one atomic adds its
     // partial length AND 1 << WATCH_COUNT_SHIFT to its candidate's slot, so the slot itself says how many of the
     // candidate's ngroups waves have arrived; eight extra workgroups at the END of the grid (dealt last, i.e. into the
-    // launch's tail) wait for every slot to be complete, store the lengths into host_len, and the last of their 32
-    // waves (done_count, zero between launches) releases the flag.  The
+    // launch's tail) wait for every slot to be complete and store the lengths into host_len; each of their WATCH_WAVES
+    // waves then sets ITS word of host_flag[WATCH_WAVES] to step_seq (the host waits for all of them).  The
     // walking waves pay nothing for it (no returning atomic, no fence, no counter of their own), and a step needs no
     // read-back copy behind the walk.
     uint32_t watcher;
