@@ -28,7 +28,10 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
     for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                if KERNEL in row["Kernel_Name"]:
+                name = row["Kernel_Name"].split("(")[0]
+                # <COMMIT = false, WIDE, WATCH>: the watcher variant (a lone step's walk, a handful of launches of the
+                # profiled run) is left out - the summary is of the plain scoring walk the bench's roofline quotes
+                if KERNEL in name and not (name.count(",") == 2 and name.endswith(", true>")):
                     counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
     summary = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(counters.items())}
     mean = lambda k: summary[k]["mean_per_launch"] if k in summary else None
