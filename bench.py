@@ -50,7 +50,7 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 MOVES = {"nni": 0, "spr": 1, "tbr": 2}
-KERNEL = "lvbgpu::fitch_walk<false, false, false>"   # <COMMIT, WIDE, WATCH>: the plain scoring walk
+KERNEL = "lvbgpu::fitch_walk<false, false, 0>"   # <COMMIT, WIDE, HANDOVER>: the plain scoring walk
 WALK_TIMING_EVERY = 4   # HIP events around every 4th scoring walk of the timed region
 
 

@@ -151,9 +151,8 @@ struct OffVec
 // instruction count is the second-order term: DESIGN.md section 3).
 // (Two items per wave with both descriptors and token vectors requested up front was tried and measured 2-5 % slower:
 // profiles/experiments/r02_walk_and_step.md; commit 3b695f1 still has it.)
-// WATCH: the launch has watcher waves (WalkArgs::watcher) - a kernel of its own, so that the plain scoring walk's code
-// is not touched by it (with the watcher as a run-time branch of the one kernel the walk took 92.8 instead of 87.5 us)
-template <bool COMMIT, bool WIDE, bool WATCH = false>
+// (HANDOVER, below: with the watcher as a run-time branch of the one kernel the walk took 92.8 instead of 87.5 us)
+template <bool COMMIT, bool WIDE, int HANDOVER = 0>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(COMMIT ? 4 : 8))) void fitch_walk(const WalkArgs a)
 {
     extern __shared__ uint4 lds_stack[]; // operand stack: [wave][level][lane]
@@ -164,7 +163,11 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     // XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs; give
     // XCD x the x-th contiguous eighth of the tile-major item list.  gridDim.x % 8 == 0.
     // (a watcher launch has eight more blocks than item blocks: the first of them watches, see WalkArgs::watcher)
-    static_assert(!(COMMIT && WATCH), "scoring launches only");
+    // HANDOVER: how a scoring launch's lengths reach the host.  0: they stay in len_out (the caller copies them);
+    // 1: direct step (small launches: the last wave, or with one wave per candidate every wave, stores them to the host);
+    // 2: watcher waves.  Kernels of their own, so that the plain walk carries none of the other two's code.
+    constexpr bool WATCH = HANDOVER == 2, DIRECT = HANDOVER == 1;
+    static_assert(!(COMMIT && HANDOVER != 0), "scoring launches only");
     const uint32_t nblk = WATCH ? gridDim.x - 8u : gridDim.x;
     if constexpr (WATCH)
         if (blockIdx.x >= nblk)
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     }
     if constexpr (!COMMIT)
     {
-        if (!WATCH && a.host_len && a.ngroups == 1u)
+        if (DIRECT && a.ngroups == 1u)
         {
             // direct step, one wave per candidate: `total` is the whole length - straight to the host, and the
             // last wave to tick releases the flag (every wave's store is system-visible before its tick)
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     }
     else
     {
-        if (!WATCH && a.host_len)
+        if constexpr (DIRECT)
         {
             // the launch's last wave hands the lengths to the host itself (threadfence-reduction pattern)
             uint32_t last = 0;
@@ -928,9 +931,16 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
     else if (a.watcher)
     {
         if (wide)
-            hipLaunchKernelGGL((fitch_walk<false, true, true>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<false, true, 2>), grid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((fitch_walk<false, false, true>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((fitch_walk<false, false, 2>), grid, block, lds, stream, a);
+    }
+    else if (a.host_len)
+    {
+        if (wide)
+            hipLaunchKernelGGL((fitch_walk<false, true, 1>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((fitch_walk<false, false, 1>), grid, block, lds, stream, a);
     }
     else if (wide)
         hipLaunchKernelGGL((fitch_walk<false, true>), grid, block, lds, stream, a);
@@ -957,8 +967,10 @@ hipError_t raise_lds_limit()
                           reinterpret_cast<const void *>(&fitch_walk<true, false>),
                           reinterpret_cast<const void *>(&fitch_walk<false, true>),
                           reinterpret_cast<const void *>(&fitch_walk<false, false>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, true, true>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, false, true>)})
+                          reinterpret_cast<const void *>(&fitch_walk<false, true, 1>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, false, 1>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, true, 2>),
+                          reinterpret_cast<const void *>(&fitch_walk<false, false, 2>)})
     {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         if (e != hipSuccess)

@@ -29,9 +29,10 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].split("(")[0]
-                # <COMMIT = false, WIDE, WATCH>: the watcher variant (a lone step's walk, a handful of launches of the
-                # profiled run) is left out - the summary is of the plain scoring walk the bench's roofline quotes
-                if KERNEL in name and not (name.count(",") == 2 and name.endswith(", true>")):
+                # <COMMIT = false, WIDE, HANDOVER>: the direct-step and watcher variants (lone steps: a handful of launches
+                # of the profiled run) are left out - the summary is of the plain scoring walk the bench's roofline quotes
+                # (r02t: <.., true>; later: <.., 1> / <.., 2>)
+                if KERNEL in name and not (name.count(",") == 2 and not name.endswith((", 0>", ", false>"))):
                     counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
     summary = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(counters.items())}
     mean = lambda k: summary[k]["mean_per_launch"] if k in summary else None
