@@ -228,3 +228,19 @@ def test_device_moves_on_a_caterpillar(mods):
         _, l, r, root = ctx.topology()
         tree = host.HostTree(left=l, right=r, root=root, seed=4 + round_)
     ctx.close()
+
+
+def test_lone_steps_without_the_watcher_take_the_copy_path():
+    """A lone step's lengths normally come through the walk's watcher waves (fitch_walk<.., 2>); LVBGPU_WATCHER=0 - and
+    launches of more tile groups than the slots' arrival counts can hold - read them back with a copy instead.  The
+    replay test once more in a child process with the watcher off keeps that path covered."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LVBGPU_WATCHER="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_device_proposals.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "replay_on_host or grow_and_shrink", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout, r.stdout[-500:]
