@@ -1,6 +1,7 @@
 // api_propose.cpp - liblvbgpu.so: neighbourhoods whose rewrites and programs are built on the device (drawn there, or
 // named by the host) - for one resident tree, or for several chains in ONE generator launch and ONE walk.
 #include "ctx.hpp"
+#include "gather.hpp"
 
 namespace lvbgpu_detail
 {
@@ -622,12 +623,21 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     uint32_t *done = (uint32_t *)ctx->d_done.p;
-    // 1. what the host needs to follow the moves (so that it can work while the walk runs)
-    //    (on a stream of its own: descriptors and rewrites are complete - the batch's lengths have been read - and
-    //    nothing here touches state sets, so it runs beside the commit walk AND beside the table rebuild below; behind
-    //    one another on the side stream they were 7 + 23 us, longer than the commit walk they hide behind)
-    HIPCHK(ctx, launch_gather_picks(h_picks, (uint32_t)k, (const ProposalInfo *)ps.d_pinfo.p, (const lvbgpu_edit_dev *)ps.d_pedits.p,
-                                    ctx->p_stride_e, h + o_out, out_stride, flag, seq, done + MAX_CHAINS, ctx->copy_stream));
+    // 1. what the host needs to follow the moves (so that it can work while the walk runs): descriptors and rewrites
+    //    are complete - the batch's lengths have been read - and nothing here touches state sets, so the gather runs
+    //    beside the commit walk; as the first workgroups of the table rebuild's launch where there is one (1b), else
+    //    as a launch of its own
+    GatherArgs gat{};
+    gat.pick = h_picks;
+    gat.k = (uint32_t)k;
+    gat.info = (const ProposalInfo *)ps.d_pinfo.p;
+    gat.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
+    gat.stride_e = ctx->p_stride_e;
+    gat.out = h + o_out;
+    gat.out_stride = out_stride;
+    gat.flag = flag;
+    gat.seq = seq;
+    gat.arrived = done + MAX_CHAINS;
     // 1b. the generator's tables of the picked chains follow their moves on the device (they describe the trees the
     //     candidates were drawn from: the picks were checked against the chains' versions above)
     bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES;
@@ -648,10 +658,12 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         ra.info = (const ProposalInfo *)ps.d_pinfo.p;
         ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
         ra.stride_e = ctx->p_stride_e;
-        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream));
+        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream, &gat));
         HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
         ctx->side_pending = true;
     }
+    else
+        HIPCHK(ctx, launch_gather_picks(gat, ctx->side_stream));
     // 2. the picked candidates' own programs in commit form: produced sets and change counts go to their chains'
     //    rows, every candidate's last wave settles its chain's changes[] and S_all (fused commit)
     HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
@@ -676,9 +688,9 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
             break;
         if ((spins & 1023u) == 0)
         {
-            const hipError_t q = hipStreamQuery(ctx->copy_stream);
+            const hipError_t q = hipStreamQuery(ctx->side_stream);
             if (q == hipSuccess)
-                break; // everything the kernel wrote is visible
+                break; // everything the kernels wrote is visible
             if (q != hipErrorNotReady)
                 return ctx->fail_hip(q, "lvbgpu_chains_commit: waiting for the picked moves");
         }

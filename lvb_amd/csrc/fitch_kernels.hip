@@ -41,6 +41,7 @@
 #include <stdint.h>
 
 #include "kernels.hpp"
+#include "gather.hpp"
 
 namespace lvbgpu
 {
@@ -604,32 +605,9 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
 
 // descriptors and rewrites of the picked candidates of a device-built batch -> pinned host memory (one wave per
 // pick), then the flag: the host applies the moves to its topologies while the commit walk runs
-__global__ __launch_bounds__(64) void gather_picks_kernel(const uint32_t *pick, uint32_t k, const ProposalInfo *info,
-                                                          const lvbgpu_edit_dev *edits, uint32_t stride_e, char *out,
-                                                          uint32_t out_stride, uint32_t *flag, uint32_t seq, uint32_t *arrived)
+__global__ __launch_bounds__(64) void gather_picks_kernel(const GatherArgs g)
 {
-    const uint32_t j = blockIdx.x, lane = threadIdx.x;
-    const uint32_t g = pick[j];
-    const ProposalInfo pi = info[g];
-    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)j * out_stride);
-    // word by word, as system-scope stores (written through to the host, see atomics_acknowledged)
-    constexpr uint32_t PI_WORDS = sizeof(ProposalInfo) / 4u;
-    static_assert(sizeof(ProposalInfo) % 4u == 0 && sizeof(lvbgpu_edit_dev) == 12, "records are copied word by word");
-    if (lane < PI_WORDS)
-        __hip_atomic_store(dst + lane, reinterpret_cast<const uint32_t *>(info + g)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t ne = pi.overflow ? 0u : (uint32_t)pi.n_edits;
-    if (ne > stride_e)
-        ne = stride_e;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(edits + (size_t)g * stride_e);
-    for (uint32_t i = lane; i < 3u * ne; i += 64u)
-        __hip_atomic_store(dst + PI_WORDS + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    atomics_acknowledged();
-    if (lane == 0 && atomicAdd(arrived, 1u) == k - 1u)
-    {
-        __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomics_acknowledged();
-        __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    gather_one_pick(g, blockIdx.x, threadIdx.x);
 }
 
 // changes[dst] = 0 for every node a commit program is about to recompute, plus the two scalars the
@@ -949,14 +927,11 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_gather_picks(const uint32_t *pick, uint32_t k, const ProposalInfo *info, const lvbgpu_edit_dev *edits,
-                               uint32_t stride_e, char *out, uint32_t out_stride, uint32_t *flag, uint32_t seq, uint32_t *arrived,
-                               hipStream_t stream)
+hipError_t launch_gather_picks(const GatherArgs &g, hipStream_t stream)
 {
-    if (k == 0)
+    if (g.k == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(gather_picks_kernel, dim3(k), dim3(64), 0, stream, pick, k, info, edits, stride_e, out, out_stride, flag, seq,
-                       arrived);
+    hipLaunchKernelGGL(gather_picks_kernel, dim3(g.k), dim3(64), 0, stream, g);
     return hipGetLastError();
 }
 

@@ -212,13 +212,15 @@ struct RebuildArgs
     const RebuildExt *ext;   // non-null: workgroup j rebuilds for ext[j] instead of a picked candidate
     const lvbgpu_edit_dev *ext_edits;
 };
-hipError_t launch_rebuild_tables(const RebuildArgs &args, uint32_t k, hipStream_t stream);
+struct GatherArgs;
+hipError_t launch_rebuild_tables(const RebuildArgs &args, uint32_t k, hipStream_t stream, const GatherArgs *gather = nullptr);
 
-// what lvbgpu_chains_commit needs on the host of every picked candidate, written straight into pinned memory:
-// out + j * out_stride: [ProposalInfo][n_edits rewrites]; then *flag = seq (released after the data)
-hipError_t launch_gather_picks(const uint32_t *pick, uint32_t k, const ProposalInfo *info, const lvbgpu_edit_dev *edits,
-                               uint32_t stride_e, char *out, uint32_t out_stride, uint32_t *flag, uint32_t seq, uint32_t *arrived,
-                               hipStream_t stream);
+// what lvbgpu_chains_commit needs on the host of every picked candidate, written straight into pinned memory
+// (gather.hpp): alone (trees too large for the device-side table rebuild), or as the first k workgroups of the rebuild
+// launch (launch_rebuild_tables with gather != null: one launch fewer on the accept path - a launch costs the host
+// 6-9 us with its event, and there the host is what a step waits for)
+struct GatherArgs;
+hipError_t launch_gather_picks(const GatherArgs &g, hipStream_t stream);
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
 hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);

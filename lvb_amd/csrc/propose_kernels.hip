@@ -32,6 +32,7 @@
 #include <stdint.h>
 
 #include "kernels.hpp"
+#include "gather.hpp"
 
 namespace lvbgpu
 {
@@ -639,11 +640,19 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 // ancestors, preorder number and first-leaf position from ONE walk of each node along its own root-ward path (no
 // level-by-level rounds: a barrier of 16 waves costs as much as a path).  No host work and no
 // upload per accepted move; with R chains accepting in one step that was most of the step.
+// With ga.k != 0 the launch's FIRST ga.k workgroups are the accepted candidates' gather (gather.hpp: wave 0 of each; they
+// are dealt first and done in a few microseconds, so the host has its flag long before the rebuilds end).
 template <typename IdxT>
-__global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const RebuildArgs g)
+__global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const RebuildArgs g, const GatherArgs ga)
 {
     extern __shared__ int32_t lds_i32[];
-    const uint32_t j = blockIdx.x;
+    if (blockIdx.x < ga.k)
+    {
+        if (threadIdx.x < 64u)
+            gather_one_pick(ga, blockIdx.x, threadIdx.x);
+        return;
+    }
+    const uint32_t j = blockIdx.x - ga.k;
     const uint32_t cand = g.ext ? 0u : g.pick[j];
     const uint32_t chain = g.ext ? (uint32_t)g.ext[j].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
     IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
@@ -740,8 +749,11 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
     }
 }
 
-hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t stream)
+hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t stream, const GatherArgs *gather)
 {
+    GatherArgs ga{};
+    if (gather)
+        ga = *gather;
     if (k == 0)
         return hipSuccess;
     const size_t lds = ((size_t)4 * g.nb + 4) * sizeof(int32_t);
@@ -759,9 +771,9 @@ hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t s
         raised_on[dev] = true;
     }
     if (g.idx_bytes == 2)
-        hipLaunchKernelGGL(rebuild_tables_kernel<uint16_t>, dim3(k), dim3(REBUILD_THREADS), lds, stream, g);
+        hipLaunchKernelGGL(rebuild_tables_kernel<uint16_t>, dim3(k + ga.k), dim3(REBUILD_THREADS), lds, stream, g, ga);
     else
-        hipLaunchKernelGGL(rebuild_tables_kernel<int32_t>, dim3(k), dim3(REBUILD_THREADS), lds, stream, g);
+        hipLaunchKernelGGL(rebuild_tables_kernel<int32_t>, dim3(k + ga.k), dim3(REBUILD_THREADS), lds, stream, g, ga);
     return hipGetLastError();
 }
 
