@@ -283,11 +283,7 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->d_gen_prof.release();
     ctx->d_done.release();
     for (int i = 0; i < lvbgpu_ctx::PICK_SLOTS; i++)
-    {
         ctx->h_pick[i].release();
-        if (ctx->pick_ev[i])
-            (void)hipEventDestroy(ctx->pick_ev[i]);
-    }
     ctx->d_moves.release();
     ctx->h_moves.release();
     ctx->h_step.release();

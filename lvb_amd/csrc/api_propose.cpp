@@ -473,6 +473,7 @@ int propose_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
         HIPCHK(ctx, q);
     }
     ctx->last_slot = slot;
+    ctx->pick_uses_since_collect = 0; // (take_pick_slot)
     const int32_t B = ps.B;
     const int64_t *len = (const int64_t *)ps.batch->h_len.p;
     for (int32_t b = 0; b < B; b++)
@@ -570,6 +571,31 @@ extern "C" int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *len
     return propose_collect(ctx, slot, lengths_out);
 }
 
+namespace lvbgpu_detail
+{
+// The next pinned slot for a commit's or a re-root's picks / programs.  Its readers - the commit walk (main stream),
+// the table rebuild and the gather (side stream) - are all finished once a LATER batch has been collected: that batch's
+// walk was enqueued behind the commit walk, and its generator waited for the rebuild.  So slots need no events of their
+// own (an event record + a wait cost the host 4-5 us per commit, where the host is what the device waits for): only
+// PICK_SLOTS uses in a row without a collect in between have to drain the streams.
+hipError_t take_pick_slot(lvbgpu_ctx *ctx, int *slot)
+{
+    if (++ctx->pick_uses_since_collect >= lvbgpu_ctx::PICK_SLOTS)
+    {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->side_stream);
+        if (e != hipSuccess)
+            return e;
+        ctx->pick_uses_since_collect = 1;
+    }
+    *slot = ctx->pick_slot;
+    ctx->pick_slot = (*slot + 1) % lvbgpu_ctx::PICK_SLOTS;
+    return hipSuccess;
+}
+} // namespace lvbgpu_detail
+
+
 extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_pick *picks)
 {
     if (!ctx || k < 1 || k > MAX_CHAINS || !picks)
@@ -603,12 +629,8 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     // a pinned slot: [flag][picks][k x (descriptor + rewrites)]
     const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
     const size_t o_pick = 64, o_out = 64 + align16((size_t)MAX_CHAINS * 4);
-    const int slot = ctx->pick_slot;
-    ctx->pick_slot = (slot + 1) % lvbgpu_ctx::PICK_SLOTS;
-    if (!ctx->pick_ev[slot])
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pick_ev[slot], hipEventDisableTiming));
-    else
-        HIPCHK(ctx, hipEventSynchronize(ctx->pick_ev[slot])); // long done unless 4 commits are in flight
+    int slot = 0;
+    HIPCHK(ctx, take_pick_slot(ctx, &slot));
     HIPCHK(ctx, ctx->h_pick[slot].reserve(o_out + (size_t)MAX_CHAINS * out_stride));
     char *h = (char *)ctx->h_pick[slot].p;
     uint32_t *flag = (uint32_t *)h;
@@ -680,7 +702,6 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     a.tmp_stride = (uint32_t)(ctx->nb + 1);
     a.done_count = done;
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->pick_ev[slot], ctx->stream)); // the slot is free once the walk has read its picks
     // 3. follow the moves on the host
     for (uint32_t spins = 1;; spins++)
     {
@@ -770,12 +791,8 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     const size_t o_x = o_d + align16(prog.dsts.size() * 4);
     const size_t o_e = o_x + align16((size_t)k * sizeof(RebuildExt));
     const size_t total = o_e + align16(n_all_edits * sizeof(lvbgpu_edit_dev));
-    const int slot = ctx->pick_slot;
-    ctx->pick_slot = (slot + 1) % lvbgpu_ctx::PICK_SLOTS;
-    if (!ctx->pick_ev[slot])
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pick_ev[slot], hipEventDisableTiming));
-    else
-        HIPCHK(ctx, hipEventSynchronize(ctx->pick_ev[slot]));
+    int slot = 0;
+    HIPCHK(ctx, take_pick_slot(ctx, &slot));
     const size_t slot_min = 64 + align16((size_t)MAX_CHAINS * 4) + (size_t)MAX_CHAINS * 16; // never below what a pick needs first
     HIPCHK(ctx, ctx->h_pick[slot].reserve(std::max(total, slot_min)));
     char *h = (char *)ctx->h_pick[slot].p;
@@ -842,7 +859,6 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     a.tmp_stride = (uint32_t)(ctx->nb + 1);
     a.done_count = (uint32_t *)ctx->d_done.p;
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->pick_ev[slot], ctx->stream));
     // the host's topologies follow
     for (int32_t j = 0; j < k; j++)
     {

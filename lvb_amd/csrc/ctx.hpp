@@ -235,7 +235,7 @@ struct lvbgpu_ctx
     // lvbgpu_chains_commit: picks / fetched rewrites travel through a small ring of pinned slots
     static constexpr int PICK_SLOTS = 4;
     PinBuf h_pick[PICK_SLOTS];
-    hipEvent_t pick_ev[PICK_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int pick_uses_since_collect = 0; // api_propose.cpp take_pick_slot
     int pick_slot = 0;
     uint32_t pick_seq = 0;
     int last_pick_slot = 0, last_pick_count = 0; // what lvbgpu_chains_picked_edits reads

@@ -232,6 +232,24 @@ def test_rerooting_several_chains_at_once_equals_rerooting_them_one_by_one(mods)
             assert np.array_equal(multi.all_sets(), ref.all_sets())
             seed = 900 + 10 * step + c
             assert np.array_equal(multi.propose_score(25, -1, seed), ref.propose_score(25, -1, seed))
+    # many re-roots in a row with no batch collected in between: the pinned slots their programs lie in are recycled
+    # without events (a later collected batch proves the readers done), so a run of them has to drain the streams itself
+    for burst in range(7):
+        reqs = []
+        for c in range(R):
+            nr = int((trees[c].root + 1 + rng.integers(0, n - 1)) % n)
+            reqs.append((c, nr))
+            ed = trees[c].reroot_edits(nr)
+            ref.select_chain(c)
+            ref.commit(ed, root=nr)
+            trees[c].apply(ed, nr)
+        multi.chains_reroot(reqs)
+    for c in range(R):
+        multi.select_chain(c)
+        ref.select_chain(c)
+        assert multi.current_length() == ref.current_length()
+        assert np.array_equal(multi.changes(), ref.changes()) and np.array_equal(multi.all_sets(), ref.all_sets())
+        assert np.array_equal(multi.propose_score(25, -1, 4242 + c), ref.propose_score(25, -1, 4242 + c))
     with pytest.raises(api.LvbGpuError):
         multi.chains_reroot([(0, trees[0].root)])              # already the root
     with pytest.raises(api.LvbGpuError):
