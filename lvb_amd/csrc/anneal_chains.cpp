@@ -452,6 +452,7 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
     int64_t steps = 0;
     double dev_seconds = 0.0;
     double t_plan = 0, t_score = 0, t_consume = 0, t_commit = 0, t_after = 0; // LVBHOST_PROFILE=1 prints them
+    double t_submit = 0, t_reroot = 0; // ... and, of those, the submit call (part of propose_score) and the re-roots (part of plan)
     const bool lockstep = params[0].sync_every > 0;
     if (lockstep && params[0].max_device_steps <= 0)
         return LVBGPU_E_ARG;
@@ -485,7 +486,9 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
                 roots.push_back({c, runs[(size_t)c].pending_root});
         if (!roots.empty())
         {
+            auto tr = Clock::now();
             int rr = lvbgpu_chains_reroot(ctx, (int32_t)roots.size(), roots.data());
+            t_reroot += since(tr);
             for (size_t i = 0; i < roots.size() && rr == LVBGPU_OK; i++)
                 rr = runs[(size_t)roots[i].chain].rerooted();
             if (rr != LVBGPU_OK)
@@ -499,6 +502,7 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
         const int r = lvbgpu_chains_submit(ctx, g, (int32_t)f.draws.size(), f.draws.data());
         dev_seconds += since(td);
         t_score += since(td);
+        t_submit += since(td);
         f.active = r == LVBGPU_OK;
         return r;
     };
@@ -595,10 +599,10 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
         return rc;
     const double secs = since(wall0);
     if (getenv("LVBHOST_PROFILE"))
-        fprintf(stderr, "[anneal_chains] R=%d steps=%lld  per step (us): plan %.1f  propose_score %.1f  consume %.1f  commit %.1f  "
-                        "after_commit %.1f  total %.1f\n",
-                R, (long long)steps, 1e6 * t_plan / steps, 1e6 * t_score / steps, 1e6 * t_consume / steps, 1e6 * t_commit / steps,
-                1e6 * t_after / steps, 1e6 * secs / steps);
+        fprintf(stderr, "[anneal_chains] R=%d steps=%lld  per step (us): plan %.1f (re-roots %.1f)  propose_score %.1f (submit %.1f)  "
+                        "consume %.1f  commit %.1f  after_commit %.1f  total %.1f\n",
+                R, (long long)steps, 1e6 * t_plan / steps, 1e6 * t_reroot / steps, 1e6 * t_score / steps, 1e6 * t_submit / steps,
+                1e6 * t_consume / steps, 1e6 * t_commit / steps, 1e6 * t_after / steps, 1e6 * secs / steps);
     for (ChainRun &r : runs)
     {
         const int64_t keep_global = r.res->global_best_length;
