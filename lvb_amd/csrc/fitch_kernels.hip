@@ -260,10 +260,17 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
         return make_uint4(v.x, v.y, v.z, v.w);
     };
 
-    // COMMIT with defer_slots: [slot][lane] sets and [slot] counts of the combines not yet written out
+    // COMMIT with defer_slots: [slot][lane] sets and [slot][lane] change counts (one byte each: <= 32 sites per lane) of
+    // the combines not yet written out.  The counts are summed per combine at the burst, 64 bytes per lane, instead of
+    // with six ballots per token: a commit is a handful of lone waves whose time is their instruction latency
+    // (25 of a token's ~65 instructions were that sum).
     uint4 *const my_rows = lds_stack + (size_t)WALK_WAVES * a.stack_depth * 64u + (size_t)wave * a.defer_slots * 64u + lane;
-    uint32_t *const my_cnt = reinterpret_cast<uint32_t *>(lds_stack + (size_t)WALK_WAVES * (a.stack_depth + a.defer_slots) * 64u) +
-                             (size_t)wave * a.defer_slots;
+    // (an LDS-typed pointer: through a generic uint8_t * the byte stores may alias anything - the compiler then keeps
+    // the walk's state in scratch around each of them)
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u8 *const my_cnt = (lds_u8 *)(reinterpret_cast<uint8_t *>(lds_stack + (size_t)WALK_WAVES * (a.stack_depth + a.defer_slots) * 64u) +
+                                      (size_t)wave * a.defer_slots * 64u);
     uint32_t pend = 0;      // combines waiting in LDS
     uint32_t k_flushed = 0; // combines of this tile already written out
     auto add_count = [&](uint32_t k, int32_t dst, uint32_t s) {
@@ -278,11 +285,19 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     };
     // write out what waits in LDS: destinations fetched with one vector load BEFORE the first store, so the
     // burst itself never waits on memory; lane s adds combine s's count (at most 64 slots)
-    auto flush = [&]() {
+    auto flush = [&]() __attribute__((always_inline)) {
         if (pend == 0)
             return;
         const int32_t mydst = lane < pend ? ds[k_flushed + lane] : -1;
-        const uint32_t mycnt = lane < pend ? my_cnt[lane] : 0u;
+        __builtin_amdgcn_wave_barrier(); // (compiler only: the lanes' byte stores before other lanes' reads of them)
+        uint32_t mycnt = 0;
+        if (lane < pend)
+        {
+            const lds_u32 *const w = (const lds_u32 *)(my_cnt + (size_t)lane * 64u);
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                mycnt = __builtin_amdgcn_udot4(w[q], 0x01010101u, mycnt, false);
+        }
         for (uint32_t s = 0; s < pend; s++)
         {
             const int32_t dst = __builtin_amdgcn_readlane(mydst, (int)s);
@@ -299,11 +314,9 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     };
     // COMMIT: the combine just done produced node ds[k_comb] with `ch` changes in this lane; set and count wait
     // in LDS for the next burst
-    auto produce = [&](uint32_t ch) {
-        const uint32_t s = wave_sum_bits(ch, 6); // ch <= 32
+    auto produce = [&](uint32_t ch) __attribute__((always_inline)) {
         my_rows[(size_t)pend * 64u] = acc;
-        if (lane == 0)
-            my_cnt[pend] = s;
+        my_cnt[(size_t)pend * 64u + lane] = (uint8_t)ch; // ch <= 32
         pend++;
         k_comb++;
         if (__builtin_expect(pend == a.defer_slots, 0))
@@ -869,7 +882,7 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
     if (commit)
     {
         // what LDS is left after the operand stack holds produced sets until a burst: 1 KiB per slot and wave
-        // (+ 4 bytes for its count); at least one slot (check_depth leaves room for it)
+        // + 64 bytes for its lanes' change counts; at least one slot (check_depth leaves room for it)
         static const uint32_t max_slots = [] {
             const char *e = getenv("LVBGPU_DEFER_SLOTS"); // tests: small bursts
             const int v = e ? atoi(e) : 32;
@@ -878,9 +891,9 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         const uint32_t per_wave_kib = MAX_LDS_BYTES / WALK_WAVES / 1024u;
         if (per_wave_kib < a.stack_depth + 2u)
             return hipErrorInvalidValue;
-        const uint32_t room = per_wave_kib - a.stack_depth - 1u;
+        const uint32_t room = (per_wave_kib - a.stack_depth) * 1024u / (1024u + 64u); // slots of 1 KiB + 64 B
         a.defer_slots = room < max_slots ? room : max_slots;
-        lds += (size_t)WALK_WAVES * a.defer_slots * (64u * sizeof(uint4) + sizeof(uint32_t));
+        lds += (size_t)WALK_WAVES * a.defer_slots * (64u * sizeof(uint4) + 64u);
     }
     // measurement knob: extra dynamic LDS per workgroup caps the waves a CU can hold (160 KiB per CU, 4 waves per
     // workgroup): LVBGPU_LDS_PAD_KB=36 -> 16 waves per CU, 76 -> 8

@@ -165,7 +165,7 @@ struct Gen
 
     // ---- pieces of a program (all arguments wave-uniform)
     // chain head with two clean children
-    __device__ void head2(int32_t row_a, uint32_t flags_a, int32_t row_b, int32_t dst, bool merge_after)
+    __device__ __forceinline__ void head2(int32_t row_a, uint32_t flags_a, int32_t row_b, int32_t dst, bool merge_after)
     {
         if (lane == 0)
         {
@@ -178,7 +178,7 @@ struct Gen
         o.nfresh += 1;
     }
     // one node fed by the running set and one clean row
-    __device__ void one(int32_t row, int32_t dst, bool merge_after = false)
+    __device__ __forceinline__ void one(int32_t row, int32_t dst, bool merge_after = false)
     {
         if (lane == 0)
         {
@@ -189,7 +189,7 @@ struct Gen
         o.ndst += 1;
     }
     // the destination of a merge (its count rides on the token emitted just before: merge_after / merge_last)
-    __device__ void merge_dst(int32_t dst)
+    __device__ __forceinline__ void merge_dst(int32_t dst)
     {
         if (lane == 0)
             o.dsts[o.ndst] = dst;
@@ -199,7 +199,7 @@ struct Gen
     // running set from below and by its clean child: the one given for position 0 of the path (row0, y's own
     // clean child in the new topology), otherwise the child that does not hold y - where a child that is the
     // pruned parent's old place (fix_from) now holds its sister (fix_to).  Lane-parallel, 64 nodes per trip.
-    __device__ void run(int32_t y, uint32_t j0, uint32_t count, int32_t row0, int32_t fix_from, int32_t fix_to, bool merge_last)
+    __device__ __forceinline__ void run(int32_t y, uint32_t j0, uint32_t count, int32_t row0, int32_t fix_from, int32_t fix_to, bool merge_last)
     {
         for (uint32_t base = 0; base < count; base += 64u)
         {
@@ -218,14 +218,14 @@ struct Gen
         o.ntok += count;
         o.ndst += count;
     }
-    __device__ void edit(int32_t node, int32_t l, int32_t r)
+    __device__ __forceinline__ void edit(int32_t node, int32_t l, int32_t r)
     {
         if (lane == 0 && o.nedit < o.cap_e)
             o.edits[o.nedit] = {node, l, r};
         o.nedit += 1;
     }
     // the root's two combines: its clean child (new topology), then the root leaf's own row
-    __device__ void finish(int32_t root_clean_child)
+    __device__ __forceinline__ void finish(int32_t root_clean_child)
     {
         if (root_clean_child >= 0)
             one(root_clean_child, -1);
@@ -266,24 +266,29 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
     }
     // moves != nullptr: nothing is drawn, candidate b IS moves[b] (validated by the host side of
     // lvbgpu_score_moves); everything after the draws is shared
-    lvbgpu_move_dev given{0, -1, -1, -1};
+    // (as scalars: a struct assigned under a condition lived in scratch memory)
+    int32_t given_a = -1, given_b = -1, given_c = -1;
     if (g.moves)
     {
-        given = g.moves[b];
-        kind = given.kind;
+        const lvbgpu_move_dev mv = g.moves[b];
+        kind = mv.kind;
+        given_a = mv.a;
+        given_b = mv.b;
+        given_c = mv.c;
     }
-    ProposalInfo pi{kind, -1, -1, -1, 0, 0, 0, 0};
+    // (the move's description as scalars: as a struct filled field by field it lived in scratch memory)
+    int32_t pi_a = -1, pi_b = -1, pi_c = -1, pi_flag = 0;
     bool unusable = false;
 
     if (kind == 0)
     {
         // ---- NNI: u any internal node, v its parent, swap one child of u with u's sister
-        const int32_t u = g.moves ? given.a : n + (int32_t)rng.below(1, 0, (uint32_t)(nb - n));
-        const bool swap_right = g.moves ? given.b != 0 : (rng.draw(1, 1) >> 63) != 0;
+        const int32_t u = g.moves ? given_a : n + (int32_t)rng.below(1, 0, (uint32_t)(nb - n));
+        const bool swap_right = g.moves ? given_b != 0 : (rng.draw(1, 1) >> 63) != 0;
         const int32_t v = t.par(u), a = (int32_t)t.left[u], bb = (int32_t)t.right[u], c = t.sister(u);
         const int32_t keep = swap_right ? a : bb, moved = swap_right ? bb : a;
-        pi.a = u;
-        pi.flag = swap_right ? 1 : 0;
+        pi_a = u;
+        pi_flag = swap_right ? 1 : 0;
         // edits: v trades c for `moved` (same side), u holds (keep, c)
         {
             const int32_t vl = (int32_t)t.left[v], vr = (int32_t)t.right[v];
@@ -304,7 +309,7 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
     else
     {
         // ---- SPR / TBR: prune src (with its parent sp), graft on the edge above dest
-        int32_t src = given.a, dest = given.b;
+        int32_t src = given_a, dest = given_b;
         if (!g.moves)
         {
             // src: any node but the root and its two children (TreeOperations.c:256-259)
@@ -345,15 +350,15 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
         {
             stamp(1); // drawn
             const int32_t dp = t.par(dest);
-            pi.a = src;
-            pi.b = dest;
+            pi_a = src;
+            pi_b = dest;
 
             int32_t top = src;     // what hangs under sp next to dest
             bool have_acc = false; // a chain inside the moved subtree already feeds sp
-            if (kind == 2 && (int32_t)t.nleaf[src] > 2 && !(g.moves && given.c < 0))
+            if (kind == 2 && (int32_t)t.nleaf[src] > 2 && !(g.moves && given_c < 0))
             {
                 // TBR: re-root the moved subtree on the edge above a random leaf x (not a child of src)
-                int32_t x = given.c;
+                int32_t x = given_c;
                 if (!g.moves)
                 {
                     const int32_t c1 = (int32_t)t.left[src], c2 = (int32_t)t.right[src];
@@ -371,7 +376,7 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                     unusable = true;
                 else
                 {
-                    pi.c = x;
+                    pi_c = x;
                     // path P0 = parent(x) .. Pk = src (P_i = the (i+1)-th ancestor of x); k >= 1
                     const uint32_t k = (uint32_t)(t.dep(x) - t.dep(src)) - 1u;
                     const int32_t p0 = t.par(x), sis_x = t.other(p0, x);
@@ -454,16 +459,19 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                 // not one of them).  Three shapes (TreeOperations.c:302, 330-334: both root-ward paths are dirty):
                 const int32_t oc_dp = dp == root ? -1 : t.other(dp, dest); // dp's clean child once sp has taken dest's place
                 const int32_t oc_pp = t.other(pp, sp);                     // pp's other child (pp keeps it; sp's place goes to ss)
-                auto head_sp = [&](bool merge_after) {
-                    if (have_acc)
-                        e.one(dest, sp, merge_after);
-                    else
-                        e.head2(dest, 0u, top, sp, merge_after);
-                };
+                // the chain's head at sp: fed by dest and, if the moved subtree was recomputed, by the running set, else by its top
+#define LVB_HEAD_SP()                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (have_acc)                                                                                                  \
+            e.one(dest, sp, false);                                                                                    \
+        else                                                                                                           \
+            e.head2(dest, 0u, top, sp, false);                                                                         \
+    } while (0)
                 if (dest != ss && t.inside(dest, ss))
                 {
                     // (1) dest below the sister: one chain sp, dp .. ss, then pp .. (sp's old place is skipped)
-                    head_sp(false);
+                    LVB_HEAD_SP();
                     e.run(dp, 0u, (uint32_t)(t.dep(dp) - t.dep(ss)) + 1u, oc_dp, -1, -1, false);
                     if (pp != root)
                     {
@@ -498,7 +506,7 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                     if (pp == root || m == pp)
                     {
                         // pp is the root or lies on the path from dp: one chain; where it passes pp, sp's place holds ss
-                        head_sp(false);
+                        LVB_HEAD_SP();
                         if (dp != root)
                         {
                             e.run(dp, 0u, (uint32_t)t.dep(dp), oc_dp, sp, ss, false);
@@ -512,7 +520,7 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                         const uint32_t dm = m == root ? 0u : (uint32_t)t.dep(m);
                         const uint32_t len_a = dp == root ? 0u : (uint32_t)t.dep(dp) - dm; // dp .. below M (0: M is dp)
                         const uint32_t len_b = (uint32_t)t.dep(pp) - dm;                     // pp .. below M (>= 1)
-                        head_sp(false);
+                        LVB_HEAD_SP();
                         e.run(dp, 0u, len_a, oc_dp, -1, -1, false);
                         e.head2(ss, TOK_PUSH, oc_pp, pp, len_b == 1u);
                         e.run(pp, 1u, len_b - 1u, -1, -1, -1, true);
@@ -552,16 +560,14 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
         }
         g.cands[b] = cd;
         g.len_out[b] = 0ull; // the walk accumulates into it: cleared here, so a step needs no clearing pass of its own
-        pi.n_edits = (int32_t)e.o.nedit;
-        pi.overflow = overflow ? 1 : 0;
-        pi.ncomb = (int32_t)e.o.ndst;
-        g.info[b] = pi;
+        g.info[b] = ProposalInfo{kind, pi_a, pi_b, pi_c, pi_flag, (int32_t)e.o.nedit, overflow ? 1 : 0, (int32_t)e.o.ndst};
     }
     stamp(4);
 }
 
 } // namespace
 
+#undef LVB_HEAD_SP
 template <typename IdxT, bool IN_LDS>
 __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 {
@@ -591,8 +597,7 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
             for (uint32_t u = 0; u < DEPTH; u++)
             {
                 const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
-                if (i < n16)
-                    v[u] = src4[i];
+                v[u] = src4[i < n16 ? i : n16 - 1u]; // (unconditional: a conditionally filled array went through scratch)
             }
 #pragma unroll
             for (uint32_t u = 0; u < DEPTH; u++)
