@@ -110,19 +110,6 @@ __device__ __forceinline__ uint4 planes_to_nibbles(const uint4 p)
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// Sum of a small per-lane value over the 64 lanes of the wave, computed on the scalar unit:
-// bit b of the sum's binary expansion is weighted popcount(ballot(bit b of v)).
-__device__ __forceinline__ uint32_t wave_sum_bits(uint32_t v, uint32_t nbits)
-{
-    uint32_t total = 0;
-    for (uint32_t b = 0; b < nbits; b++)
-    {
-        const uint64_t m = __builtin_amdgcn_ballot_w64(((v >> b) & 1u) != 0u);
-        total += (uint32_t)__builtin_popcountll(m) << b;
-    }
-    return total;
-}
-
 // What the waves of a launch hand one another (partial lengths, partial change counts, arrival ticks) is written by
 // agent-scope atomics and read by agent-scope atomic loads: those are performed where all XCDs see them, so the
 // hand-over needs ORDER only - this wave's atomics acknowledged before its tick is sent - and no cache written back or
@@ -273,7 +260,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                                       (size_t)wave * a.defer_slots * 64u);
     uint32_t pend = 0;      // combines waiting in LDS
     uint32_t k_flushed = 0; // combines of this tile already written out
-    auto add_count = [&](uint32_t k, int32_t dst, uint32_t s) {
+    auto add_count = [&](uint32_t k, int32_t dst, uint32_t s) __attribute__((always_inline)) {
         if (a.tmp_changes)
             atomicAdd(a.tmp_changes + (size_t)cand * a.tmp_stride + k, (unsigned long long)s); // settled by the candidate's last wave
         else
@@ -390,7 +377,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
             auto tok_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)mytok, (int)j); };
 
             // rare: what follows token j's own combine
-            auto post = [&](uint32_t j) {
+            auto post = [&](uint32_t j) __attribute__((always_inline)) {
                 const uint32_t tok = tok_at(j);
                 for (uint32_t m = (tok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK; m != 0; m--)
                 {
@@ -411,7 +398,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                     acc = ones;
                 }
             };
-            auto step = [&](uint32_t j, uint32_t flagged, const uint4 cur) {
+            auto step = [&](uint32_t j, uint32_t flagged, const uint4 cur) __attribute__((always_inline)) {
                 const uint32_t before = nonempty;
                 acc = fitch_planes(acc, cur, nonempty);
                 if constexpr (COMMIT)
