@@ -8,13 +8,15 @@ Workload (BASELINE.json configs[2], the configuration the headline metric is quo
 
 One "step" is SURVEY.md 8(d)(i)'s unit: batch submit -> lengths on the host.  Per step the library draws B
 random neighbours of the resident tree, builds their programs and scores them on the GPU, and the B lengths
-are on the host before the next step starts (`lvbgpu_propose_score`).  Alignment and current tree are in HBM
-when the timed region starts; nothing else is.  `value` = candidates of all ranks / wall time of K steps.
+come back to the host; two steps are in flight (`lvbgpu_chains_submit` / `_collect`: while the host reads step
+i's lengths, step i + 1 is on the device).  Alignment and current tree are in HBM when the timed region starts;
+nothing else is.  `value` = candidates of all ranks / wall time of K steps.
 
 Beside it, in the same JSON line:
+  one_at_a_time the same step with ONE batch in flight (`lvbgpu_propose_score`): a step's latency
   kernel_only   the scoring kernel alone, replaying resident pre-built batches (round 1's headline)
-  roofline      the dominant kernel (fitch_walk<false,false>) against the L2 -> CU path that bounds it: duration
-                from HIP events around every walk of the timed region, ceiling from the guide (34.5 TB/s) and
+  roofline      the dominant kernel (fitch_walk<false, false, 0>) against the L2 -> CU path that bounds it: duration
+                from HIP events around every 4th walk of the timed region, ceiling from the guide (34.5 TB/s) and
                 from a pure-load probe with the walk's access pattern run in this process; `hbm` = measured HBM
                 traffic (rocprofv3 PMC, profiles/traffic.json) over the same duration against 8 TB/s
   mixed_walk    the same measurements on a tree mixed by >= 3000 accepted moves (longer dirty paths), with the
@@ -22,7 +24,8 @@ Beside it, in the same JSON line:
   cpu_baseline  LVB's own CPU path (the compiled reference, oracle/_ref) on the SAME tree and neighbourhood
                 as the headline leg, one core and all cores
   shapes        B = 256 / 1024 / 16 384 and the i.i.d.-uniform alignment (SURVEY.md 8d "U")
-  anneal        best-length-vs-wallclock of the batched SA host
+  anneal        best length against the wall clock: 32 chains annealing on the GPU (starting temperatures included),
+                one chain alone, and the reference PROGRAM annealing the same alignment for a bounded time
 
 For N > 1 every rank is an independent restart (own seed, own start tree, own candidates) on its own GPU; the
 only collective is the min-reduce of the best length (`lvbgpu_allreduce_min`, RCCL).  Started without
