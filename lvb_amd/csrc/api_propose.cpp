@@ -628,14 +628,12 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     }
     // a pinned slot: [flag][picks][k x (descriptor + rewrites)]
     const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
-    const size_t o_pick = 64, o_out = 64 + align16((size_t)MAX_CHAINS * 4);
+    const size_t o_out = 64 + align16((size_t)MAX_CHAINS * 4); // (the flag, a gap the picks used to lie in, the records)
     int slot = 0;
     HIPCHK(ctx, take_pick_slot(ctx, &slot));
     HIPCHK(ctx, ctx->h_pick[slot].reserve(o_out + (size_t)MAX_CHAINS * out_stride));
     char *h = (char *)ctx->h_pick[slot].p;
     uint32_t *flag = (uint32_t *)h;
-    uint32_t *h_picks = (uint32_t *)(h + o_pick);
-    memcpy(h_picks, where.data(), (size_t)k * 4);
     const uint32_t seq = ++ctx->pick_seq;
     const size_t old_done = ctx->d_done.cap;
     HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
@@ -650,7 +648,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     //    beside the commit walk; as the first workgroups of the table rebuild's launch where there is one (1b), else
     //    as a launch of its own
     GatherArgs gat{};
-    gat.pick = h_picks;
+    memcpy(gat.pick_idx, where.data(), (size_t)k * 4);
     gat.k = (uint32_t)k;
     gat.info = (const ProposalInfo *)ps.d_pinfo.p;
     gat.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
@@ -675,7 +673,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         ra.nb = ctx->nb;
         ra.K = ctx->gen_kmax;
         ra.leaf_order_len = (uint32_t)ctx->n;
-        ra.pick = h_picks;
+        memcpy(ra.pick_idx, where.data(), (size_t)k * 4);
         ra.cands = (const CandDesc *)bt->d_prog.p;
         ra.info = (const ProposalInfo *)ps.d_pinfo.p;
         ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
@@ -696,7 +694,8 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     }
     HIPCHK(ctx, ctx->d_len.reserve(8));
     WalkArgs a = resident_args(ctx, bt->d_prog.p, bt->off_toks, bt->off_dsts, ctx->d_len.p, (uint32_t)k, 1);
-    a.pick = h_picks;
+    a.use_pick = 1;
+    memcpy(a.pick_idx, where.data(), (size_t)k * 4);
     a.s_all_out = (unsigned long long *)ctx->d_scalars;
     a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
     a.tmp_stride = (uint32_t)(ctx->nb + 1);

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     const uint32_t tile_begin = group * a.tiles_per + (group < a.tiles_rem ? group : a.tiles_rem);
     const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
 
-    const CandDesc cd = a.cands[a.pick ? a.pick[cand] : cand];
+    const CandDesc cd = a.cands[(COMMIT && a.use_pick) ? a.pick_idx[cand] : cand];
     // which resident tree: node numbers from bias_from on (the internal nodes) move by the chain's row block
     const uint32_t chain = cd.flags >> CAND_CHAIN_SHIFT;
     const uint32_t row_bias = chain * a.chain_rows;

@@ -15,7 +15,7 @@ __device__ __forceinline__ void gather_acknowledged()
 
 struct GatherArgs
 {
-    const uint32_t *pick;          // batch positions of the picked candidates
+    uint32_t pick_idx[MAX_CHAINS]; // batch positions of the picked candidates (in the kernel arguments)
     uint32_t k;
     const ProposalInfo *info;
     const lvbgpu_edit_dev *edits;
@@ -30,7 +30,7 @@ struct GatherArgs
 // pick j by one wave (lane = 0..63): word by word, as system-scope stores (written through to the host)
 __device__ __forceinline__ void gather_one_pick(const GatherArgs &a, uint32_t j, uint32_t lane)
 {
-    const uint32_t g = a.pick[j];
+    const uint32_t g = a.pick_idx[j];
     const ProposalInfo pi = a.info[g];
     uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + (size_t)j * a.out_stride);
     constexpr uint32_t PI_WORDS = sizeof(ProposalInfo) / 4u;

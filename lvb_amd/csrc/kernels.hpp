@@ -98,10 +98,13 @@ struct WalkArgs
     // with the difference to what those nodes held before, and clears tmp_changes and done_count again - no
     // separate zeroing launch in front of a commit.
     unsigned long long *tmp_changes;
-    // several candidates committed in one launch (one per chain): launch candidate j walks cands[pick[j]] (pick ==
-    // null: cands[j]), accumulates in tmp_changes + j * tmp_stride and ticks done_count[j]; the last of ITS waves
-    // settles that candidate.  A single commit is j = 0, tmp_stride irrelevant.
-    const uint32_t *pick;
+    // several candidates committed in one launch (one per chain): launch candidate j walks cands[pick_idx[j]]
+    // (use_pick == 0: cands[j]), accumulates in tmp_changes + j * tmp_stride and ticks done_count[j]; the last of ITS
+    // waves settles that candidate.  A single commit is j = 0, tmp_stride irrelevant.  The picks travel IN the kernel
+    // arguments: from pinned host memory every commit wave (and the table rebuild, and the gather) began with a read
+    // over the host link.
+    uint32_t use_pick;
+    uint32_t pick_idx[MAX_CHAINS];
     uint32_t tmp_stride;
     uint32_t flip; // walk each XCD's share of the items from its far end (filled by launch_walk)
     // COMMIT: produced sets and their counts wait in LDS, this many per wave, and go out in bursts (filled by
@@ -204,7 +207,7 @@ struct RebuildArgs
     uint32_t table_stride, idx_bytes;
     int32_t n, nb, K;
     uint32_t leaf_order_len;
-    const uint32_t *pick;    // batch positions of the picked candidates
+    uint32_t pick_idx[MAX_CHAINS]; // batch positions of the picked candidates (in the kernel arguments, see WalkArgs)
     const CandDesc *cands;   // their descriptors (flags carry the chain)
     const ProposalInfo *info;
     const lvbgpu_edit_dev *edits;

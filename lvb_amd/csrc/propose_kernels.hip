@@ -658,7 +658,7 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
         return;
     }
     const uint32_t j = blockIdx.x - ga.k;
-    const uint32_t cand = g.ext ? 0u : g.pick[j];
+    const uint32_t cand = g.ext ? 0u : g.pick_idx[j];
     const uint32_t chain = g.ext ? (uint32_t)g.ext[j].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
     IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
     const int32_t n = g.n, nb = g.nb, K = g.K;
