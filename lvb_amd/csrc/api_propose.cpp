@@ -375,8 +375,14 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         const char *e = getenv("LVBGPU_WATCHER");
         return !(e && e[0] == '0');
     }();
-    ps.watched = allow_watcher && !ctx->pslot[1 - slot].in_flight &&
-                 choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves) <= WATCH_MAX_GROUPS;
+    // (pipelined batches of a small launch - below WATCH_PIPELINED_MAX_ITEMS waves - take the watcher too: the copy
+    // stream's two events and its copy cost such a step more than the hand-over lengthens its walk: 64 x 10k NNI,
+    // B = 1024: 34 -> 61 M candidates/s; 500 x 50k, B = 256: 8.2 -> 9.4, B = 1024: +4 %; at B = 4096 the two are equal
+    // within 1 % and the walk is 1.6 us shorter without the hand-over)
+    constexpr uint64_t WATCH_PIPELINED_MAX_ITEMS = 32768;
+    const uint32_t groups_now = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
+    ps.watched = allow_watcher && groups_now <= WATCH_MAX_GROUPS &&
+                 (!ctx->pslot[1 - slot].in_flight || (uint64_t)B * groups_now < WATCH_PIPELINED_MAX_ITEMS);
     if (ps.watched)
     {
         if (!ps.h_flag.p)
