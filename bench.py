@@ -81,6 +81,9 @@ def parse_args(argv=None):
                     help="run the batched SA host end to end for this long and report best-length-vs-wallclock (0 = skip)")
     ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
     ap.add_argument("--anneal-chains", type=int, default=32, help="independent chains stepped together on the GPU")
+    ap.add_argument("--anneal-groups", type=int, default=4,
+                    help="the chains are dealt to this many groups that anneal side by side, each with a context and a host "
+                         "thread of its own (lvbhost_anneal_chain_groups); 1 = all chains lock-stepped in one context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 / 16 384 and uniform-alignment legs")
     ap.add_argument("--headline-only", action="store_true",
@@ -101,13 +104,16 @@ def spawn_ranks(args) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, errs = [], []
+    logdir = Path(tempfile.mkdtemp(prefix="lvb_bench_ranks_"))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stderr is this process's; the other ranks' goes to a file each, relayed if the run fails
+        errs.append(None if r == 0 else open(logdir / f"rank{r}.stderr", "w+"))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r], text=True))
     out0, failed = "", []
     deadline = time.time() + 3000
     try:
@@ -123,7 +129,19 @@ def spawn_ranks(args) -> int:
                 p.kill()
     if failed:
         print(f"bench.py: rank(s) {failed} failed", file=sys.stderr)
+        for r, f in enumerate(errs):
+            if f is not None:
+                f.seek(0)
+                tail = f.read()[-4000:]
+                if tail.strip():
+                    print(f"---- stderr of rank {r} (tail)\n{tail}", file=sys.stderr)
         sys.stdout.write(out0)
+    for f in errs:
+        if f is not None:
+            f.close()
+    import shutil
+    shutil.rmtree(logdir, ignore_errors=True)
+    if failed:
         return 1
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
     if not lines:
@@ -133,30 +151,72 @@ def spawn_ranks(args) -> int:
     return 0
 
 
+def timed_steps(run, synchronize, ranks, steps: int, seed0: int, reduce_best=None, warm_best: int = 1 << 40, before_t0=None):
+    """The timed region's skeleton, shared by the GPU flow (submit_to_lengths) and its CPU rehearsal (--dry-ranks):
+
+        [untimed: one min-reduce + barrier]  t0  K steps  min-reduce of the best length  synchronize  barrier  t1
+
+    The untimed reduce is there because a communicator sets itself up lazily in its FIRST collective (RCCL: channel
+    and proxy set-up; likewise the first torch barrier after it): at N > 1 that would otherwise land in a timed region
+    that is a few milliseconds long and be read as a scaling loss.  The in-region reduce is timed on its own
+    (`reduce_ms`); `order` records what ran in which order (tests/test_bench_launch.py checks it)."""
+    order = []
+    if reduce_best is not None:
+        reduce_best(int(warm_best))
+        order.append("reduce:warmup")
+    synchronize()
+    ranks.barrier()
+    order.append("barrier")
+    if before_t0:
+        before_t0()
+    t0 = time.perf_counter()
+    order.append("t0")
+    best = run(steps, seed0)
+    t_steps = time.perf_counter() - t0
+    order.append("steps")
+    tr = time.perf_counter()
+    best_global = reduce_best(best) if reduce_best is not None else best
+    reduce_ms = 1e3 * (time.perf_counter() - tr)
+    order.append("reduce:timed")
+    synchronize()
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    order.append("t1")
+    return {"elapsed_local": elapsed, "elapsed_s": ranks.max_over_ranks(elapsed), "steps_s_local": t_steps,
+            "reduce_ms": reduce_ms if reduce_best is not None else 0.0, "best": best_global, "best_local": best, "order": order}
+
+
 def dry_rank_main(args) -> None:
-    """The rank flow of rank_main with the GPU taken out: rendezvous, barriers, max-over-ranks timing and a
-    min-reduce of a stand-in best length, all over gloo."""
+    """The rank flow of rank_main with the GPU taken out: rendezvous, the timed region's skeleton (timed_steps: warm-up
+    reduce, barriers, max-over-ranks timing) and a min-reduce of a stand-in best length, all over gloo."""
     from lvb_amd.launch import Ranks
     ranks = Ranks(backend="gloo")
     if ranks.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}")
-    ranks.barrier()
-    t0 = time.perf_counter()
-    best_local = 1000 + 7 * ((ranks.rank + 1) % ranks.world)    # the minimum sits on the last rank
-    best = -ranks.max_over_ranks(-float(best_local))
-    ranks.barrier()
-    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    reduces = []
+
+    def reduce_best(best_local: int) -> int:
+        reduces.append(int(best_local))
+        return int(-ranks.max_over_ranks(-float(best_local)))
+
+    def run(n, seed):   # stands in for n device steps; the minimum sits on the last rank
+        return 1000 + 7 * ((ranks.rank + 1) % ranks.world)
+
+    head = timed_steps(run, lambda: None, ranks, args.steps, 1000, reduce_best if ranks.world > 1 else None)
+    per_rank = ranks.all_values(float(ranks.rank + 1))
     seeds = ranks.sum_over_ranks(ranks.restart_seed(args.seed))
     if ranks.rank == 0:
         print(json.dumps({
             "metric": "candidate trees scored/sec (Fitch getplen), 500 taxa x 50k sites", "value": 0.0,
             "unit": "trees/s", "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * head["elapsed_s"] / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic", "dry": True,
             "config": {"workload": "dry run of the rank flow: no GPU, nothing scored",
                        "parallelism": f"{ranks.world} ranks over gloo (on GPUs: one independent restart per GPU, "
                                       "best length min-reduced by lvbgpu_allreduce_min over RCCL)",
-                       "best_length": int(best), "seed_sum": seeds}}), flush=True)
+                       "best_length": int(head["best"]), "seed_sum": seeds, "reduce_ms": head["reduce_ms"],
+                       "order": head["order"], "reduces": len(reduces), "per_rank": per_rank,
+                       "reducer": "gloo (dry)", "comm_size": ranks.world}}), flush=True)
     ranks.close()
 
 
@@ -213,21 +273,18 @@ def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, se
         return best
 
     run(settle, (seed0 - 100000) & 0x7FFFFFFF)
-    run(warmup, (seed0 - 1000) & 0x7FFFFFFF)
-    ctx.synchronize()
-    ranks.barrier()
-    ctx.walk_timing(WALK_TIMING_EVERY)   # a pair of events costs the step ~20 us: sample
+    warm_best = run(warmup, (seed0 - 1000) & 0x7FFFFFFF)
     gc_was = gc.isenabled()
-    gc.disable()                         # a collection inside a few-millisecond region would be most of it
-    t0 = time.perf_counter()
-    best = run(steps, seed0)
-    t_steps = time.perf_counter() - t0
-    best_global = reduce_best(best) if reduce_best else best
-    ctx.synchronize()
-    ranks.barrier()
-    elapsed = time.perf_counter() - t0
+
+    def before_t0():
+        ctx.walk_timing(WALK_TIMING_EVERY)   # a pair of events costs the step ~20 us: sample
+        gc.disable()                         # a collection inside a few-millisecond region would be most of it
+
+    head = timed_steps(run, ctx.synchronize, ranks, steps, seed0, reduce_best,
+                       warm_best if warmup > 0 else 1 << 40, before_t0)
     if gc_was:
         gc.enable()
+    best, best_global, t_steps, elapsed = head["best_local"], head["best"], head["steps_s_local"], head["elapsed_local"]
     walk_ms, walks = ctx.walk_timing_read()
     ctx.walk_timing(False)
     # what those batches cost: the draw is a function of (seed, b), so re-drawing a few of the timed seeds
@@ -239,8 +296,8 @@ def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, se
         st.append(ctx.proposal_stats())
     mean = lambda key: float(np.mean([x[key] for x in st])) if st else 0.0
     return {
-        "elapsed_s": ranks.max_over_ranks(elapsed), "steps_s_local": t_steps,
-        "launch_ms": walk_ms / max(walks, 1), "walks": walks, "best": best_global, "best_local": best,
+        "elapsed_s": head["elapsed_s"], "elapsed_local": elapsed, "steps_s_local": t_steps, "reduce_ms": head["reduce_ms"],
+        "order": head["order"], "launch_ms": walk_ms / max(walks, 1), "walks": walks, "best": best_global, "best_local": best,
         "alg_bytes": mean("algorithmic_bytes"), "mean_dirty": mean("dirty_nodes") / max(mean("candidates"), 1.0),
         "scored_per_step": mean("candidates"),
     }
@@ -537,7 +594,9 @@ def rank_main(args) -> None:
 
     # ---- the timed region: K steps of submit -> lengths on the host (+ the min-reduce over ranks)
     head = submit_to_lengths(ctx, ranks, B, kind, args.steps, args.warmup, 1000, reduce_best, settle=args.settle)
-    total_trees = head["scored_per_step"] * args.steps * world if head["scored_per_step"] else B * args.steps * world
+    per_step = head["scored_per_step"] if head["scored_per_step"] else B
+    total_trees = per_step * args.steps * world
+    per_rank = ranks.all_values(per_step * args.steps / head["elapsed_local"])   # each rank's own clock around ITS region
     print(f"[rank {rank}] timed region {1e3 * head['elapsed_s']:.2f} ms for {args.steps} steps "
           f"(local loop {1e3 * head['steps_s_local']:.2f} ms), walk {head['launch_ms'] * 1e3:.1f} us x {head['walks']}",
           file=sys.stderr)
@@ -567,6 +626,12 @@ def rank_main(args) -> None:
             "parallelism": f"{world} independent restart(s), one per GPU; best length min-reduced over RCCL"
                            + ("" if world == 1 else (" by lvbgpu_allreduce_min" if own_comm else " (torch fallback)")),
             "best_length": head["best"], "min_len_tree": min_len, "setup_seconds": round(setup_s, 2),
+            "reducer": "none (one rank)" if world == 1 else ("lvbgpu_allreduce_min (the library's own RCCL communicator)"
+                                                             if own_comm else "torch.distributed all_reduce (fallback)"),
+            "comm_size": ctx.comm_size() if own_comm else world, "reduce_ms": round(head["reduce_ms"], 4),
+            "per_rank_trees_per_s": [round(v) for v in per_rank],
+            "timed_region": "one untimed min-reduce + barrier, t0, K steps, min-reduce of the best length (reduce_ms), "
+                            "synchronize, barrier, t1; value = all ranks' candidates / max over ranks of (t1 - t0)",
         },
         "roofline": roofline_block(ctx, B, head["alg_bytes"], head["launch_ms"], head["mean_dirty"],
                                    load_traffic(args, False)),
@@ -635,16 +700,21 @@ def rank_main(args) -> None:
             p.log_cap = 4096
             return p
         R = max(1, args.anneal_chains)
-        actx = api.FitchContext(text_rows=rows, device=ranks.device)
+        G = max(1, min(args.anneal_groups, R))
+        actxs = [api.FitchContext(text_rows=rows, device=ranks.device) for _ in range(G)]
+        actx = actxs[0]
         atrees = [host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100 + c) for c in range(R)]
-        res, log = host.anneal_chains(actx, atrees, [params_for(c) for c in range(R)])
+        if G > 1:
+            res, log = host.anneal_chain_groups(actxs, atrees, [params_for(c) for c in range(R)])
+        else:
+            res, log = host.anneal_chains(actx, atrees, [params_for(c) for c in range(R)])
         anneal_log = list(log)
         keep = log[:: max(1, len(log) // 12)] + log[-1:]
         secs = max(r["seconds"] for r in res)
         tot = lambda k: sum(r[k] for r in res)
         if rank == 0:
             out["anneal"] = {
-                "chains": R, "seconds": round(secs, 3),
+                "chains": R, "groups": G, "seconds": round(secs, 3),
                 "best_length": min(r["best_length"] for r in res), "best_lengths": [r["best_length"] for r in res],
                 "start_lengths": [r["start_length"] for r in res],
                 "scored": tot("scored"), "consumed": tot("consumed"), "accepted": tot("accepted"),
@@ -653,8 +723,9 @@ def rank_main(args) -> None:
                 "device_fraction": round(res[0]["seconds_device"] / secs, 3), "batch": args.anneal_batch,
                 "temperatures": [r["temperatures"] for r in res], "frozen": sum(r["frozen"] for r in res),
                 "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
-                "what": f"{R} independent chains (own seeds and start trees) stepped together: one generator launch, one "
-                        "walk and one commit walk per device step for all of them; starting temperatures included",
+                "what": f"{R} independent chains (own seeds and start trees) in {G} group(s) side by side (a context and a host "
+                        "thread per group); a group's chains are stepped together: one generator launch, one walk and one "
+                        "commit walk per device step for all of them; starting temperatures included",
             }
             # one chain alone, for comparison: the same loop with R = 1
             fresh = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100)
@@ -666,7 +737,8 @@ def rank_main(args) -> None:
                 "scored_per_s": round(one[0]["scored"] / one[0]["seconds"]), "frozen": one[0]["frozen"]}
         for t in atrees:
             t.close()
-        actx.close()
+        for c in actxs:
+            c.close()
     # LVB's own CPU path last: 32 reference processes at once leave the host's CPU quota throttled for a while, which
     # the legs above (host threads beside the GPU) would feel
     if extras and not args.no_cpu_baseline and args.dist == "tree":

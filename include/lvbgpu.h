@@ -251,6 +251,14 @@ int lvbgpu_timer_start(lvbgpu_ctx *ctx);
 int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms); /* synchronises */
 int lvbgpu_synchronize(lvbgpu_ctx *ctx);
 void *lvbgpu_stream(lvbgpu_ctx *ctx); /* hipStream_t, for interop */
+/* Where the library polls for the device itself (a step's lengths, a watcher's flags, the picked moves of a commit)
+ * it gives up after this many seconds and the call returns LVBGPU_E_HIP with the stream's state in
+ * lvbgpu_last_error(): a stuck stream does not become an endless host spin.  Default 30 s (or LVBGPU_WAIT_SECONDS
+ * when the context is created).  What was waited for is lost: synchronise and resubmit, or destroy the context. */
+int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds);
+/* test hook: keeps the context's stream busy for about `ms` milliseconds (1 .. 2000) with a kernel that only watches
+ * the clock, so that what is enqueued behind it cannot complete before then */
+int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms);
 
 /* per-kernel timing for the roofline line: while enabled (every > 0), every `every`-th scoring walk the
  * library launches (batch launches, lvbgpu_score_batch, lvbgpu_propose_score*, lvbgpu_score_moves) is
@@ -272,6 +280,9 @@ int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave, int32_t r
 int lvbgpu_comm_available(void);
 int lvbgpu_comm_unique_id(void *id128);
 int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const void *id128);
+int lvbgpu_comm_size(const lvbgpu_ctx *ctx); /* ranks of the context's communicator; 1 without one */
+/* values of 2^47 and more (a rank that has no length yet passes INT64_MAX) take part as "no length": they lose
+ * against every real length, come back as INT64_MAX if no rank had one, and then *argmin_rank = -1 */
 int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value /* in: local best, out: global best */,
                          int32_t *argmin_rank /* may be NULL */);
 /* the other sharding of the path (the reference's OpenMP site slices, TreeEvaluation.c:95-97): rank r

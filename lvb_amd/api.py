@@ -92,9 +92,12 @@ SIGNATURES = {
     "lvbgpu_walk_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lvbgpu_probe_l2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "lvbgpu_stream": (C.c_void_p, [C.c_void_p]),
+    "lvbgpu_set_wait_limit": (C.c_int, [C.c_void_p, C.c_double]),
+    "lvbgpu_debug_stall": (C.c_int, [C.c_void_p, C.c_int32]),
     "lvbgpu_comm_available": (C.c_int, []),
     "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lvbgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lvbgpu_comm_size": (C.c_int, [C.c_void_p]),
     "lvbgpu_allreduce_min": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "lvbgpu_allreduce_sum": (C.c_int, [C.c_void_p, _i64p, C.c_int32]),
     "lvbgpu_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -206,6 +209,12 @@ class FitchContext:
         self.n = int(self.lib.lvbgpu_n(h))
         self.nwords = int(self.lib.lvbgpu_nwords(h))
         self.nbranches = 2 * self.n - 3
+
+    def last_error(self) -> str:
+        return (self.lib.lvbgpu_last_error(self.h) or b"").decode()
+
+    def set_wait_limit(self, seconds: float) -> None:
+        self._chk(self.lib.lvbgpu_set_wait_limit(self.h, float(seconds)))
 
     def _chk(self, rc: int) -> None:
         if rc != 0:
@@ -416,6 +425,9 @@ class FitchContext:
     def comm_init(self, nranks: int, rank: int, unique_id: bytes) -> None:
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self.lib.lvbgpu_comm_init(self.h, nranks, rank, buf))
+
+    def comm_size(self) -> int:
+        return int(self.lib.lvbgpu_comm_size(self.h))
 
     def allreduce_sum(self, values) -> np.ndarray:
         """Site-axis sharding: per-candidate partial lengths in, their sums over the ranks out."""

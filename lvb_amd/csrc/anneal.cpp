@@ -272,7 +272,7 @@ extern "C" int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree,
                 }
             }
         }
-        ratio = prop_pos ? (double)acc_pos / prop_pos : 0.0;
+        ratio = (double)acc_pos / prop_pos; // 0/0 gives NaN and ends the loop, as in the reference (StartingTemperature.c:170)
         t += 0.00001; // increment_size
         if (t >= 1 || t <= 0)
         {

@@ -348,7 +348,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         }
         HIPCHK(ctx, hipEventRecord(ctx->wt_ev[2 * ctx->wt_pending], ctx->stream));
     }
-    HIPCHK(ctx, launch_walk(a, false, ctx->stream));
+    HIPCHK(ctx, launch_walk(a, false, ctx->stream, &ctx->flip_counter));
     if (timed)
     {
         HIPCHK(ctx, hipEventRecord(ctx->wt_ev[2 * ctx->wt_pending + 1], ctx->stream));
@@ -364,18 +364,13 @@ namespace lvbgpu_detail
 static hipError_t wait_for_direct_step(lvbgpu_ctx *ctx)
 {
     const uint32_t *flag = (const uint32_t *)ctx->h_step.p;
-    for (uint32_t spins = 1;; spins++)
+    const WaitClock clock(ctx->wait_limit_s);
+    for (uint32_t spins = 1;; spins++) // (memory only: hipStreamQuery can block behind a running kernel, api_propose.cpp)
     {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->step_seq)
             return hipSuccess;
-        if ((spins & 1023u) == 0)
-        {
-            // a finished (or failed) stream ends the wait whatever the flag says: after the kernel
-            // everything it wrote is visible
-            const hipError_t q = hipStreamQuery(ctx->stream);
-            if (q != hipErrorNotReady)
-                return q;
-        }
+        if ((spins & 1023u) == 0 && clock.expired())
+            return hipErrorNotReady; // (fail_hip words it: the wait limit)
     }
 }
 } // namespace lvbgpu_detail

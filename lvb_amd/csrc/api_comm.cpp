@@ -92,6 +92,8 @@ extern "C" int lvbgpu_comm_init(lvbgpu_ctx *ctx, int nranks, int rank, const voi
     return LVBGPU_OK;
 }
 
+extern "C" int lvbgpu_comm_size(const lvbgpu_ctx *ctx) { return ctx && ctx->comm ? ctx->comm_size : 1; }
+
 extern "C" int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value, int32_t *argmin_rank)
 {
     if (!ctx || !value)
@@ -101,7 +103,11 @@ extern "C" int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value, int32_t *ar
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // one 8-byte min over xGMI finds the best length; a second one over (length, rank) keys
     // names a rank that holds it.  Lengths are < 2^47 (MAX_M * 2 * MAX_N), ranks < 2^16.
-    long long vals[2] = {(long long)*value, ((long long)*value << 16) | (long long)ctx->comm_rank};
+    // A rank without a length yet (INT64_MAX, anything from 2^47 on) takes part with the largest key: the key is built
+    // in unsigned arithmetic from a clamped value, so nothing overflows.
+    constexpr int64_t NO_LENGTH = (int64_t)1 << 47;
+    const int64_t mine = *value >= NO_LENGTH || *value < 0 ? NO_LENGTH : *value;
+    long long vals[2] = {(long long)mine, (long long)(((uint64_t)mine << 16) | (uint64_t)(ctx->comm_rank & 0xFFFF))};
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm.p, vals, 16, hipMemcpyHostToDevice, ctx->stream));
     const int r = g_rccl.AllReduce(ctx->d_comm.p, ctx->d_comm.p, 2, NCCL_INT64, NCCL_MIN, ctx->comm, ctx->stream);
     if (r != 0)
@@ -109,9 +115,9 @@ extern "C" int lvbgpu_allreduce_min(lvbgpu_ctx *ctx, int64_t *value, int32_t *ar
                          std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
     HIPCHK(ctx, hipMemcpyAsync(vals, ctx->d_comm.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *value = vals[0];
+    *value = vals[0] >= NO_LENGTH ? INT64_MAX : vals[0];
     if (argmin_rank)
-        *argmin_rank = (int32_t)(vals[1] & 0xFFFF);
+        *argmin_rank = vals[0] >= NO_LENGTH ? -1 : (int32_t)(vals[1] & 0xFFFF);
     return LVBGPU_OK;
 }
 

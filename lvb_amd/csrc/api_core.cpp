@@ -18,13 +18,20 @@ int hip_status_noctx(hipError_t e, const char *what)
 }
 
 // end of a search step on the context's stream
+// Small steps are polled for (the runtime's wake-up costs ~10 us), big ones sleep between polls; either way the wait
+// ends at the context's limit with hipErrorNotReady, which fail_hip words as what it is.
 hipError_t wait_for_step(lvbgpu_ctx *ctx, int32_t B)
 {
-    if (B > SPIN_WAIT_MAX_B)
-        return hipStreamSynchronize(ctx->stream);
+    const WaitClock clock(ctx->wait_limit_s);
     hipError_t q;
+    uint32_t spins = 0;
     while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady)
-        ;
+    {
+        if (B > SPIN_WAIT_MAX_B)
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if ((++spins & 1023u) == 0 && clock.expired())
+            break;
+    }
     return q;
 }
 
@@ -85,6 +92,9 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     ctx->stride4 = ctx->stride_words / 2;
     if (const char *tw = getenv("LVBGPU_TARGET_WAVES"))
         ctx->target_waves = (uint32_t)std::max(1, atoi(tw));
+    if (const char *wl = getenv("LVBGPU_WAIT_SECONDS"))
+        if (atof(wl) > 0.0)
+            ctx->wait_limit_s = atof(wl);
     // (row offsets are 64-bit in the kernels: the tree block is limited by HBM, not by index width)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
@@ -834,4 +844,23 @@ extern "C" int lvbgpu_synchronize(lvbgpu_ctx *ctx)
 }
 
 extern "C" void *lvbgpu_stream(lvbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds)
+{
+    if (!ctx || !(seconds > 0.0))
+        return LVBGPU_E_ARG;
+    ctx->wait_limit_s = seconds;
+    return LVBGPU_OK;
+}
+
+// test hook for the wait limit: keeps the context's stream busy for about `ms` milliseconds (bounded: <= 2000) with a
+// kernel that does nothing but watch the clock, so that a step enqueued behind it cannot complete before then
+extern "C" int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms)
+{
+    if (!ctx || ms < 1 || ms > 2000)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, launch_stall(ctx->stream, (uint32_t)ms));
+    return LVBGPU_OK;
+}
 

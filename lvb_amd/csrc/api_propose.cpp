@@ -245,6 +245,8 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         HIPCHK(ctx, hipEventCreateWithFlags(&ps.done_ev, hipEventDisableTiming));
     if (!ps.walk_ev)
         HIPCHK(ctx, hipEventCreateWithFlags(&ps.walk_ev, hipEventDisableTiming));
+    if (!ps.gen_ev)
+        HIPCHK(ctx, hipEventCreateWithFlags(&ps.gen_ev, hipEventDisableTiming));
     lvbgpu_batch *bt = ps.batch;
     const size_t o_t = align16((size_t)B * sizeof(CandDesc));
     const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
@@ -419,6 +421,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         }
     }
     ps.in_flight = true;
+    ps.submit_ord = ++ctx->submits;
     if (k == 1 && draws[0].chain == guard.sel)
         ps.p_B = B; // lvbgpu_proposal_edits may name its candidates (slot 0, once collected)
     return LVBGPU_OK;
@@ -434,11 +437,17 @@ int propose_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ps.in_flight = false;
     // this batch alone: whatever was enqueued behind it (the other slot's batch, commits) is not waited for
+    const WaitClock clock(ctx->wait_limit_s);
     if (ps.watched)
     {
         const uint32_t *flag = (const uint32_t *)ps.h_flag.p;
         // every watcher wave sets its own word: all of them, in any order (a word still behind is re-read, the ones
         // before it were seen complete)
+        // (Nothing but memory is polled here.  The loop used to ask hipStreamQuery every few thousand spins whether the
+        // stream had drained or failed; measured on MI355X / ROCm 7.2 that call can BLOCK until the kernel at the head
+        // of the stream has finished - with a 400 ms kernel in front it returned after 400 ms - and it serialises
+        // host threads that drive other contexts.  A wait that cannot be trusted to return cannot be bounded by it: the
+        // clock alone ends this one.)
         uint32_t seen = ps.seq, w = 0;
         for (uint32_t spins = 1; w < WATCH_WAVES; spins++)
         {
@@ -450,16 +459,11 @@ int propose_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
             }
             if (seen == 0xFFFFFFFFu)
                 break;
-            if ((spins & 4095u) == 0)
+            if ((spins & 4095u) == 0 && clock.expired())
             {
-                // a stream that has drained (or failed) ends the wait whatever the flags say
-                const hipError_t q = hipStreamQuery(ctx->stream);
-                if (q == hipErrorNotReady)
-                    continue;
-                HIPCHK(ctx, q);
-                seen = __atomic_load_n(flag + w, __ATOMIC_ACQUIRE);
-                if (seen != ps.seq)
-                    break;
+                ps.segs.clear();
+                ps.p_B = 0;
+                return ctx->fail_wait("lvbgpu_chains_collect: the walk's watcher waves", clock.waited());
             }
         }
         if (seen != ps.seq)
@@ -469,17 +473,27 @@ int propose_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
             return ctx->fail(LVBGPU_E_STATE, "the walk's watcher did not hand the lengths over (flag " + std::to_string(seen) + ")");
         }
     }
-    else if (ps.B > SPIN_WAIT_MAX_B)
-        HIPCHK(ctx, hipEventSynchronize(ps.done_ev));
     else
     {
+        // small batches are polled for (the runtime's wake-up costs ~10 us), big ones sleep between polls; both give up
+        // at the context's wait limit
         hipError_t q;
+        uint32_t spins = 0;
         while ((q = hipEventQuery(ps.done_ev)) == hipErrorNotReady)
-            ;
+        {
+            if (ps.B > SPIN_WAIT_MAX_B)
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if ((++spins & 1023u) == 0 && clock.expired())
+            {
+                ps.segs.clear();
+                ps.p_B = 0;
+                return ctx->fail_wait("lvbgpu_chains_collect: the lengths' read-back", clock.waited());
+            }
+        }
         HIPCHK(ctx, q);
     }
     ctx->last_slot = slot;
-    ctx->pick_uses_since_collect = 0; // (take_pick_slot)
+    ctx->collected_ord = std::max(ctx->collected_ord, ps.submit_ord); // (take_pick_slot)
     const int32_t B = ps.B;
     const int64_t *len = (const int64_t *)ps.batch->h_len.p;
     for (int32_t b = 0; b < B; b++)
@@ -580,23 +594,67 @@ extern "C" int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *len
 namespace lvbgpu_detail
 {
 // The next pinned slot for a commit's or a re-root's picks / programs.  Its readers - the commit walk (main stream),
-// the table rebuild and the gather (side stream) - are all finished once a LATER batch has been collected: that batch's
-// walk was enqueued behind the commit walk, and its generator waited for the rebuild.  So slots need no events of their
-// own (an event record + a wait cost the host 4-5 us per commit, where the host is what the device waits for): only
-// PICK_SLOTS uses in a row without a collect in between have to drain the streams.
+// the table rebuild and the gather (side stream) - are all finished once a batch SUBMITTED AFTER this use has been
+// collected: that batch's walk was enqueued behind the commit walk, and its generator waited for the rebuild.  (A batch
+// submitted BEFORE the use proves nothing: it may have been collected while the commit walk was still queued behind
+// it.)  So slots need no events of their own (an event record + a wait cost the host 4-5 us per commit, where the host
+// is what the device waits for): every use remembers how many batches had been submitted before it, and a slot whose
+// use no later batch has come back for drains the streams before it is written again.
 hipError_t take_pick_slot(lvbgpu_ctx *ctx, int *slot)
 {
-    if (++ctx->pick_uses_since_collect >= lvbgpu_ctx::PICK_SLOTS)
+    const int s = ctx->pick_slot;
+    if (ctx->pick_used[s] && ctx->collected_ord <= ctx->pick_use_ord[s])
     {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess)
             e = hipStreamSynchronize(ctx->side_stream);
         if (e != hipSuccess)
             return e;
-        ctx->pick_uses_since_collect = 1;
+        for (int i = 0; i < lvbgpu_ctx::PICK_SLOTS; i++)
+            ctx->pick_used[i] = false; // everything enqueued so far is done
     }
-    *slot = ctx->pick_slot;
-    ctx->pick_slot = (*slot + 1) % lvbgpu_ctx::PICK_SLOTS;
+    ctx->pick_used[s] = true;
+    ctx->pick_use_ord[s] = ctx->submits;
+    *slot = s;
+    ctx->pick_slot = (s + 1) % lvbgpu_ctx::PICK_SLOTS;
+    return hipSuccess;
+}
+
+// A table rebuild (side stream) rewrites the generator's tables of the listed chains in place.  A batch that is still
+// in flight may have been drawn from one of those chains (a chain may sit in both slots; the commit makes that batch's
+// candidates of the chain stale, but its generator may not even have run yet): the rebuild must not start before that
+// generator is done, or the generator reads torn tables - paths and programs from garbage, walked by the scoring kernel.
+// lvbgpu_proposal_edits names candidates of slot 0's last single-chain batch relative to the tree they were drawn
+// from: once that chain's tree has moved (and its device tables with it, so the version test there no longer sees it)
+// their rewrites mean nothing
+void forget_named_candidates(lvbgpu_ctx *ctx, uint64_t chain_mask)
+{
+    lvbgpu_ctx::PropSlot &p0 = ctx->pslot[0];
+    if (p0.p_B > 0 && p0.segs.size() == 1 && ((chain_mask >> p0.segs[0].chain) & 1u))
+        p0.p_B = 0;
+}
+
+hipError_t order_rebuild_after_readers(lvbgpu_ctx *ctx, uint64_t chain_mask)
+{
+    for (lvbgpu_ctx::PropSlot &other : ctx->pslot)
+    {
+        if (!other.in_flight)
+            continue;
+        bool reads = false;
+        for (const lvbgpu_ctx::PSeg &sg : other.segs)
+            reads |= ((chain_mask >> sg.chain) & 1u) != 0;
+        if (!reads)
+            continue;
+        // mark the main stream where it stands now - behind that batch's generator (and its walk) - and hold the side
+        // stream back until then.  Only here, where it is needed: an event per submit would cost every step of the
+        // bench's pipelined loop a few microseconds of host time.
+        const hipError_t er = hipEventRecord(other.gen_ev, ctx->stream);
+        if (er != hipSuccess)
+            return er;
+        const hipError_t e = hipStreamWaitEvent(ctx->side_stream, other.gen_ev, 0);
+        if (e != hipSuccess)
+            return e;
+    }
     return hipSuccess;
 }
 } // namespace lvbgpu_detail
@@ -684,6 +742,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         ra.info = (const ProposalInfo *)ps.d_pinfo.p;
         ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
         ra.stride_e = ctx->p_stride_e;
+        HIPCHK(ctx, order_rebuild_after_readers(ctx, seen));
         HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream, &gat));
         HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
         ctx->side_pending = true;
@@ -708,17 +767,16 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     a.done_count = done;
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     // 3. follow the moves on the host
-    for (uint32_t spins = 1;; spins++)
+    const WaitClock clock(ctx->wait_limit_s);
+    for (uint32_t spins = 1;; spins++) // (memory only, see propose_collect)
     {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq)
             break;
-        if ((spins & 1023u) == 0)
+        if ((spins & 1023u) == 0 && clock.expired())
         {
-            const hipError_t q = hipStreamQuery(ctx->side_stream);
-            if (q == hipSuccess)
-                break; // everything the kernels wrote is visible
-            if (q != hipErrorNotReady)
-                return ctx->fail_hip(q, "lvbgpu_chains_commit: waiting for the picked moves");
+            for (int32_t j = 0; j < k; j++) // the device may or may not have walked them: not trustworthy any more
+                ctx->parked[(size_t)picks[j].chain].have_tree = false;
+            return ctx->fail_wait("lvbgpu_chains_commit: the picked moves' gather", clock.waited());
         }
     }
     for (int32_t j = 0; j < k; j++)
@@ -737,6 +795,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         if (tables_on_device)
             cs.d_topo_version = cs.topo_version; // rebuilt in place by the launch above
     }
+    forget_named_candidates(ctx, seen);
     ctx->last_pick_slot = slot;
     ctx->last_pick_count = k;
     return LVBGPU_OK;
@@ -830,6 +889,7 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         ra.leaf_order_len = (uint32_t)ctx->n;
         ra.ext = ext;
         ra.ext_edits = all;
+        HIPCHK(ctx, order_rebuild_after_readers(ctx, seen));
         HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream));
         HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
         ctx->side_pending = true;
@@ -879,6 +939,7 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         if (tables_on_device)
             cs.d_topo_version = cs.topo_version;
     }
+    forget_named_candidates(ctx, seen);
     return LVBGPU_OK;
 }
 

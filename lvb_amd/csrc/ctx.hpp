@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdint>
 #include <cstdio>
@@ -142,6 +143,18 @@ struct ChainSlot
     int32_t gen_K = 1;
 };
 
+// Host-side waits for the device are bounded: a spin on a flag, an event or a stream gives up after the context's wait
+// limit (lvbgpu_set_wait_limit; default LVBGPU_WAIT_SECONDS or 30 s) and the call returns LVBGPU_E_HIP naming what it
+// waited for and the stream's state - a stuck stream must not become an endless host spin.
+struct WaitClock
+{
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double limit;
+    explicit WaitClock(double seconds) : limit(seconds) {}
+    double waited() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    bool expired() const { return waited() > limit; }
+};
+
 struct lvbgpu_ctx
 {
     int device = 0;
@@ -211,6 +224,8 @@ struct lvbgpu_ctx
         int32_t B = 0;
         hipEvent_t done_ev = nullptr; // after the lengths' read-back (on the copy stream)
         hipEvent_t walk_ev = nullptr; // after the walk (on the main stream): what the read-back waits for
+        hipEvent_t gen_ev = nullptr;  // recorded behind this batch when a table rebuild of one of its chains must wait for it
+        uint64_t submit_ord = 0;      // this batch's ordinal among the context's submits (1-based)
         PinBuf h_flag;                // the watcher's word for this slot's batches (kernels.hpp WalkArgs::watcher)
         uint32_t seq = 0;
         bool watched = false;         // this batch's lengths come through the watcher, not a copy
@@ -219,6 +234,10 @@ struct lvbgpu_ctx
     static constexpr int PROP_SLOTS = 2;
     PropSlot pslot[PROP_SLOTS];
     int last_slot = 0;              // the batch lvbgpu_chains_commit picks from: the one collected last
+    uint64_t submits = 0;           // device-built batches submitted so far
+    uint64_t collected_ord = 0;     // highest submit ordinal among the batches collected so far
+    double wait_limit_s = 30.0;     // lvbgpu_set_wait_limit
+    uint32_t flip_counter = 0;      // direction of this context's next big scoring launch (launch_walk)
     DevBuf d_gen_prof; // LVBGPU_GEN_PROFILE: clock stamps of the generator (diagnostic)
     DevBuf d_topo4; // the generator's tables of the resident topologies, gen_table_stride each
     uint32_t gen_table_stride = 0;
@@ -235,7 +254,12 @@ struct lvbgpu_ctx
     // lvbgpu_chains_commit: picks / fetched rewrites travel through a small ring of pinned slots
     static constexpr int PICK_SLOTS = 4;
     PinBuf h_pick[PICK_SLOTS];
-    int pick_uses_since_collect = 0; // api_propose.cpp take_pick_slot
+    // A slot's readers (commit walk on the main stream, table rebuild and gather on the side stream) are finished once
+    // a batch SUBMITTED AFTER that use has been collected: its walk was enqueued behind the commit walk, its generator
+    // waited for the rebuild.  Every use remembers how many batches had been submitted before it (api_propose.cpp
+    // take_pick_slot); a slot is taken again only when a later batch has come back, else the streams are drained first.
+    uint64_t pick_use_ord[PICK_SLOTS] = {0, 0, 0, 0};
+    bool pick_used[PICK_SLOTS] = {false, false, false, false};
     int pick_slot = 0;
     uint32_t pick_seq = 0;
     int last_pick_slot = 0, last_pick_count = 0; // what lvbgpu_chains_picked_edits reads
@@ -279,9 +303,20 @@ struct lvbgpu_ctx
     int fail_hip(hipError_t e, const char *what)
     {
         last_error = std::string(what) + ": " + hipGetErrorString(e);
+        if (e == hipErrorNotReady) // only a bounded wait that gave up returns this
+            last_error += " (the wait limit of " + std::to_string(wait_limit_s) + " s passed: lvbgpu_set_wait_limit / LVBGPU_WAIT_SECONDS)";
         return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
                    ? LVBGPU_E_NODEVICE
                    : (e == hipErrorOutOfMemory ? LVBGPU_E_NOMEM : LVBGPU_E_HIP);
+    }
+    // a bounded host wait gave up (WaitClock)
+    int fail_wait(const char *what, double seconds)
+    {
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.3f", seconds);
+        last_error = std::string(what) + " did not complete within " + buf +
+                     " s (wait limit: lvbgpu_set_wait_limit / LVBGPU_WAIT_SECONDS); the stream is still busy or stuck";
+        return LVBGPU_E_HIP;
     }
     int fail(int code, const std::string &why)
     {

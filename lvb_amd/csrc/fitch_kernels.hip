@@ -840,7 +840,7 @@ hipError_t upload_iupac_table()
     return hipMemcpyToSymbol(HIP_SYMBOL(k_iupac), tab, sizeof(tab));
 }
 
-hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
+hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream, uint32_t *flip_state)
 {
     if (args.nitems == 0)
         return hipSuccess;
@@ -853,10 +853,11 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         const char *e = getenv("LVBGPU_FLIP");
         return !(e && e[0] == '0');
     }();
-    static uint32_t flip_counter = 0;
+    // (the direction alternates per CONTEXT - flip_state is the caller's counter: a process-wide one would be shared,
+    // and raced on, by contexts driven from different host threads)
     a.flip = 0;
-    if (allow_flip && !commit && (uint64_t)args.nrows * args.in_stride4 * 16u > FLIP_MIN_BYTES)
-        a.flip = (flip_counter++) & 1u;
+    if (allow_flip && flip_state && !commit && (uint64_t)args.nrows * args.in_stride4 * 16u > FLIP_MIN_BYTES)
+        a.flip = ((*flip_state)++) & 1u;
     a.tiles_per = a.ntiles / a.ngroups;
     a.tiles_rem = a.ntiles % a.ngroups;
     // floor(2^32 / B): mulhi(item, inv_B) is floor(item / B) or one less for item < 2^31 (the kernel
@@ -924,6 +925,21 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream)
         hipLaunchKernelGGL((fitch_walk<false, true>), grid, block, lds, stream, a);
     else
         hipLaunchKernelGGL((fitch_walk<false, false>), grid, block, lds, stream, a);
+    return hipGetLastError();
+}
+
+// nothing but a clock watcher (lvbgpu_debug_stall: the wait-limit test needs a stream that is busy for a known time).
+// One wave; wall_clock64 counts at 100 MHz; the loop is bounded twice over (clock and trip count).
+__global__ __launch_bounds__(64) void stall_kernel(uint32_t ms)
+{
+    const uint64_t t0 = wall_clock64(), ticks = (uint64_t)ms * 100000ull;
+    for (uint32_t trips = 0; trips < (1u << 26) && wall_clock64() - t0 < ticks; trips++)
+        __builtin_amdgcn_s_sleep(64);
+}
+
+hipError_t launch_stall(hipStream_t stream, uint32_t ms)
+{
+    hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, stream, ms > 2000u ? 2000u : ms);
     return hipGetLastError();
 }
 

@@ -226,7 +226,9 @@ struct GatherArgs;
 hipError_t launch_gather_picks(const GatherArgs &g, hipStream_t stream);
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
-hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream);
+hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream, uint32_t *flip_state = nullptr);
+// bounded busy kernel for the wait-limit test (lvbgpu_debug_stall): keeps `stream` busy for about `ms` milliseconds
+hipError_t launch_stall(hipStream_t stream, uint32_t ms);
 hipError_t launch_zero_changes(unsigned long long *changes, const int32_t *dsts, uint32_t n, unsigned long long *root_slot,
                                unsigned long long *len_slot, unsigned long long *s_all, uint32_t bias_from, uint32_t row_bias,
                                hipStream_t stream);

@@ -66,6 +66,17 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
+    def all_values(self, value: float) -> list:
+        """every rank's value, in rank order, on every rank (one sum of a vector that is zero but at one's own place)"""
+        if self.dist is None:
+            return [float(value)]
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.zeros(self.world, dtype=torch.float64, device=dev)
+        t[self.rank] = float(value)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
     def barrier(self) -> None:
         if self.dist is not None:
             self.dist.barrier()

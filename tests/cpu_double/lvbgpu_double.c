@@ -254,9 +254,10 @@ typedef struct
     int in_flight;
 } dbl_slot;
 
-static struct
+/* (per THREAD: lvbhost_anneal_chain_groups runs every group - one context each - on a thread of its own) */
+static __thread struct
 {
-    lvbgpu_ctx *owner;                            /* one multi-chain context at a time is all the tests need */
+    lvbgpu_ctx *owner;                            /* one multi-chain context at a time (and thread) is all the tests need */
     int32_t R, sel;
     dbl_chain ch[DBL_MAX_CHAINS];
     dbl_slot slot[2];

@@ -411,3 +411,149 @@ def test_random_operations_over_chains_against_the_cpu_oracle(mods):
                 cand.mark_dirty([d for d in prog["dsts"] if d >= 0])
                 assert int(lens[b]) == cand.getplen(), (step, c, b)
     ctx.close()
+
+
+def test_pick_slots_survive_collects_of_batches_submitted_before_their_use(mods):
+    """a collected batch proves a pinned pick slot's readers done only if it was SUBMITTED AFTER the slot was
+    used.  Here a big batch is submitted first, then re-roots and commits pile up behind it (their commit walks read
+    programs in place from the pinned slots), the old batch is collected in between (which used to reset the recycling
+    count), and more re-roots follow - enough to come round to the first slot again while its walk may still be queued.
+    Every chain must end exactly where the same re-roots, done one by one with a synchronous commit, put it."""
+    api, host = mods
+    n, m, R = 64, 20000, 4
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 23))
+    multi, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
+    trees = [host.HostTree(n, seed=700 + c) for c in range(R)]
+    for ctx in (multi, ref):
+        ctx.set_chains(R)
+        for c in range(R):
+            ctx.select_chain(c)
+            trees[c].upload(ctx)
+    rng = np.random.default_rng(8)
+
+    def reroot_all():
+        reqs = []
+        for c in range(1, R):                      # chain 0 is the one the long batch was drawn from: left alone
+            nr = int((trees[c].root + 1 + rng.integers(0, n - 1)) % n)
+            reqs.append((c, nr))
+            ed = trees[c].reroot_edits(nr)
+            ref.select_chain(c)
+            ref.commit(ed, root=nr)
+            trees[c].apply(ed, nr)
+        multi.chains_reroot(reqs)
+
+    for rnd in range(3):
+        counts = multi.chains_submit(0, [(0, 6000, 2, 40 + rnd)])   # long: its walk keeps the stream busy for a while
+        reroot_all()                                                # slot p0, queued behind the batch
+        reroot_all()                                                # p1
+        got = multi.chains_collect(0, counts)[0]                    # submitted BEFORE those uses: proves nothing about them
+        ref.select_chain(0)
+        assert np.array_equal(got, ref.propose_score(6000, 2, 40 + rnd))
+        for _ in range(4):                                          # p2, p3, then p0 and p1 again
+            reroot_all()
+    for c in range(R):
+        multi.select_chain(c)
+        ref.select_chain(c)
+        assert multi.current_length() == ref.current_length()
+        assert np.array_equal(multi.changes(), ref.changes()) and np.array_equal(multi.all_sets(), ref.all_sets())
+        assert np.array_equal(multi.propose_score(30, -1, 99 + c), ref.propose_score(30, -1, 99 + c))
+    multi.close()
+    ref.close()
+
+
+def test_commit_while_the_other_slot_holds_the_same_chain(mods):
+    """include/lvbgpu.h lets a chain sit in both slots.  A commit picked from the batch collected first
+    rebuilds that chain's generator tables on the side stream - which must not overtake the OTHER batch's generator,
+    still queued on the main stream and reading the same tables.  The other batch was drawn from the tree BEFORE the
+    commit: its lengths must be exactly what that tree gives (and picking from it afterwards is refused as stale)."""
+    api, host = mods
+    n, m = 500, 50000
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 3))
+    ctx, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=77)
+    tree.upload(ctx)
+    tree.upload(ref)
+    for rnd in range(12):
+        B0, B1 = 4096, 2048
+        want1 = ref.propose_score(B1, 1, 9000 + rnd)               # the old tree's neighbourhood
+        want0 = ref.propose_score(B0, 1, 8000 + rnd)
+        c0 = ctx.chains_submit(0, [(0, B0, 1, 8000 + rnd)])
+        got0 = ctx.chains_collect(0, c0)[0]
+        # two more batches queue up: slot 0 keeps the stream busy, so slot 1's generator is still waiting when the commit comes
+        ctx.chains_submit(0, [(0, B0, 1, 8100 + rnd)])
+        c1 = ctx.chains_submit(1, [(0, B1, 1, 9000 + rnd)])
+        assert np.array_equal(got0, want0)
+        with pytest.raises(api.LvbGpuError):
+            ctx.chains_commit([(0, 0)])                             # slot 0's NEW batch is in flight: nothing to pick from
+        junk = ctx.chains_collect(0, c0)[0]
+        b = int(np.argmin(junk))
+        ctx.chains_commit([(0, b)])                                 # rebuild on the side stream; slot 1 still in flight
+        got1 = ctx.chains_collect(1, c1)[0]
+        assert np.array_equal(got1, want1), rnd                     # drawn from intact tables of the OLD tree
+        with pytest.raises(api.LvbGpuError) as ei:
+            ctx.chains_commit([(0, 0)])                             # ... and stale now
+        assert ei.value.status == -5
+        # the reference context follows the same move
+        ref.propose_score(B0, 1, 8100 + rnd)
+        edits, _ = ref.proposal_edits(b)
+        assert ref.commit(edits) == junk[b] == ctx.current_length()
+    assert np.array_equal(ctx.all_sets(), ref.all_sets())
+    ctx.close()
+    ref.close()
+
+
+def test_proposal_edits_are_refused_once_a_chain_commit_has_moved_the_tree(mods):
+    """after lvbgpu_propose_score -> lvbgpu_chains_commit (tables rebuilt on the device, versions equal
+    again) the OLD batch's rewrites are relative to a tree that is gone."""
+    api, host = mods
+    n, m = 40, 1200
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 5))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=6)
+    tree.upload(ctx)
+    lens = ctx.propose_score(16, -1, 3)
+    edits, _ = ctx.proposal_edits(2)                                # fine: same tree
+    assert len(edits) >= 2
+    ctx.chains_commit([(0, int(np.argmin(lens)))])
+    with pytest.raises(api.LvbGpuError) as ei:
+        ctx.proposal_edits(2)
+    assert ei.value.status == -5
+    lens = ctx.propose_score(16, -1, 4)
+    ctx.proposal_edits(1)
+    nr = (ctx.topology()[3] + 3) % n
+    ctx.chains_reroot([(0, nr)])
+    with pytest.raises(api.LvbGpuError) as ei:
+        ctx.proposal_edits(1)
+    assert ei.value.status == -5
+    ctx.close()
+
+
+def test_groups_side_by_side_on_the_gpu(mods):
+    """lvbhost_anneal_chain_groups on the HIP scorer: three contexts, three host threads, every chain's run equal to
+    what one lock-stepped group gives it (tests/test_anneal_chains_cpu.py holds the same on the CPU double)."""
+    api, host = mods
+    n, m = 40, 1500
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 91))
+    seeds = [3, 4, 5, 6, 7, 8, 9]
+    together, together_final, _ = _run_chains(api, host, rows, min_len, n, seeds, 2500, 1)
+    ctxs = [api.FitchContext(text_rows=rows) for _ in range(3)]
+    trees = [host.HostTree(n, seed=1000 + s) for s in seeds]
+    params = []
+    for s in seeds:
+        p = host.anneal_defaults()
+        p.seed, p.algorithm, p.batch, p.t0, p.min_len_tree, p.max_proposals, p.log_cap = 7000 + s, 1, 256, 0.0, min_len, 2500, 64
+        params.append(p)
+    res, log = host.anneal_chain_groups(ctxs, trees, params)
+    keys = ("start_length", "best_length", "final_length", "consumed", "accepted", "temperatures", "device_steps", "scored",
+            "reroots", "topologies", "t_final")
+    for c, t in enumerate(trees):
+        assert {k: res[c][k] for k in keys} == {k: together[c][k] for k in keys}, c
+        _, l, r = t.arrays()
+        assert np.array_equal(l, together_final[c][0]) and np.array_equal(r, together_final[c][1])
+        assert (t.root, t.best_count()) == together_final[c][2:]
+    assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)
+    assert log[-1][1] == min(r["best_length"] for r in res)
+    for t in trees:
+        t.close()
+    for c in ctxs:
+        c.close()

@@ -79,3 +79,35 @@ def test_zero_length_is_the_reference_assertion(mods):
         ctx.set_tree(left, right, tree.root)
     assert ei.value.status == -8 and "changes > 0" in str(ei.value)
     ctx.close()
+
+
+def test_a_wait_gives_up_at_the_contexts_limit(mods):
+    """no host spin without a deadline.  The stream is kept busy by a clock-watching kernel for 400 ms
+    (lvbgpu_debug_stall), the wait limit is 50 ms: collecting a batch queued behind it returns LVBGPU_E_HIP naming what
+    was waited for, within the limit's order of magnitude - and the context is serviceable again once the stream has
+    drained."""
+    import time
+    api, host = mods
+    rows, _ = host.prepare_alignment(synth.treelike_rows(30, 900, 5))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(30, seed=6)
+    tree.upload(ctx)
+    want = ctx.propose_score(64, -1, 11)
+    ctx.set_wait_limit(0.05)
+    for collect_kind in ("watcher", "score_batch"):
+        ctx._chk(ctx.lib.lvbgpu_debug_stall(ctx.h, 400))
+        t0 = time.perf_counter()
+        with pytest.raises(api.LvbGpuError) as ei:
+            if collect_kind == "watcher":
+                ctx.propose_score(64, -1, 11)                # device-built batch: its lengths come through the watcher waves
+            else:
+                ctx.score_batch([tree.propose(1) for _ in range(9)])
+        took = time.perf_counter() - t0
+        assert ei.value.status == -3 and ("wait limit" in str(ei.value)), str(ei.value)
+        assert 0.04 < took < 0.35, took                       # gave up at the limit, not when the stall ended
+        ctx.synchronize()                                     # the stall kernel is bounded: the stream drains
+    ctx.set_wait_limit(30.0)
+    assert np.array_equal(ctx.propose_score(64, -1, 11), want)   # nothing resident was harmed
+    with pytest.raises(api.LvbGpuError):
+        ctx.set_wait_limit(0.0)
+    ctx.close()
