@@ -81,7 +81,7 @@ def parse_args(argv=None):
                     help="run the batched SA host end to end for this long and report best-length-vs-wallclock (0 = skip)")
     ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
     ap.add_argument("--anneal-chains", type=int, default=32, help="independent chains stepped together on the GPU")
-    ap.add_argument("--anneal-groups", type=int, default=4,
+    ap.add_argument("--anneal-groups", type=int, default=1,
                     help="the chains are dealt to this many groups that anneal side by side, each with a context and a host "
                          "thread of its own (lvbhost_anneal_chain_groups); 1 = all chains lock-stepped in one context")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -77,6 +77,7 @@ struct ChainRun
     // starting temperature (StartingTemperature.c:49-195)
     double st_t = LVB_EPS;
     int st_acc_pos = 0, st_prop_pos = 0, st_iter = 0;
+    int64_t st_total = 0; // proposals consumed while the starting temperature was being estimated
     bool st_rerooted = false;
     // annealing (Solve.c:144-479)
     double t0 = 0, t = 0, log_t0 = 0;
@@ -270,6 +271,7 @@ struct ChainRun
             for (int b = 0; b < B; b++)
             {
                 st_iter++;
+                st_total++;
                 const int64_t len = lens[b];
                 if (len == INT64_MAX)
                     continue; // a device candidate that did not fit its buffers: not a proposal
@@ -322,23 +324,52 @@ struct ChainRun
             accept_rate = std::max(1e-4, 0.8 * accept_rate + 0.2 * (double)accepted_now / consumed_now);
     }
 
-    // the accepted candidate has been committed on the device: follow it here and finish the proposal.
-    // Returns true if the chain's best length improved.
-    bool after_commit(int32_t pick_index)
+    // The accepted candidate's commit has been ENQUEUED (lvbgpu_chains_commit does not wait): finish the proposal.
+    // What has to happen before the next step can be planned needs the new topology in one case only - the accepted tree
+    // TIES the best length, so whether it counts as accepted depends on whether the treestack already holds it
+    // (Solve.c:316-319).  Everything else (a strictly better tree is new for certain, a worse one is not offered, the
+    // starting-temperature phase keeps no trees) is bookkeeping on numbers; the host's copy of the tree and the
+    // treestack follow AFTER the next step has been submitted (finish_follow), while the device is busy with it - on the
+    // accept path the host is what the device waits for.
+    int32_t deferred_pick = -1; // pick index of the move the host's tree has not followed yet
+    bool deferred_stack = false;
+
+    // the move's rewrites -> the host's topology (waits for them if they are still on their way from the device)
+    void follow(int32_t pick_index)
     {
-        // the move's rewrites are on the host already (the commit fetched them): follow them
         fetched.resize((size_t)2 * tree->topo.nb + 8);
         int32_t ne = 0;
         rc = lvbgpu_chains_picked_edits(ctx, pick_index, fetched.data(), (int32_t)fetched.size(), &ne);
         if (rc == LVBGPU_OK)
             rc = lvbhost_tree_apply(tree, fetched.data(), ne, -1);
-        if (rc != LVBGPU_OK)
-            return false;
+    }
+    void finish_follow()
+    {
+        if (deferred_pick < 0)
+            return;
+        follow(deferred_pick);
+        deferred_pick = -1;
+        if (rc == LVBGPU_OK && deferred_stack)
+        {
+            tree->best.clear(); // discard old bests (Solve.c:312-315)
+            tree->best.insert(tree->topo);
+        }
+        deferred_stack = false;
+    }
+    // Returns true if the chain's best length improved.
+    bool after_commit(int32_t pick_index)
+    {
         cur = pending_len;
         if (phase == START_TEMP)
         {
             if (st_iter > 100)
-                end_of_start_temperature_sample();
+            {
+                follow(pick_index); // the estimate may end here, and the annealing starts from the tree as it is
+                if (rc == LVBGPU_OK)
+                    end_of_start_temperature_sample();
+            }
+            else
+                deferred_pick = pick_index;
             return false;
         }
         res->accepted++;
@@ -346,10 +377,22 @@ struct ChainRun
         if (pending_stack)
         {
             if (cur < best)
-                tree->best.clear(); // discard old bests (Solve.c:312-315)
-            if (tree->best.insert(tree->topo))
-                accepted++; // only topologies new to the treestack count (316-319)
+            {
+                accepted++; // new to the treestack for certain (316-319): the trees themselves follow later
+                deferred_pick = pick_index;
+                deferred_stack = true;
+            }
+            else
+            {
+                follow(pick_index);
+                if (rc != LVBGPU_OK)
+                    return false;
+                if (tree->best.insert(tree->topo))
+                    accepted++; // only topologies new to the treestack count
+            }
         }
+        else
+            deferred_pick = pick_index;
         if (cur < best)
         {
             best = cur;
@@ -445,6 +488,7 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         std::vector<int64_t> lens;
         size_t total = 0;
         bool active = false;
+        int slot = 0;
     };
     static const int want_groups = [] {
         const char *e = getenv("LVBHOST_CHAIN_GROUPS");
@@ -459,6 +503,14 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     double dev_seconds = 0.0;
     double t_plan = 0, t_score = 0, t_consume = 0, t_commit = 0, t_after = 0; // LVBHOST_PROFILE=1 prints them
     double t_submit = 0, t_reroot = 0; // ... and, of those, the submit call (part of propose_score) and the re-roots (part of plan)
+    const bool profile = getenv("LVBHOST_PROFILE") != nullptr;
+    int64_t p_sc = 0, p_co = 0, p_ac = 0, p_cs = 0;
+    auto chain_steps_now = [&] {
+        int64_t v = 0;
+        for (const ChainRun &r : runs)
+            v += r.res->device_steps;
+        return v;
+    };
     const bool lockstep = params[0].sync_every > 0;
     if (lockstep && params[0].max_device_steps <= 0)
         return LVBGPU_E_ARG;
@@ -489,7 +541,12 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         roots.clear();
         for (int32_t c : f.who)
             if (runs[(size_t)c].pending_root >= 0)
+            {
+                runs[(size_t)c].finish_follow(); // the re-root's rewrites are made from the tree as it is NOW
+                if (runs[(size_t)c].rc != LVBGPU_OK)
+                    return runs[(size_t)c].rc;
                 roots.push_back({c, runs[(size_t)c].pending_root});
+            }
         if (!roots.empty())
         {
             auto tr = Clock::now();
@@ -505,12 +562,26 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             return LVBGPU_OK;
         f.lens.resize(f.total);
         auto td = Clock::now();
-        const int r = lvbgpu_chains_submit(ctx, g, (int32_t)f.draws.size(), f.draws.data());
+        f.slot = g;
+        const int r = lvbgpu_chains_submit(ctx, f.slot, (int32_t)f.draws.size(), f.draws.data());
         dev_seconds += since(td);
         t_score += since(td);
         t_submit += since(td);
         f.active = r == LVBGPU_OK;
         return r;
+    };
+    // the trees of the chains that accepted in the step before follow their moves now, while the device works
+    auto follow_group = [&](int g) -> int {
+        auto tf = Clock::now();
+        for (ChainRun &r : runs)
+            if (r.chain % ngroups == g && r.deferred_pick >= 0)
+            {
+                r.finish_follow();
+                if (r.rc != LVBGPU_OK)
+                    return r.rc;
+            }
+        t_after += since(tf);
+        return LVBGPU_OK;
     };
     // the group's lengths are back (or are waited for): consume, commit the accepted moves, finish those proposals
     auto finish_group = [&](int g, bool discard) -> int {
@@ -519,7 +590,7 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             return LVBGPU_OK;
         f.active = false;
         auto td = Clock::now();
-        int r = lvbgpu_chains_collect(ctx, g, f.lens.data());
+        int r = lvbgpu_chains_collect(ctx, f.slot, f.lens.data());
         dev_seconds += since(td);
         t_score += since(td);
         if (r != LVBGPU_OK || discard)
@@ -572,6 +643,24 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         if (rc != LVBGPU_OK)
             break;
         steps++;
+        if (profile && steps % 1000 == 0) // how full the batches are and how often a proposal is accepted, as the run goes
+        {
+            int64_t sc = 0, co = 0, ac = 0;
+            for (const ChainRun &r : runs)
+            {
+                sc += r.res->scored;
+                co += r.iter + r.st_total;
+                ac += r.res->accepted;
+            }
+            fprintf(stderr, "[anneal_chains] step %lld at %.3f s: scored %lld (+%lld), consumed +%lld, accepted +%lld  => %.1f candidates per chain-step, "
+                            "acceptance %.3f per consumed proposal\n",
+                    (long long)steps, since(wall0), (long long)sc, (long long)(sc - p_sc), (long long)(co - p_co), (long long)(ac - p_ac),
+                    (double)(sc - p_sc) / std::max<int64_t>(1, chain_steps_now() - p_cs), (double)(ac - p_ac) / std::max<int64_t>(1, co - p_co));
+            p_sc = sc;
+            p_co = co;
+            p_ac = ac;
+            p_cs = chain_steps_now();
+        }
         bool stop = false;
         if (params[0].max_seconds > 0 && since(wall0) >= params[0].max_seconds)
             stop = true;
@@ -593,7 +682,11 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         if (stop)
             break;
         rc = submit_group(g);
+        if (rc == LVBGPU_OK)
+            rc = follow_group(g);
     }
+    for (int g = 0; g < ngroups && rc == LVBGPU_OK; g++)
+        rc = follow_group(g); // (a run that stopped right after a commit)
     // leave nothing in flight
     for (int g = 0; g < ngroups; g++)
     {

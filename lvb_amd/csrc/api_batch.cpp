@@ -287,6 +287,11 @@ extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
 {
     if (!ctx || !out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     *out = nullptr;
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
@@ -370,7 +375,10 @@ static hipError_t wait_for_direct_step(lvbgpu_ctx *ctx)
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->step_seq)
             return hipSuccess;
         if ((spins & 1023u) == 0 && clock.expired())
+        {
+            ctx->wait_gave_up = true;
             return hipErrorNotReady; // (fail_hip words it: the wait limit)
+        }
     }
 }
 } // namespace lvbgpu_detail
@@ -427,6 +435,11 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
 {
     if (!ctx || !lengths_out || B < 1 || !edit_offsets || (!edits && edit_offsets[B] > 0))
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -459,8 +472,26 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
     }
     for (int k = 0; k < K && rc == LVBGPU_OK; k++)
         rc = lvbgpu_batch_lengths(ctx, ctx->step_batch[k], lengths_out + (int64_t)B * k / K);
-    if (rc != LVBGPU_OK) // leave nothing in flight that reads the staging buffers
-        (void)hipStreamSynchronize(ctx->stream);
+    if (rc != LVBGPU_OK)
+    {
+        // Leave nothing in flight that reads the staging buffers.  After an ordinary failure (bad edits in a later
+        // piece) the stream is healthy: drain it.  After a wait that gave up it may be stuck, and draining would be the
+        // endless wait the limit exists to prevent: the step batches - whose buffers a queued walk may still read and
+        // write - are set aside instead (freed with the context, after its streams have been waited for) and the next
+        // call makes new ones.
+        if (ctx->wait_gave_up)
+        {
+            ctx->wait_gave_up = false;
+            for (lvbgpu_batch *&b : ctx->step_batch)
+                if (b)
+                {
+                    ctx->set_aside.push_back(b);
+                    b = nullptr;
+                }
+        }
+        else
+            (void)hipStreamSynchronize(ctx->stream);
+    }
     return rc;
 }
 

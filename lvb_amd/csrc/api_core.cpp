@@ -30,7 +30,10 @@ hipError_t wait_for_step(lvbgpu_ctx *ctx, int32_t B)
         if (B > SPIN_WAIT_MAX_B)
             std::this_thread::sleep_for(std::chrono::microseconds(20));
         if ((++spins & 1023u) == 0 && clock.expired())
+        {
+            ctx->wait_gave_up = true;
             break;
+        }
     }
     return q;
 }
@@ -321,6 +324,12 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->h_cout.release();
     ctx->d_comm.release();
     ctx->d_probe_sink.release();
+    for (lvbgpu_batch *zb : ctx->set_aside) // step batches abandoned after a wait that gave up (the streams have been waited for above)
+    {
+        zb->ctx = nullptr;
+        lvbgpu_batch_free(zb);
+    }
+    ctx->set_aside.clear();
     for (lvbgpu_batch *hb : ctx->held) // the caller still owns them; they must not reach into a dead context
         hb->ctx = nullptr;
     ctx->held.clear();
@@ -536,6 +545,11 @@ extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
 {
     if (!ctx || nchains < 1 || nchains > MAX_CHAINS)
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->side_stream));
     ctx->side_pending = false;
@@ -597,6 +611,11 @@ extern "C" int lvbgpu_select_chain(lvbgpu_ctx *ctx, int32_t chain)
 {
     if (!ctx || chain < 0 || chain >= ctx->nchains)
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     if (chain != ctx->chain)
     {
         park_chain(ctx);
@@ -613,6 +632,11 @@ extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32
 {
     if (!ctx || !left || !right)
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::string why;
     Topology t;
@@ -652,6 +676,11 @@ extern "C" int lvbgpu_get_topology(lvbgpu_ctx *ctx, int32_t *parent, int32_t *le
 {
     if (!ctx)
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
     if (parent)
@@ -702,6 +731,11 @@ extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit
 {
     if (!ctx || n_edits < 0 || (n_edits > 0 && !edits))
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -838,8 +872,15 @@ extern "C" int lvbgpu_synchronize(lvbgpu_ctx *ctx)
 {
     if (!ctx)
         return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->side_stream)); // table rebuilds of the last commit / re-root
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     return LVBGPU_OK;
 }
 

@@ -207,6 +207,21 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         return ctx->fail(LVBGPU_E_ARG, "rearrangements need at least 5 taxa");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     AllParked guard(ctx);
+    if (ctx->follow.pending)
+    {
+        // the generator needs versions, roots (no move changes a root) and device tables - not the host's topologies,
+        // unless a chain's tables have to be built from one here, or the moves are named against one
+        bool need = moves != nullptr;
+        for (int32_t i = 0; i < k && !need; i++)
+            if (draws[i].chain >= 0 && draws[i].chain < ctx->nchains)
+                need = ctx->parked[(size_t)draws[i].chain].d_topo_version != ctx->parked[(size_t)draws[i].chain].topo_version;
+        if (need)
+        {
+            const int rf = resolve_follow(ctx);
+            if (rf != LVBGPU_OK)
+                return rf;
+        }
+    }
     int64_t total = 0;
     std::vector<int32_t> chains((size_t)k);
     uint64_t seen = 0;
@@ -227,8 +242,13 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     if ((uint64_t)total * stride_t >= (1ull << 32) || (uint64_t)total * ctx->ntiles >= (1ull << 31))
         return ctx->fail(LVBGPU_E_ARG, "batch too large");
     const int32_t B = (int32_t)total;
-    if (ctx->side_pending) // tables being rebuilt on the side stream: before an upload below could be overtaken by them,
-    {                      // and before the generator reads them
+    // Tables being rebuilt on the side stream (an accepted move or a re-root just before this call): before an upload
+    // below could be overtaken by them, and before the generator reads them.  (Round 3 tried the generator BEHIND the
+    // rebuild on the side stream, beside the commit walk, with only the scoring walk waiting for both: 2-5 us per step
+    // SLOWER - a second cross-stream hand-over costs more than the 10-17 us of generator it hides;
+    // profiles/experiments/r03_anneal_step.md)
+    if (ctx->side_pending)
+    {
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
         ctx->side_pending = false;
     }
@@ -600,6 +620,47 @@ namespace lvbgpu_detail
 // it.)  So slots need no events of their own (an event record + a wait cost the host 4-5 us per commit, where the host
 // is what the device waits for): every use remembers how many batches had been submitted before it, and a slot whose
 // use no later batch has come back for drains the streams before it is written again.
+int resolve_follow(lvbgpu_ctx *ctx)
+{
+    lvbgpu_ctx::Follow &f = ctx->follow;
+    if (!f.pending)
+        return LVBGPU_OK;
+    f.pending = false;
+    const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
+    const size_t o_out = 64 + align16((size_t)MAX_CHAINS * 4);
+    const char *h = (const char *)ctx->h_pick[f.slot].p;
+    const uint32_t *flag = (const uint32_t *)h;
+    const WaitClock clock(ctx->wait_limit_s);
+    for (uint32_t spins = 1; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != f.seq; spins++) // (memory only, see propose_collect)
+        if ((spins & 1023u) == 0 && clock.expired())
+        {
+            for (int32_t j = 0; j < f.k; j++) // the device may or may not have walked them: not trustworthy any more
+                ctx->parked[(size_t)f.chains[j]].have_tree = false;
+            return ctx->fail_wait("lvbgpu_chains_commit: the picked moves' gather", clock.waited());
+        }
+    for (int32_t j = 0; j < f.k; j++)
+    {
+        const char *rec = h + o_out + (size_t)j * out_stride;
+        const ProposalInfo pi = *(const ProposalInfo *)rec;
+        ChainSlot &cs = ctx->parked[(size_t)f.chains[j]];
+        std::string why;
+        if (pi.overflow || !ctx->pb.apply_edits(cs.topo, (const Edit *)(rec + sizeof(ProposalInfo)), pi.n_edits, -1, &why))
+        {
+            cs.have_tree = false; // the device has walked it: this chain's resident state is no longer trustworthy
+            return ctx->fail(LVBGPU_E_TOPOLOGY, "chain " + std::to_string(f.chains[j]) + ": " + (pi.overflow ? "overflowed candidate" : why));
+        }
+    }
+    return LVBGPU_OK;
+}
+
+int settle(lvbgpu_ctx *ctx)
+{
+    if (!ctx->follow.pending)
+        return LVBGPU_OK;
+    AllParked guard(ctx);
+    return resolve_follow(ctx);
+}
+
 hipError_t take_pick_slot(lvbgpu_ctx *ctx, int *slot)
 {
     const int s = ctx->pick_slot;
@@ -670,6 +731,11 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     ctx->last_pick_count = 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     AllParked guard(ctx);
+    {
+        const int rf = resolve_follow(ctx); // the commit before this one: long done; its pinned slot may come round again
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     lvbgpu_batch *bt = ps.batch;
     // where each pick sits in the batch; nothing may have changed that chain's tree since it was drawn
     std::vector<uint32_t> where((size_t)k);
@@ -766,30 +832,16 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     a.tmp_stride = (uint32_t)(ctx->nb + 1);
     a.done_count = done;
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
-    // 3. follow the moves on the host
-    const WaitClock clock(ctx->wait_limit_s);
-    for (uint32_t spins = 1;; spins++) // (memory only, see propose_collect)
-    {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq)
-            break;
-        if ((spins & 1023u) == 0 && clock.expired())
-        {
-            for (int32_t j = 0; j < k; j++) // the device may or may not have walked them: not trustworthy any more
-                ctx->parked[(size_t)picks[j].chain].have_tree = false;
-            return ctx->fail_wait("lvbgpu_chains_commit: the picked moves' gather", clock.waited());
-        }
-    }
+    // 3. the host's topologies follow LATER (ctx->follow): the records are on their way into the pinned slot; versions
+    //    move now, so that everything that compares versions (stale picks, stale batches) sees the tree as changed
+    ctx->follow.pending = true;
+    ctx->follow.slot = slot;
+    ctx->follow.k = k;
+    ctx->follow.seq = seq;
     for (int32_t j = 0; j < k; j++)
     {
-        const char *rec = h + o_out + (size_t)j * out_stride;
-        const ProposalInfo pi = *(const ProposalInfo *)rec;
+        ctx->follow.chains[j] = picks[j].chain;
         ChainSlot &cs = ctx->parked[(size_t)picks[j].chain];
-        std::string why;
-        if (pi.overflow || !ctx->pb.apply_edits(cs.topo, (const Edit *)(rec + sizeof(ProposalInfo)), pi.n_edits, -1, &why))
-        {
-            cs.have_tree = false; // the device has walked it: this chain's resident state is no longer trustworthy
-            return ctx->fail(LVBGPU_E_TOPOLOGY, "chain " + std::to_string(picks[j].chain) + ": " + (pi.overflow ? "overflowed candidate" : why));
-        }
         cs.topo_version = ++ctx->version_counter;
         cs.cur_length_stale = true;
         if (tables_on_device)
@@ -811,6 +863,11 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     AllParked guard(ctx);
+    {
+        const int rf = resolve_follow(ctx); // the programs below are built from the chains' topologies as they are NOW
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     uint64_t seen = 0;
     std::vector<std::vector<Edit>> edits((size_t)k);
     Packed pk;
@@ -949,6 +1006,11 @@ extern "C" int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edi
         return LVBGPU_E_ARG;
     if (j >= ctx->last_pick_count)
         return ctx->fail(LVBGPU_E_STATE, "the last lvbgpu_chains_commit had no such pick");
+    {
+        const int rf = settle(ctx); // waits for the records if they are still on their way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
     const char *rec = (const char *)ctx->h_pick[ctx->last_pick_slot].p + 64 + align16((size_t)MAX_CHAINS * 4) + (size_t)j * out_stride;
     const ProposalInfo pi = *(const ProposalInfo *)rec;

@@ -264,6 +264,19 @@ struct lvbgpu_ctx
     uint32_t pick_seq = 0;
     int last_pick_slot = 0, last_pick_count = 0; // what lvbgpu_chains_picked_edits reads
     DevBuf d_done; // per picked candidate: finished-wave count of a multi-chain commit (zero between launches)
+    // The host side of the last lvbgpu_chains_commit, not done yet: the picked moves' descriptors and rewrites are on
+    // their way into pinned slot `slot` (flag = seq), and the chains' host topologies follow when somebody needs them
+    // (resolve_follow / settle in api_propose.cpp) - the commit call itself does not wait: on the accept path the host
+    // is what the device waits for, and what the host has to do next (plan and submit the next step) needs no topology.
+    // Versions are bumped at the commit already; ChainSlot::topo of the listed chains is one move behind until then.
+    struct Follow
+    {
+        bool pending = false;
+        int slot = 0;
+        int32_t k = 0;
+        uint32_t seq = 0;
+        int32_t chains[MAX_CHAINS];
+    } follow;
     PinBuf h_pin;
     // direct steps: small batches whose programs the walk reads straight from h_pin and whose lengths its last
     // wave writes straight into the batch's pinned buffer; the host polls h_step's first word for step_seq
@@ -286,6 +299,10 @@ struct lvbgpu_ctx
     // batches the caller holds (lvbgpu_batch_build): lvbgpu_destroy detaches them, so that a batch freed
     // after its context touches nothing of it
     std::vector<lvbgpu_batch *> held;
+    // a bounded wait of lvbgpu_score_batch gave up: its recycled step batches may still be read and written by queued
+    // walks, so they are set aside (freed with the context) instead of being reused or drained for
+    bool wait_gave_up = false;
+    std::vector<lvbgpu_batch *> set_aside;
 
     // lvbgpu_walk_timing: HIP events around every scoring walk, on the stream it is launched on
     static constexpr int WT_RING = 32;
@@ -413,6 +430,10 @@ int check_depth(lvbgpu_ctx *ctx, int32_t max_stack);
 int read_current_length(lvbgpu_ctx *ctx);
 int run_commit_program(lvbgpu_ctx *ctx, const Program &prog, bool zero_all, bool readback);
 int walk_timing_drain(lvbgpu_ctx *ctx);
+// api_propose.cpp: finish the host side of the last lvbgpu_chains_commit (Follow).  resolve_follow: every chain parked
+// (inside a multi-chain call); settle: from anywhere - every entry point that reads a chain's host topology calls it
+int resolve_follow(lvbgpu_ctx *ctx);
+int settle(lvbgpu_ctx *ctx);
 } // namespace lvbgpu_detail
 
 using namespace lvbgpu_detail;

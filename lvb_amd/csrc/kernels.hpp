@@ -194,7 +194,7 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
 
 // rebuild the generator's tables of the picked candidates' chains on the device (one workgroup per pick)
 constexpr uint32_t REBUILD_THREADS = 1024;
-constexpr uint32_t REBUILD_MAX_NODES = (MAX_LDS_BYTES - 16) / 16; // four int32 arrays in LDS; larger trees keep the host path
+constexpr uint32_t REBUILD_MAX_NODES = (MAX_LDS_BYTES - 32) / 24; // four int32 arrays + one uint2 array in LDS; larger trees keep the host path
 // a move that is not a candidate of a device batch (a re-root named by the host): its chain, its new root and its
 // rewrites ext_edits[edit_off .. edit_off + n_edits)
 struct RebuildExt

@@ -666,6 +666,8 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
          *t_depth = tab + 4 * (size_t)nb, *t_tin = tab + 5 * (size_t)nb, *t_first = tab + 6 * (size_t)nb,
          *t_order = tab + 7 * (size_t)nb, *t_up = tab + 7 * (size_t)nb + g.leaf_order_len;
     int32_t *left = lds_i32, *right = left + nb, *parent = right + nb, *nleaf = parent + nb, *shared = nleaf + nb; // shared[0] root
+    // one step of a root-ward walk as ONE 8-byte LDS read: {parent, weight}; 8-byte aligned behind the int32 arrays
+    uint2 *step = reinterpret_cast<uint2 *>(lds_i32 + ((4 * (size_t)nb + 4 + 1) & ~(size_t)1));
     const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
     for (int32_t v = tid; v < nb; v += nt)
     {
@@ -717,25 +719,31 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
                 atomicAdd(&nleaf[x], 1);
             }
     __syncthreads();
-    // everything else is a function of the node's own path to the root: its length is the depth, the ancestors met at
-    // distances 1, 2, 4, .. are the lifting table's entries (the root beyond), and the preorder number (left subtree
-    // first) and the position of the first leaf below are sums along it - stepping up from a right child skips its left
-    // sister's whole subtree, from a left child only the parent
+    // What a node's root-ward walk adds at each step depends on the node stepped FROM only: from a right child the
+    // preorder number skips the left sister's whole subtree (2 leaves-below, and as many leaf positions), from a left
+    // child just the parent.  Packed once per node - {parent, weight}, weight = 2 nleaf[left sister] or 1 - the walk
+    // below is one 8-byte LDS read per level instead of a chain of four dependent ones (parent, right[parent],
+    // left[parent], nleaf[that]): the kernel's time was its depth (20-31 us on the start trees of a 500-taxon run,
+    // 8 us on the shallow trees at its end) and it sits on the accept path of every annealing step.
     for (int32_t v = tid; v < nb; v += nt)
     {
-        int32_t tv = 0, fv = 0, d = 0, filled = 0;
+        const int32_t p = parent[v];
+        step[v] = make_uint2((uint32_t)p, (v != root && right[p] == v) ? 2u * (uint32_t)nleaf[left[p]] : 1u);
+    }
+    __syncthreads();
+    // everything else is a function of the node's own path to the root: its length is the depth, the ancestors met at
+    // distances 1, 2, 4, .. are the lifting table's entries (the root beyond), and the preorder number (left subtree
+    // first) and the position of the first leaf below are sums along it (weight, and weight / 2: 1 / 2 = 0)
+    for (int32_t v = tid; v < nb; v += nt)
+    {
+        uint32_t tv = 0, fv = 0;
+        int32_t d = 0, filled = 0;
         for (int32_t x = v; x != root;)
         {
-            const int32_t p = parent[x];
-            if (right[p] == x)
-            {
-                const int32_t ls = nleaf[left[p]];
-                tv += 2 * ls;
-                fv += ls;
-            }
-            else
-                tv += 1;
-            x = p;
+            const uint2 s = step[x];
+            tv += s.y;
+            fv += s.y >> 1;
+            x = (int32_t)s.x;
             d++;
             if ((d & (d - 1)) == 0 && filled < K)
                 t_up[(size_t)filled++ * nb + v] = (IdxT)x; // d = 2^filled
@@ -761,7 +769,7 @@ hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t s
         ga = *gather;
     if (k == 0)
         return hipSuccess;
-    const size_t lds = ((size_t)4 * g.nb + 4) * sizeof(int32_t);
+    const size_t lds = (((size_t)4 * g.nb + 4 + 1) & ~(size_t)1) * sizeof(int32_t) + (size_t)g.nb * sizeof(uint2);
     if (lds > MAX_LDS_BYTES)
         return hipErrorInvalidValue; // the caller keeps the host path for trees this large
     static bool raised_on[64];
