@@ -86,6 +86,8 @@ def parse_args(argv=None):
                          "thread of its own (lvbhost_anneal_chain_groups); 1 = all chains lock-stepped in one context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 / 16 384 and uniform-alignment legs")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip BASELINE.json's other single-GPU configurations (cfg2 64 x 10k NNI, cfg5 2000 x 200k TBR)")
     ap.add_argument("--headline-only", action="store_true",
                     help="the timed region and its roofline only (profiling runs: every scoring walk of the process is "
                          "then one of the headline's device-built batches)")
@@ -527,15 +529,95 @@ def tree_arrays_of(tree):
 
 
 def load_traffic(args, mixed: bool):
+    return traffic_for(args.taxa, args.sites, args.batch, args.move, mixed)
+
+
+def traffic_for(taxa: int, sites: int, batch: int, move: str, mixed: bool = False):
     tfile = ROOT / "profiles" / "traffic.json"
     if not tfile.exists():
         return None
     t = json.loads(tfile.read_text())
     for e in t if isinstance(t, list) else [t]:
         if (e.get("taxa"), e.get("sites"), e.get("batch"), e.get("move"), bool(e.get("mixed_walk", False))) == \
-                (args.taxa, args.sites, args.batch, args.move, mixed):
+                (taxa, sites, batch, move, mixed):
             return e["hbm_bytes_per_launch"]   # rocprofv3 PMC passes (profiles/collect.sh), gfx950-corrected
     return None
+
+
+def config_leg(ranks, device: int, cfg: str, taxa: int, sites: int, move: str, batches, seed: int, steps: int, walk: int = 75,
+               multi_chain=()):
+    """One of BASELINE.json's other single-GPU configurations through the headline's own measurement: submit -> lengths
+    with two steps in flight, the walk's duration from HIP events, D measured on the timed batches, the roofline block
+    (L2 -> CU path; `hbm` from the rocprofv3 PMC entry of that shape in profiles/traffic.json where there is one)."""
+    from lvb_amd import api, host
+    t0 = time.perf_counter()
+    rows, min_len = host.prepare_alignment(synth_rows(taxa, sites, seed, "tree"))
+    ctx = api.FitchContext(text_rows=rows, device=device)
+    tree = host.HostTree(taxa, seed=ranks.restart_seed(seed))
+    tree.upload(ctx)
+    length = random_walk(ctx, tree, MOVES[move], walk)
+    out = {"config": cfg, "taxa": taxa, "sites": sites, "sites_after_constant_cut": len(rows[0]), "nwords": ctx.nwords,
+           "move": move, "start_tree": f"random + {walk} accepted moves", "tree_length": length, "min_len_tree": min_len,
+           "resident_tree_block_mb": round((2 * taxa - 3) * ((ctx.nwords + 127) // 128 * 128) * 8 / 1e6, 1),
+           "setup_seconds": round(time.perf_counter() - t0, 1)}
+    for B in batches:
+        r = submit_to_lengths(ctx, ranks, B, MOVES[move], steps, 5, 1000, settle=40)
+        out[f"B{B}"] = {
+            "value": r["scored_per_step"] * steps / r["elapsed_s"], "unit": "trees/s", "ms_per_step": 1e3 * r["elapsed_s"] / steps,
+            "steps": steps, "walk_us": 1e3 * r["launch_ms"], "mean_dirty_nodes": round(r["mean_dirty"], 2),
+            "roofline": roofline_block(ctx, B, r["alg_bytes"], r["launch_ms"], r["mean_dirty"],
+                                       traffic_for(taxa, sites, B, move), 6 if taxa >= 1000 else 20),
+        }
+    if multi_chain:
+        # small shapes do not fill the chip with one chain's batch (cfg2: 1024 candidates x 5 tiles = 5120 waves against
+        # 8192 wave slots, a 13 us walk inside a launch chain): the path's own remedy is the one annealing uses - R
+        # independent chains (restarts) in one context, ONE generator launch and ONE walk for all of them per step
+        # (lvbgpu_chains_submit with R draws); every chain's lengths are what its own single-chain step gives
+        # (tests/test_gpu_chains.py::test_cfg2_chains_step_equals_single_chain_steps)
+        B = batches[0]
+        for R in multi_chain:
+            mctx = api.FitchContext(text_rows=rows, device=device)
+            mctx.set_chains(R)
+            trees = []
+            for c in range(R):
+                t = host.HostTree(taxa, seed=ranks.restart_seed(seed) * 100 + c)
+                mctx.select_chain(c)
+                t.upload(mctx)
+                random_walk(mctx, t, MOVES[move], walk)
+                trees.append(t)
+            draws = np.zeros(R, dtype=api.DRAW_DTYPE)
+            outs = [np.zeros(R * B, dtype=np.int64), np.zeros(R * B, dtype=np.int64)]
+            for c in range(R):
+                draws[c]["chain"], draws[c]["count"], draws[c]["kind"] = c, B, MOVES[move]
+
+            def submit(slot, seed):
+                for c in range(R):
+                    draws[c]["seed"] = (seed * 64 + c) & 0xFFFFFFFFFFFFFFFF
+                mctx._chk(mctx.lib.lvbgpu_chains_submit(mctx.h, slot, R, draws.ctypes.data))
+
+            def run(n, first_seed):
+                for j in range(min(2, n)):
+                    submit(j % 2, first_seed + j)
+                for i in range(n):
+                    mctx._chk(mctx.lib.lvbgpu_chains_collect(mctx.h, i % 2, outs[i % 2]))
+                    if i + 2 < n:
+                        submit(i % 2, first_seed + i + 2)
+            run(60, 1)
+            mctx.synchronize()
+            t1 = time.perf_counter()
+            run(steps, 1000)
+            mctx.synchronize()
+            dt = time.perf_counter() - t1
+            out[f"chains{R}_B{B}"] = {"value": R * B * steps / dt, "unit": "trees/s", "ms_per_step": 1e3 * dt / steps, "chains": R,
+                                      "candidates_per_step": R * B,
+                                      "what": f"{R} chains x {B} candidates per step: one generator launch and one walk for all of them, "
+                                              "two steps in flight"}
+            for t in trees:
+                t.close()
+            mctx.close()
+    tree.close()
+    ctx.close()
+    return out
 
 
 # ----------------------------------------------------------------------------------------- one rank
@@ -593,7 +675,8 @@ def rank_main(args) -> None:
         return int(-ranks.max_over_ranks(-float(best_local)))
 
     # ---- the timed region: K steps of submit -> lengths on the host (+ the min-reduce over ranks)
-    head = submit_to_lengths(ctx, ranks, B, kind, args.steps, args.warmup, 1000, reduce_best, settle=args.settle)
+    head = submit_to_lengths(ctx, ranks, B, kind, args.steps, args.warmup, 1000, reduce_best if world > 1 else None,
+                             settle=args.settle)
     per_step = head["scored_per_step"] if head["scored_per_step"] else B
     total_trees = per_step * args.steps * world
     per_rank = ranks.all_values(per_step * args.steps / head["elapsed_local"])   # each rank's own clock around ITS region
@@ -666,6 +749,15 @@ def rank_main(args) -> None:
                                  "sites_after_constant_cut": len(urows[0])}
             uctx.close()
         out["shapes"] = shapes
+
+    if extras and not args.no_configs:
+        # BASELINE.json configs[1] and configs[4] at one GPU, measured like the headline (same code path, same events)
+        out["configs"] = {
+            "cfg2": config_leg(ranks, ranks.device, "BASELINE configs[1]: 64 taxa x 10 000 sites, NNI neighbourhood, batch = 1024",
+                               64, 10000, "nni", (1024,), args.seed, steps_side, multi_chain=(4, 8)),
+            "cfg5": config_leg(ranks, ranks.device, "BASELINE configs[4] at one GPU: 2000 taxa x 200 000 sites, TBR neighbourhood, "
+                               "matrix and tree HBM-resident", 2000, 200000, "tbr", (1024, 4096), args.seed, max(20, steps_side // 2)),
+        }
 
     if extras and args.mixed_walk > 0:
         # the shape an annealing run spends its time on: the walk drifts toward uniform-random trees whose

@@ -863,6 +863,9 @@ extern "C" int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         if (ms > 0.f)
             best = std::max(best, (double)loads * 1024.0 * reps / (ms * 1e-3) / 1e9);
+        if (getenv("LVBGPU_PROBE_VERBOSE") && ms > 0.f) // both depths, not only the better one (tools/cfg5_probe.py)
+            fprintf(stderr, "[lvbgpu_probe_l2] B=%d rows/wave=%d ring=%d: %.1f us per launch, %.0f GB/s\n", B, rows_per_wave, ring,
+                    1e3 * ms / reps, (double)loads * 1024.0 * reps / (ms * 1e-3) / 1e9);
     }
     *gb_per_s = best;
     return LVBGPU_OK;

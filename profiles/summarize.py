@@ -19,8 +19,24 @@ ROOT = Path(__file__).resolve().parent.parent
 KERNEL = "fitch_walk<false,"  # <COMMIT=false, WIDE=...>
 
 
+def workload_of(extra) -> dict:
+    """taxa / sites / batch / move of the profiled bench run, from the bench arguments it was taken with"""
+    key = dict(taxa=500, sites=50000, batch=4096, move="spr")
+    ex = list(extra)
+    for i, a in enumerate(ex[:-1]):
+        if a in ("--taxa", "--sites", "--batch"):
+            key[a[2:]] = int(ex[i + 1])
+        elif a == "--move":
+            key["move"] = ex[i + 1]
+    return key
+
+
 def main(tag: str, mixed: bool = False, extra=()) -> None:
+    if tag.startswith("-"):
+        raise SystemExit(f"usage: summarize.py <tag> [mixed] [bench args ...]   ('{tag}' is not a tag)")
     src = ROOT / "gpurun_out" / f"prof_{tag}"
+    if not src.is_dir():
+        raise SystemExit(f"{src} does not exist: run profiles/collect.sh {tag} on the GPU box first")
     stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], ROOT / "profiles" / f"{tag}_kernel_stats.csv")
@@ -34,6 +50,8 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
                 # (r02t: <.., true>; later: <.., 1> / <.., 2>)
                 if KERNEL in name and not (name.count(",") == 2 and not name.endswith((", 0>", ", false>"))):
                     counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if not counters and not stats:
+        raise SystemExit(f"nothing under {src} matches the scoring kernel: no summary written")
     summary = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(counters.items())}
     mean = lambda k: summary[k]["mean_per_launch"] if k in summary else None
     derived = {}
@@ -64,7 +82,7 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
         entries = json.loads(tf.read_text()) if tf.exists() else []
         if isinstance(entries, dict):
             entries = [entries]
-        key = dict(taxa=500, sites=50000, batch=4096, move="spr", mixed_walk=mixed)
+        key = dict(workload_of(extra), mixed_walk=mixed)
         entries = [e for e in entries if any(e.get(k, False if k == "mixed_walk" else None) != v for k, v in key.items())]
         entries.append(dict(key, hbm_bytes_per_launch=derived["hbm_read_bytes_per_launch_corrected"] + derived.get(
             "hbm_write_bytes_per_launch", 0.0), source=f"profiles/{tag}_pmc_summary.json"))

@@ -37,7 +37,49 @@ FIELDS = {"rearrangements": r"Rearrangements evaluated: +(\d+)", "trees": r"Topo
           "score": r"Tree score: +(\d+)", "t0": r"SA Starting Temperature: +([0-9.]+)"}
 
 
+# A run at a shape where the speculative batches are LONG (hundreds of proposals drawn ahead, scored through
+# lvbgpu_score_moves: refsearch.cpp's device-move path), on a synthetic alignment the test regenerates from its seed
+# (tests/synth.treelike_rows(taxa, sites, 4000 + taxa), written as the reference's PHYLIP reader wants it)
+SYNTHETIC = [(200, 20000, 77, 1)]
+
+
+def write_synthetic(path, taxa, sites):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from tests import synth
+    rows = synth.treelike_rows(taxa, sites, 4000 + taxa)
+    with open(path, "w") as f:
+        f.write(f"{taxa} {sites}\n")
+        for i, r in enumerate(rows):
+            f.write(f"T{i:<9d}{r.decode()}\n")
+
+
+def synthetic():
+    cases = []
+    for taxa, sites, seed, alg in SYNTHETIC:
+        with tempfile.TemporaryDirectory() as d:
+            write_synthetic(Path(d) / "infile", taxa, sites)
+            args = ["-s", str(seed), "-a", str(alg), "-p", "1"]
+            p = subprocess.run([str(REFBIN), *args], cwd=d, capture_output=True, text=True, timeout=3000, check=True)
+            out = {}
+            for k, pat in FIELDS.items():
+                m = re.search(pat, p.stdout)
+                out[k] = m.group(1) if k == "t0" else int(m.group(1))
+            trees = (Path(d) / "outtree").read_bytes()
+            out["outtree_sha256"] = hashlib.sha256(trees).hexdigest()
+            cases.append({"taxa": taxa, "sites": sites, "seed": seed, "algorithm": alg, "args": args, "expect": out})
+            print(taxa, sites, seed, alg, out)
+    doc = {"_comment": "Runs of the compiled reference program (oracle/_ref/lvb_ref) on synthetic alignments "
+                       "(tests/synth.treelike_rows(taxa, sites, 4000 + taxa)); see gen_ref_trajectories.py --synthetic. "
+                       "Output of the reference, not of this repository's code.",
+           "cases": cases}
+    (ROOT / "tests" / "golden" / "ref_trajectories_synthetic.json").write_text(json.dumps(doc, indent=1) + "\n")
+
+
 def main():
+    import sys
+    if "--synthetic" in sys.argv:
+        return synthetic()
     cases = []
     for infile, seed, alg, cool, max_trees in RUNS:
         with tempfile.TemporaryDirectory() as d:

@@ -24,6 +24,20 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert d["config"]["best_length"] == 1000              # the minimum sat on rank 1: the reduce crossed ranks
     assert d["config"]["seed_sum"] == 3001 + 3002          # every rank had its own restart seed
     assert "lvbgpu_allreduce_min" in d["config"]["parallelism"]
+    # the timed region measures steady state: one untimed min-reduce (+ barrier) BEFORE t0, so that the communicator's
+    # lazy first-collective set-up is not read as a scaling loss; the in-region reduce is timed on its own
+    assert d["config"]["order"] == ["reduce:warmup", "barrier", "t0", "steps", "reduce:timed", "t1"]
+    assert d["config"]["reduces"] == 2 and d["config"]["reduce_ms"] >= 0.0
+    assert d["config"]["per_rank"] == [1.0, 2.0] and d["config"]["comm_size"] == 2      # every rank's own value is in the line
+
+
+def test_one_rank_needs_no_reduce():
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--dry-ranks", "--steps", "3"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["config"]["order"] == ["barrier", "t0", "steps", "reduce:timed", "t1"]
+    assert d["config"]["reduces"] == 0 and d["config"]["reduce_ms"] == 0.0
 
 
 def test_a_failing_rank_fails_the_run():

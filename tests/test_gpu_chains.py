@@ -557,3 +557,29 @@ def test_groups_side_by_side_on_the_gpu(mods):
         t.close()
     for c in ctxs:
         c.close()
+
+
+def test_cfg2_chains_step_equals_single_chain_steps(mods):
+    """BASELINE configs[1] (64 x 10 000, NNI, 1024 candidates) through the multi-chain step - R chains x 1024 candidates in
+    one generator launch and one walk, which is how bench.py fills the chip at this shape - gives every chain exactly the
+    lengths its own lvbgpu_propose_score step gives (same seed => same moves), two steps in flight included."""
+    api, host = mods
+    n, m, R, B = 64, 10000, 4, 1024
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 3))
+    multi, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
+    multi.set_chains(R)
+    ref.set_chains(R)
+    for c in range(R):
+        t = host.HostTree(n, seed=300 + c)
+        for ctx in (multi, ref):
+            ctx.select_chain(c)
+            t.upload(ctx)
+    counts = multi.chains_submit(0, [(c, B, 0, 10 + c) for c in range(R)])
+    multi.chains_submit(1, [(c, B, 0, 50 + c) for c in range(R)])
+    for slot, base in ((0, 10), (1, 50)):
+        got = multi.chains_collect(slot, counts)
+        for c in range(R):
+            ref.select_chain(c)
+            assert np.array_equal(got[c], ref.propose_score(B, 0, base + c)), (slot, c)
+    multi.close()
+    ref.close()

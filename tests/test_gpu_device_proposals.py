@@ -81,6 +81,62 @@ def test_device_draws_cover_the_neighbourhood(mods):
     ctx.close()
 
 
+def test_device_draws_follow_the_uniform_law(mods):
+    """The admissible sets are the reference's and the device draws uniformly over them (chi-square at n = 20):
+    NNI over the 2 (n - 3) (node, side) pairs; SPR sources over the 2n - 6 nodes that may be pruned, and, given the most
+    frequent source, destinations over ITS admissible set.  (The reference's own randpint gives the two END values of
+    its range half weight - it rounds uni() * upper to nearest, RandomNumberGenerator.c:243-246 - so its draws are not
+    exactly uniform; the device's are.  Exact-trajectory runs draw on the host with the reference's generator.)"""
+    api, host = mods
+    n = 20
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, 200, 5))
+    ctx = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(n, seed=11)
+    tree.upload(ctx)
+    _, left, right, root = ctx.topology()
+    parent = np.full(2 * n - 3, -1)
+    for v in range(2 * n - 3):
+        if left[v] >= 0:
+            parent[left[v]] = parent[right[v]] = v
+
+    def chi2(counts, expected):
+        return float(((counts - expected) ** 2 / expected).sum())
+
+    def loose(dof):            # far out in the tail (p ~ 1e-6): the seeds are fixed, this guards against a skewed generator
+        return dof + 5.0 * (2.0 * dof) ** 0.5
+
+    B = 6800
+    ctx.propose_score(B, 0, 1234)
+    info = np.array([ctx.proposal_edits(b)[1] for b in range(B)])
+    cells = (info[:, 1] - n) * 2 + info[:, 2]                     # (u, which child of u was given away)
+    counts = np.bincount(cells, minlength=2 * (n - 3)).astype(float)
+    assert (counts > 0).all() and chi2(counts, B / (2 * (n - 3))) < loose(2 * (n - 3) - 1)
+
+    B = 12000
+    ctx.propose_score(B, 1, 4321)
+    info = np.array([ctx.proposal_edits(b)[1] for b in range(B)])
+    src, dest = info[:, 1], info[:, 2]
+    ok_src = [v for v in range(2 * n - 3) if v != root and v != left[root] and v != right[root]]
+    counts = np.array([(src == v).sum() for v in ok_src], dtype=float)
+    assert counts.sum() == B and chi2(counts, B / len(ok_src)) < loose(len(ok_src) - 1)
+    s0 = ok_src[int(np.argmax(counts))]
+    sp = parent[s0]
+    ss = right[sp] if left[sp] == s0 else left[sp]
+
+    def below(v, a):
+        while v != -1:
+            if v == a:
+                return True
+            v = parent[v]
+        return False
+    ok_dest = [v for v in range(2 * n - 3) if v not in (s0, sp, ss, root) and not below(v, s0)]
+    got = dest[src == s0]
+    counts = np.array([(got == v).sum() for v in ok_dest], dtype=float)
+    assert counts.sum() == len(got)                                # nothing outside the admissible set
+    assert chi2(counts, len(got) / len(ok_dest)) < loose(len(ok_dest) - 1)
+    ctx.close()
+
+
 def test_move_schedules_of_the_reference(mods):
     """-a 0: NNI/SPR alternate by parity; -a 1: kinds drawn with the given probabilities."""
     api, host = mods

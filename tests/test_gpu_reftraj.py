@@ -91,3 +91,27 @@ def test_fresh_run_side_by_side_with_the_reference_binary(tmp_path, n, m, seed, 
     assert (res["rearrangements"], res["trees"], res["best_length"]) == (
         want["Rearrangements evaluated"], want["Topologies recovered"], want["Tree score"])
     assert trees == (tmp_path / "outtree").read_bytes()
+
+
+SYNTH = json.loads((GOLD / "ref_trajectories_synthetic.json").read_text())["cases"]
+
+
+@pytest.mark.parametrize("case", SYNTH, ids=[f"synthetic-{c['taxa']}x{c['sites']}-s{c['seed']}-a{c['algorithm']}" for c in SYNTH])
+def test_golden_run_at_a_shape_with_long_batches(tmp_path, case):
+    """the small golden runs above are latency-bound chains of short batches; here the reference's
+    run is long enough in its frozen tail for hundreds of proposals to be drawn ahead, which go to the device as their
+    16-byte move parameters (lvbgpu_score_moves: refsearch.cpp's device-move path).  The reference's numbers and its
+    output tree were recorded here by tests/golden/gen_ref_trajectories.py --synthetic (25-100 s of oracle/_ref/lvb_ref
+    on the CPU); the alignment is regenerated from its seed."""
+    from tests.golden.gen_ref_trajectories import write_synthetic
+    infile = tmp_path / "infile"
+    write_synthetic(infile, case["taxa"], case["sites"])
+    res, trees = search(infile, case["seed"], case["algorithm"])
+    e = case["expect"]
+    assert f"{res['t0']:.8f}" == e["t0"]
+    assert (res["rearrangements"], res["best_length"], res["trees"]) == (e["rearrangements"], e["score"], e["trees"])
+    assert hashlib.sha256(trees).hexdigest() == e["outtree_sha256"]
+    assert res["device_move_steps"] > 0, "no batch was long enough for the device-move path: the shape no longer tests it"
+    print(f"\n{case['taxa']} x {case['sites']} -s {case['seed']} -a {case['algorithm']}: {res['rearrangements']} rearrangements in "
+          f"{res['seconds']:.2f} s, {res['device_steps']} device steps ({res['device_move_steps']} through lvbgpu_score_moves), "
+          f"{res['scored']} candidates scored")
