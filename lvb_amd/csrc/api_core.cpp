@@ -845,16 +845,18 @@ extern "C" int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave
     HIPCHK(ctx, ctx->d_probe_sink.reserve(64));
     const uint32_t ngroups = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
     double best = 0.0;
+    // experiment knob: the same reads as if the block were laid out tile-major (stride 64 in the probe kernel)
+    const uint32_t probe_stride4 = getenv("LVBGPU_PROBE_TILE_MAJOR") ? 64u : ctx->stride4;
     for (int ring : {4, 8})
     {
         uint64_t loads = 0;
         for (int i = 0; i < 3; i++) // warm the caches and the clocks
-            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, ctx->rows_total(), ctx->ntiles, ngroups,
+            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, probe_stride4, ctx->rows_total(), ctx->ntiles, ngroups,
                                         (uint32_t)B, (uint32_t)rows_per_wave, ring, (uint4 *)ctx->d_probe_sink.p, &loads,
                                         ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         for (int i = 0; i < reps; i++)
-            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, ctx->stride4, ctx->rows_total(), ctx->ntiles, ngroups,
+            HIPCHK(ctx, launch_l2_probe((const uint4 *)ctx->d_rows, probe_stride4, ctx->rows_total(), ctx->ntiles, ngroups,
                                         (uint32_t)B, (uint32_t)rows_per_wave, ring, (uint4 *)ctx->d_probe_sink.p, &loads,
                                         ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));

@@ -750,7 +750,8 @@ __global__ __launch_bounds__(WALK_THREADS) void l2_probe_kernel(const uint4 *row
     const uint32_t seed = cand * 2654435761u + 12345u;
     for (uint32_t t = t0; t < t1; t++)
     {
-        const uint4 *base = rows + (size_t)t * 64u + lane;
+        // stride4 == 64: the probe emulates a TILE-MAJOR block ([tile][row][1 KiB]: a tile's column slice contiguous)
+        const uint4 *base = rows + (stride4 == 64u ? (size_t)t * nrows * 64u : (size_t)t * 64u) + lane;
         uint32_t s = seed;
         uint4 ring[RING];
 #pragma unroll

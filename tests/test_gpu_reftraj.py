@@ -35,7 +35,7 @@ if not os.environ.get("LVB_ALL_TRAJ"):
 CASES = CASES + [b for b in BLACKBOX if os.environ.get("LVB_ALL_TRAJ") or b["format"] == "clustal"]
 
 
-def search(path, seed, algorithm, cooling="g", max_batch=None, max_trees=0, fmt="phylip"):
+def search(path, seed, algorithm, cooling="g", max_batch=None, max_trees=0, fmt="phylip", device_moves_min=None):
     from lvb_amd import api, host
     names, rows = host.read_alignment(path, fmt)
     rows, min_len = host.prepare_alignment(rows)
@@ -46,6 +46,8 @@ def search(path, seed, algorithm, cooling="g", max_batch=None, max_trees=0, fmt=
         p.max_trees = max_trees
         if max_batch:
             p.max_batch = max_batch
+        if device_moves_min is not None:
+            p.device_moves_min = device_moves_min
         res, tree = host.reference_search(ctx.h, p)
         out = []
         for t in tree.best_trees():
@@ -98,20 +100,22 @@ SYNTH = json.loads((GOLD / "ref_trajectories_synthetic.json").read_text())["case
 
 @pytest.mark.parametrize("case", SYNTH, ids=[f"synthetic-{c['taxa']}x{c['sites']}-s{c['seed']}-a{c['algorithm']}" for c in SYNTH])
 def test_golden_run_at_a_shape_with_long_batches(tmp_path, case):
-    """the small golden runs above are latency-bound chains of short batches; here the reference's
-    run is long enough in its frozen tail for hundreds of proposals to be drawn ahead, which go to the device as their
-    16-byte move parameters (lvbgpu_score_moves: refsearch.cpp's device-move path).  The reference's numbers and its
+    """the small golden runs above are latency-bound chains of short batches; here a run at a
+    batch-sized shape (200 x 20 000: 10 tiles, 31 000 device steps) whose batches go to the device as their 16-byte move
+    parameters (lvbgpu_score_moves: refsearch.cpp's device-move path).  The reference's numbers and its
     output tree were recorded here by tests/golden/gen_ref_trajectories.py --synthetic (25-100 s of oracle/_ref/lvb_ref
     on the CPU); the alignment is regenerated from its seed."""
     from tests.golden.gen_ref_trajectories import write_synthetic
     infile = tmp_path / "infile"
     write_synthetic(infile, case["taxa"], case["sites"])
-    res, trees = search(infile, case["seed"], case["algorithm"])
+    # (this run's batches stay below the default threshold of 128 proposals for the device-move path - the chain accepts
+    # too often - so the threshold is lowered: every batch of 8 proposals or more is scored from its move parameters)
+    res, trees = search(infile, case["seed"], case["algorithm"], device_moves_min=8)
     e = case["expect"]
     assert f"{res['t0']:.8f}" == e["t0"]
     assert (res["rearrangements"], res["best_length"], res["trees"]) == (e["rearrangements"], e["score"], e["trees"])
     assert hashlib.sha256(trees).hexdigest() == e["outtree_sha256"]
-    assert res["device_move_steps"] > 0, "no batch was long enough for the device-move path: the shape no longer tests it"
+    assert res["device_move_steps"] > 1000, "the device-move path (lvbgpu_score_moves) was hardly used: the shape no longer tests it"
     print(f"\n{case['taxa']} x {case['sites']} -s {case['seed']} -a {case['algorithm']}: {res['rearrangements']} rearrangements in "
           f"{res['seconds']:.2f} s, {res['device_steps']} device steps ({res['device_move_steps']} through lvbgpu_score_moves), "
           f"{res['scored']} candidates scored")
