@@ -120,11 +120,14 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     a.len_out = (unsigned long long *)ctx->d_cout.p;
     a.changes_out = (unsigned long long *)((char *)ctx->d_cout.p + oo_ch);
     a.root_slot = n_out;
-    a.in_stride4 = Wp / 2;
+    a.in_stride4 = Wp / 2;                // the staging arenas are row-major
+    a.in_tile_bytes = 1024;
+    a.block_bytes = (uint64_t)n_in * Wp * 8u;
     a.nrows = n_in; // rows of this call's staging block
     a.bias_from = UINT32_MAX; // tokens name staging slots, not nodes of a resident tree
     a.chain_rows = 0;
     a.out_stride4 = Wp / 2;
+    a.out_tile4 = 64;
     a.B = 1;
     a.ntiles = ctx->ntiles;
     a.ngroups = ctx->ntiles;

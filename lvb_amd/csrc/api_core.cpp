@@ -51,11 +51,14 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const void *prog, size_t off_toks, size_
     a.s_all = ctx->d_scalars;
     a.len_out = (unsigned long long *)d_len;
     a.changes_out = ctx->d_changes;
-    a.in_stride4 = ctx->stride4;
+    a.in_stride4 = 64;                                   // tile-major: [tile][row][64 groups of 16 bytes]
+    a.in_tile_bytes = (uint64_t)ctx->rows_total() * 1024u;
+    a.block_bytes = (uint64_t)ctx->rows_total() * ctx->stride_words * 8u;
     a.nrows = ctx->rows_total();
     a.bias_from = (uint32_t)ctx->n;
     a.chain_rows = ctx->chain_rows();
-    a.out_stride4 = ctx->stride4;
+    a.out_stride4 = 64;
+    a.out_tile4 = (uint64_t)ctx->rows_total() * 64u;
     a.B = B;
     a.ntiles = ctx->ntiles;
     a.ngroups = choose_groups(B, ctx->ntiles, ctx->target_waves);
@@ -89,9 +92,8 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     ctx->nwords = nwords;
     ctx->nb = (int32_t)(2 * n - 3);
     ctx->ntiles = round_up((uint32_t)nwords, TILE_WORDS) / TILE_WORDS;
-    // tuning knobs for experiments: extra row padding (in tiles) and the wave-count target
-    const char *pad = getenv("LVBGPU_STRIDE_PAD_TILES");
-    ctx->stride_words = (ctx->ntiles + (pad ? (uint32_t)atoi(pad) : 0u)) * TILE_WORDS;
+    // a row is ntiles whole tiles long (padding holds all-ones); tuning knob for experiments: the wave-count target
+    ctx->stride_words = ctx->ntiles * TILE_WORDS;
     ctx->stride4 = ctx->stride_words / 2;
     if (const char *tw = getenv("LVBGPU_TARGET_WAVES"))
         ctx->target_waves = (uint32_t)std::max(1, atoi(tw));
@@ -128,14 +130,20 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     return LVBGPU_OK;
 }
 
-// everything that is not a leaf word becomes all-ones (inert under fitch); then the leaf rows go
-// from the reference's nibble layout to the device's bit-plane layout (all-ones stays all-ones)
-int finish_rows(lvbgpu_ctx *ctx)
+// The leaf rows arrive row-major in `leaves` ([n][stride_words], the reference's nibble layout).  Everything that is not a
+// leaf word becomes all-ones (inert under fitch: padding words here, the internal rows with the memset of the whole
+// resident block); the leaf rows go from nibbles to bit planes (all-ones stays all-ones) and from there to their places
+// in the tile-major resident block.
+int finish_rows(lvbgpu_ctx *ctx, DevBuf &leaves)
 {
-    HIPCHK(ctx, launch_fill_pad(ctx->d_rows, ctx->rows_total(), (uint32_t)ctx->nwords, ctx->stride_words,
-                                (uint32_t)ctx->n, ctx->stream));
-    HIPCHK(ctx, launch_relayout((uint4 *)ctx->d_rows, (uint32_t)ctx->n, ctx->stride4, true, ctx->stream));
+    HIPCHK(ctx, launch_fill_pad((uint64_t *)leaves.p, (uint32_t)ctx->n, (uint32_t)ctx->nwords, ctx->stride_words, (uint32_t)ctx->n,
+                                ctx->stream));
+    HIPCHK(ctx, launch_relayout((uint4 *)leaves.p, (uint32_t)ctx->n, ctx->stride4, true, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_rows, 0xFF, (size_t)ctx->rows_total() * ctx->stride_words * 8, ctx->stream));
+    HIPCHK(ctx, launch_rows_to_tiles((const uint4 *)leaves.p, (uint4 *)ctx->d_rows, (uint32_t)ctx->n, ctx->rows_total(), ctx->ntiles,
+                                     ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    leaves.release();
     return LVBGPU_OK;
 }
 
@@ -361,16 +369,19 @@ extern "C" int lvbgpu_create(lvbgpu_ctx **out, int device, long n, long nwords, 
     if (!ctx)
         return LVBGPU_E_NOMEM;
     int rc = context_common_init(ctx, device, n, nwords);
+    DevBuf leaves; // row-major staging of the leaf rows (released by finish_rows)
     if (rc == LVBGPU_OK)
     {
-        hipError_t e = hipMemcpy2DAsync(ctx->d_rows, (size_t)ctx->stride_words * 8, leaf_matrix,
-                                        (size_t)row_stride_words * 8, (size_t)nwords * 8, (size_t)n,
-                                        hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = leaves.reserve((size_t)n * ctx->stride_words * 8);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(leaves.p, (size_t)ctx->stride_words * 8, leaf_matrix, (size_t)row_stride_words * 8,
+                                 (size_t)nwords * 8, (size_t)n, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess)
             rc = ctx->fail_hip(e, "upload leaf matrix");
     }
     if (rc == LVBGPU_OK)
-        rc = finish_rows(ctx);
+        rc = finish_rows(ctx, leaves);
+    leaves.release();
     if (rc != LVBGPU_OK)
     {
         g_last_error_noctx = ctx->last_error;
@@ -390,10 +401,18 @@ extern "C" int lvbgpu_create_from_text(lvbgpu_ctx **out, int device, long n, lon
     if (!ctx)
         return LVBGPU_E_NOMEM;
     int rc = context_common_init(ctx, device, n, lvbgpu_words_per_row(m));
+    DevBuf leaves; // row-major staging of the leaf rows (released by finish_rows)
     if (rc == LVBGPU_OK)
-        rc = encode_into(ctx, n, m, rows, ctx->d_rows, ctx->stride_words);
+    {
+        const hipError_t e = leaves.reserve((size_t)n * ctx->stride_words * 8);
+        if (e != hipSuccess)
+            rc = ctx->fail_hip(e, "leaf row staging");
+    }
     if (rc == LVBGPU_OK)
-        rc = finish_rows(ctx);
+        rc = encode_into(ctx, n, m, rows, (uint64_t *)leaves.p, ctx->stride_words);
+    if (rc == LVBGPU_OK)
+        rc = finish_rows(ctx, leaves);
+    leaves.release();
     if (rc != LVBGPU_OK)
     {
         g_last_error_noctx = ctx->last_error;
@@ -577,9 +596,14 @@ extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
         (void)hipFree(scalars);
         return ctx->fail_hip(e, "lvbgpu_set_chains: allocate");
     }
-    HIPCHK(ctx, hipMemcpyAsync(rows, ctx->d_rows, (size_t)ctx->n * row_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(rows + (size_t)ctx->n * ctx->stride_words, 0xFF, (size_t)(ctx->rows_total() - ctx->n) * row_bytes,
-                               ctx->stream));
+    // tile-major blocks: all-ones everywhere, then every tile's n leaf slices (1 KiB each, contiguous) move to the front
+    // of that tile in the new block
+    HIPCHK(ctx, hipMemsetAsync(rows, 0xFF, (size_t)ctx->rows_total() * row_bytes, ctx->stream));
+    {
+        const size_t old_total = (size_t)ctx->n + (size_t)old_chains * (size_t)(ctx->n - 3);
+        HIPCHK(ctx, hipMemcpy2DAsync(rows, (size_t)ctx->rows_total() * 1024u, ctx->d_rows, old_total * 1024u, (size_t)ctx->n * 1024u,
+                                     (size_t)ctx->ntiles, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     HIPCHK(ctx, hipMemsetAsync(changes, 0, (size_t)(ctx->rows_total() + nchains) * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(scalars, 0, (size_t)nchains * 32, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -717,8 +741,8 @@ extern "C" int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // resident rows are bit planes; hand back the reference's nibble layout
     HIPCHK(ctx, ctx->d_export.reserve((size_t)ctx->stride_words * 8));
-    HIPCHK(ctx, launch_export_row((const uint4 *)(ctx->d_rows + (size_t)ctx->row_of(node) * ctx->stride_words),
-                                  (uint4 *)ctx->d_export.p, ctx->stride4, ctx->stream));
+    HIPCHK(ctx, launch_export_row((const uint4 *)ctx->d_rows, ctx->row_of(node), ctx->rows_total(), ctx->ntiles,
+                                  (uint4 *)ctx->d_export.p, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_export.p, (size_t)ctx->nwords * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return LVBGPU_OK;
@@ -845,8 +869,9 @@ extern "C" int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave
     HIPCHK(ctx, ctx->d_probe_sink.reserve(64));
     const uint32_t ngroups = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
     double best = 0.0;
-    // experiment knob: the same reads as if the block were laid out tile-major (stride 64 in the probe kernel)
-    const uint32_t probe_stride4 = getenv("LVBGPU_PROBE_TILE_MAJOR") ? 64u : ctx->stride4;
+    // the resident block is tile-major (stride 64 in the probe kernel); LVBGPU_PROBE_ROW_MAJOR: the same reads as if it
+    // were row-major, as it was until round 3 (tools/cfg5_probe.py)
+    const uint32_t probe_stride4 = getenv("LVBGPU_PROBE_ROW_MAJOR") ? ctx->stride4 : 64u;
     for (int ring : {4, 8})
     {
         uint64_t loads = 0;

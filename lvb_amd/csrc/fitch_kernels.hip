@@ -221,9 +221,10 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     auto biased = [&](uint32_t v) { return v >= a.bias_from ? v + row_bias : v; };
     const uint32_t *__restrict__ tk = a.toks + cd.tok_off;
     const int32_t *__restrict__ ds = a.dsts + cd.dst_off;
-    uint32_t col = tile_begin * 64u + lane;          // 16-byte group within a row
-    uint32_t voff = col * 16u;                       // its byte offset (a row is far below 4 GiB)
-    const char *__restrict__ in = reinterpret_cast<const char *>(a.rows_in);
+    // this lane's 16-byte group of row 0 in the wave's first tile: input as a byte address (lane_ptr below), output as
+    // an index in 16-byte units (kernels.hpp: tile-major resident block, row-major staging arenas)
+    [[maybe_unused]] uint64_t out_col = (uint64_t)tile_begin * a.out_tile4 + lane;
+    const char *__restrict__ in = reinterpret_cast<const char *>(a.rows_in) + (uint64_t)tile_begin * a.in_tile_bytes + lane * 16u;
 
     uint4 acc;
     uint32_t sp = 0;       // stack pointer (levels)
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     // row at byte offset `off` (wave-uniform) from rows_in -> this lane's group.  lane_ptr (rows_in +
     // this lane's column offset) is kept opaque so the add stays ONE vector instruction taking the
     // scalar pair as an operand, instead of being regrouped into scalar adds
-    global_cp lane_ptr = (global_cp)(in + voff);
+    global_cp lane_ptr = (global_cp)in;
     auto load_row = [&](uint64_t off) -> uint4 {
         asm volatile("" : "+v"(lane_ptr));
         const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(lane_ptr + off);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
         {
             const int32_t dst = __builtin_amdgcn_readlane(mydst, (int)s);
             if (dst >= 0)
-                a.rows_out[(size_t)biased((uint32_t)dst) * a.out_stride4 + col] = my_rows[(size_t)s * 64u];
+                a.rows_out[(size_t)biased((uint32_t)dst) * a.out_stride4 + out_col] = my_rows[(size_t)s * 64u];
         }
         if (mycnt)
             add_count(k_flushed + lane, mydst, mycnt);
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
         s_all_early = a.s_all[4u * chain];
     }
 
-    for (uint32_t tile = tile_begin; tile < tile_end; tile++, col += 64u, lane_ptr += 1024)
+    for (uint32_t tile = tile_begin; tile < tile_end; tile++, out_col += a.out_tile4, lane_ptr += a.in_tile_bytes)
     {
         acc = ones;
         if constexpr (COMMIT)
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                 step(jl + 2u, f & 64u, rc);
         }
         if constexpr (COMMIT)
-            flush(); // this tile's last sets (col moves on with the tile)
+            flush(); // this tile's last sets (out_col moves on with the tile)
     }
 
     // changes of this lane = 32 sites per combine (and per chain start, see step) minus the non-empty ones
@@ -683,12 +684,22 @@ __global__ void relayout_kernel(uint4 *rows, uint32_t nrows, uint32_t stride4, u
     }
 }
 
-// one resident row -> reference nibble layout in a scratch buffer (lvbgpu_get_sets)
-__global__ void export_row_kernel(const uint4 *row, uint4 *out, uint32_t stride4)
+// one row of the tile-major resident block -> reference nibble layout, contiguous, in a scratch buffer (lvbgpu_get_sets)
+__global__ void export_row_kernel(const uint4 *rows, uint32_t row, uint32_t total_rows, uint32_t ntiles, uint4 *out)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < stride4)
-        out[g] = planes_to_nibbles(row[g]);
+    if (g < ntiles * 64u)
+        out[g] = planes_to_nibbles(rows[((size_t)(g >> 6) * total_rows + row) * 64u + (g & 63u)]);
+}
+
+// leaf rows as they are encoded (row-major) -> their places in the tile-major resident block
+__global__ void rows_to_tiles_kernel(const uint4 *src, uint4 *dst, uint32_t nrows, uint32_t total_rows, uint32_t ntiles)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ntiles * 64u)
+        return;
+    for (uint32_t row = blockIdx.y; row < nrows; row += gridDim.y)
+        dst[((size_t)(g >> 6) * total_rows + row) * 64u + (g & 63u)] = src[(size_t)row * ntiles * 64u + g];
 }
 
 // DNAToBinary on the device (reference DataOperations.c:164-249): one thread = one packed word in
@@ -750,7 +761,7 @@ __global__ __launch_bounds__(WALK_THREADS) void l2_probe_kernel(const uint4 *row
     const uint32_t seed = cand * 2654435761u + 12345u;
     for (uint32_t t = t0; t < t1; t++)
     {
-        // stride4 == 64: the probe emulates a TILE-MAJOR block ([tile][row][1 KiB]: a tile's column slice contiguous)
+        // stride4 == 64: a TILE-MAJOR block ([tile][row][1 KiB], the resident layout); else row-major
         const uint4 *base = rows + (stride4 == 64u ? (size_t)t * nrows * 64u : (size_t)t * 64u) + lane;
         uint32_t s = seed;
         uint4 ring[RING];
@@ -857,7 +868,7 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream, ui
     // (the direction alternates per CONTEXT - flip_state is the caller's counter: a process-wide one would be shared,
     // and raced on, by contexts driven from different host threads)
     a.flip = 0;
-    if (allow_flip && flip_state && !commit && (uint64_t)args.nrows * args.in_stride4 * 16u > FLIP_MIN_BYTES)
+    if (allow_flip && flip_state && !commit && args.block_bytes > FLIP_MIN_BYTES)
         a.flip = ((*flip_state)++) & 1u;
     a.tiles_per = a.ntiles / a.ngroups;
     a.tiles_rem = a.ntiles % a.ngroups;
@@ -1004,9 +1015,18 @@ hipError_t launch_relayout(uint4 *rows, uint32_t nrows, uint32_t stride4, bool t
     return hipGetLastError();
 }
 
-hipError_t launch_export_row(const uint4 *row, uint4 *out, uint32_t stride4, hipStream_t stream)
+hipError_t launch_export_row(const uint4 *rows, uint32_t row, uint32_t total_rows, uint32_t ntiles, uint4 *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(export_row_kernel, dim3((stride4 + 255) / 256), dim3(256), 0, stream, row, out, stride4);
+    hipLaunchKernelGGL(export_row_kernel, dim3((ntiles * 64u + 255) / 256), dim3(256), 0, stream, rows, row, total_rows, ntiles, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_to_tiles(const uint4 *src, uint4 *dst, uint32_t nrows, uint32_t total_rows, uint32_t ntiles, hipStream_t stream)
+{
+    if (nrows == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(rows_to_tiles_kernel, dim3((ntiles * 64u + 255) / 256, nrows < 65535u ? nrows : 65535u), dim3(256), 0, stream,
+                       src, dst, nrows, total_rows, ntiles);
     return hipGetLastError();
 }
 

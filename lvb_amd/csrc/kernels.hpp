@@ -64,7 +64,17 @@ struct WalkArgs
     unsigned long long *len_out;        // [B], zeroed by the caller
     unsigned long long *changes_out;    // COMMIT: per-node change accumulators, zeroed for dsts
     unsigned long long *s_all_out;      // COMMIT on the resident tree: running sum of all internal changes (may be null)
+    // Where a state set lies: group g (16 bytes = 32 sites) of row r in tile t is at
+    //     rows + t * tile_stride + r * stride4 + g          (16-byte units)
+    // The RESIDENT block is tile-major - [tile][row][64 groups]: stride4 = 64, tile stride = rows x 64 - so that a tile's
+    // column slice, which is what the waves of an XCD read together, is ONE contiguous piece of memory (500 x 50k: 1 MB,
+    // 2000 x 200k: 4 MB) instead of a thousand 1 KiB pieces a row apart: DRAM pages, TLB entries and L2 sets are used
+    // whole (pure-load probe, same reads: 2000 x 200k B = 4096 608 -> 522 us, 500 x 50k B = 16 384 400 -> 372 us).
+    // Staging arenas (strict compat) are row-major: stride4 = row length, tile stride = 64.
     uint32_t in_stride4, out_stride4;   // row strides in 16-byte units
+    uint64_t in_tile_bytes;             // input tile stride in BYTES (1024 for row-major blocks)
+    uint64_t out_tile4;                 // output tile stride in 16-byte units (64 for row-major blocks)
+    uint64_t block_bytes;               // size of the block rows_in points into (picks the launch's direction flip)
     uint32_t nrows;                     // rows addressable through rows_in (picks 32- or 64-bit row offsets)
     // several resident trees in one block: rows / change slots of node v of chain c sit at v + c * chain_rows for
     // v >= bias_from (the internal nodes; bias_from = UINT32_MAX turns the mapping off: staging arenas), the root
@@ -239,9 +249,12 @@ hipError_t launch_fill_pad(uint64_t *rows, uint32_t nrows, uint32_t nwords, uint
                            uint32_t first_full_row, hipStream_t stream);
 // reference nibble layout <-> device bit-plane layout, in place, rows [0, nrows)
 hipError_t launch_relayout(uint4 *rows, uint32_t nrows, uint32_t stride4, bool to_planes, hipStream_t stream);
-// one bit-plane row -> nibble layout in `out`
-hipError_t launch_export_row(const uint4 *row, uint4 *out, uint32_t stride4, hipStream_t stream);
+// rows [0, nrows) of a row-major block (stride4 = ntiles * 64) -> rows [0, nrows) of a tile-major block of total_rows rows
+hipError_t launch_rows_to_tiles(const uint4 *src, uint4 *dst, uint32_t nrows, uint32_t total_rows, uint32_t ntiles, hipStream_t stream);
+// one bit-plane row of the tile-major resident block -> nibble layout, contiguous, in `out`
+hipError_t launch_export_row(const uint4 *rows, uint32_t row, uint32_t total_rows, uint32_t ntiles, uint4 *out, hipStream_t stream);
 // ceiling probe of the walk's memory path: one launch; *loads_out = 1 KiB row loads it issues
+// (stride4 == 64: the block is tile-major, as the resident block is; else row-major with that row stride)
 hipError_t launch_l2_probe(const uint4 *rows, uint32_t stride4, uint32_t nrows, uint32_t ntiles, uint32_t ngroups,
                            uint32_t B, uint32_t ntok, int ring, uint4 *sink, uint64_t *loads_out, hipStream_t stream);
 hipError_t launch_encode_text(const uint8_t *text, uint32_t n, uint64_t m, uint32_t nwords, uint32_t stride_words,

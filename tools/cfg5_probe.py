@@ -14,10 +14,10 @@ nwords = api.words_per_row(m)
 rng = np.random.default_rng(1)
 enc = rng.integers(0, 2**63, size=(n, nwords), dtype=np.uint64) | np.uint64(0x1111111111111111)
 ctx = api.FitchContext(enc)
-for layout in ("row-major (as is)", "tile-major (emulated)"):
+for layout in ("tile-major (the resident layout)", "row-major (emulated: the layout until round 3)"):
     print("==", layout, file=sys.stderr, flush=True)
-    if layout.startswith("tile"):
-        os.environ["LVBGPU_PROBE_TILE_MAJOR"] = "1"
+    if layout.startswith("row"):
+        os.environ["LVBGPU_PROBE_ROW_MAJOR"] = "1"
     for B in ((1024, 4096) if n >= 1000 else (4096, 16384)):
         ctx.probe_l2(B, 34 if n >= 1000 else 24, 6)
 ctx.close()
