@@ -1,14 +1,17 @@
-"""How many of a batch's row reads would pairing candidates in one wave save?  (CPU, numpy)
+"""How many of a batch's row reads would walking two candidates per wave save?  (CPU, numpy)
 
-Two candidates whose root-ward dirty paths run together from some junction node up to the root read the SAME clean rows
-for that stretch (the siblings off the common path) with the same token flags.  A wave walking both programs would load
-each of those rows once and feed two accumulators: per shared token one load instead of two (the combines stay two).
+Two candidates whose programs end alike - the same clean rows with the same token flags from some point to the root -
+could be walked by ONE wave that carries two states (accumulator, operand stack, counters) and loads every row of the
+common suffix once: per shared token one load instead of two (the combines stay two).
 
-Estimate on the bench's own batches (500 x 50k tree shape, SPR, B = 4096; start tree + 75 moves, and + 3000 moves):
-programs from the host builder (the device generator emits the same programs), candidates sorted by their program read
-backwards (so neighbours in the order share the longest suffixes) and paired greedily: best of the two neighbours
-first.  Reported: the fraction of all row reads that disappear, and the same restricted to suffixes of whole tokens
-without merges (what a simple paired loop could take).
+Estimate on the bench's own batches (500-taxon tree shape, B = 4096; start tree + 75 moves, and + 3000 moves), programs
+from the host builder (the device generator emits the same programs).  Four orders of the candidates, consecutive ones
+paired:
+  full      sorted by the program read backwards (what a full sort gives; greedy matching of neighbours: "pairs")
+  groups4   the same, four candidates per wave
+  key       sorted by ONE small key a device could produce in a single counting-sort pass: the preorder number of the
+            bottom node of the program's last chain
+  plain     full order, but only suffixes without a chain start or merge inside (what a simple paired loop could take)
 
   python tools/shared_suffix_estimate.py [B] [moves]
 """
@@ -23,39 +26,66 @@ from lvb_amd import host  # noqa: E402
 n = 500
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kinds = {"nni": 0, "spr": 1, "tbr": 2}
+FRESH, PUSH, MSH, MMASK = 1 << 30, 1 << 31, 24, 0x3F
 
 
-def common_suffix(a, b):
+def plain(t):
+    return (t & (FRESH | PUSH)) == 0 and ((t >> MSH) & MMASK) == 0
+
+
+def common_suffix(a, b, only_plain=False):
     k, la, lb = 0, len(a), len(b)
-    while k < la and k < lb and a[la - 1 - k] == b[lb - 1 - k]:
+    while k < la and k < lb and a[la - 1 - k] == b[lb - 1 - k] and (not only_plain or plain(int(a[la - 1 - k]))):
         k += 1
     return k
 
 
-def estimate(tree, kind, B, group=2):
-    progs = []
+def preorder(tree):
+    p, l, r = tree.arrays()
+    tin, cnt, st = np.zeros(len(p), int), 0, [tree.root]
+    while st:
+        v = st.pop()
+        tin[v] = cnt
+        cnt += 1
+        if l[v] >= 0:
+            st.append(r[v])
+            st.append(l[v])
+    return tin
+
+
+def last_chain_bottom(t, d, root):
+    """the node the last chain of the program starts at (its second combine where the first is the re-used graft node)"""
+    f = max(j for j in range(len(t)) if int(t[j]) & FRESH)
+    comb = 0
+    for j in range(f):
+        tj = int(t[j])
+        if not (tj & FRESH):
+            comb += 1
+        comb += (tj >> MSH) & MMASK
+    cand = [x for x in d[comb:comb + 2] if x >= 0]
+    return cand[1] if len(cand) > 1 else (cand[0] if cand else root)
+
+
+def estimate(tree, kind, B):
+    tin = preorder(tree)
+    progs, keys = [], []
     for _ in range(B):
-        e = tree.propose(kind)
-        progs.append(tree.program(mode=0, edits=e)["toks"])
+        pr = tree.program(mode=0, edits=tree.propose(kind))
+        progs.append(pr["toks"])
+        keys.append(tin[last_chain_bottom(pr["toks"], pr["dsts"], tree.root)])
     total = sum(len(p) for p in progs)
-    order = sorted(range(B), key=lambda i: tuple(progs[i][::-1].tolist()))
-    # suffix shared by neighbours in the sorted order
-    nb = [common_suffix(progs[order[i]], progs[order[i + 1]]) for i in range(B - 1)]
-    if group == 2:
-        # greedy matching on the path graph: take the longest shared suffixes first
-        used = np.zeros(B, bool)
-        saved = 0
-        for i in sorted(range(B - 1), key=lambda i: -nb[i]):
-            if not used[i] and not used[i + 1] and nb[i] > 0:
-                used[i] = used[i + 1] = True
-                saved += nb[i]
-        return total, saved, float(np.mean([len(p) for p in progs]))
-    # groups of `group` consecutive candidates: everybody shares the group's common suffix with the first
-    saved = 0
-    for g0 in range(0, B - group + 1, group):
-        k = min(nb[g0:g0 + group - 1])
-        saved += k * (group - 1)
-    return total, saved, float(np.mean([len(p) for p in progs]))
+    full = sorted(range(B), key=lambda i: tuple(progs[i][::-1].tolist()))
+    nb = [common_suffix(progs[full[i]], progs[full[i + 1]]) for i in range(B - 1)]
+    used, pairs = np.zeros(B, bool), 0
+    for i in sorted(range(B - 1), key=lambda i: -nb[i]):   # greedy matching on the path graph
+        if not used[i] and not used[i + 1] and nb[i] > 0:
+            used[i] = used[i + 1] = True
+            pairs += nb[i]
+    groups4 = sum(min(nb[g0:g0 + 3]) * 3 for g0 in range(0, B - 3, 4))
+    by_key = sorted(range(B), key=lambda i: keys[i])
+    consecutive = lambda order, only_plain=False: sum(common_suffix(progs[order[i]], progs[order[i + 1]], only_plain)
+                                                      for i in range(0, B - 1, 2))
+    return (total / B, pairs / total, groups4 / total, consecutive(by_key) / total, consecutive(full, True) / total)
 
 
 for walk in ([int(sys.argv[2])] if len(sys.argv) > 2 else [75, 3075]):
@@ -63,8 +93,7 @@ for walk in ([int(sys.argv[2])] if len(sys.argv) > 2 else [75, 3075]):
     for _ in range(walk):
         tree.apply(tree.propose(1))
     for name, kind in kinds.items():
-        total, saved, mean_tok = estimate(tree, kind, B)
-        t4, s4, _ = estimate(tree, kind, B, group=4)
-        print(f"walk {walk:5d} {name}: B={B} mean tokens {mean_tok:.1f} (D = {mean_tok - 3:.1f}); pairs: {saved / total:.3f} of the row reads "
-              f"shared; groups of 4: {s4 / t4:.3f}", flush=True)
+        mean_tok, pairs, groups4, key, pl = estimate(tree, kind, B)
+        print(f"walk {walk:5d} {name}: B={B} mean tokens {mean_tok:.1f} (D = {mean_tok - 3:.1f}); row reads shared: full order, pairs "
+              f"{pairs:.3f}, groups of 4 {groups4:.3f}; one-pass key {key:.3f}; plain suffixes only {pl:.3f}", flush=True)
     tree.close()
