@@ -208,6 +208,30 @@ int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_root *re
  * host, no device access */
 int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits);
 
+/* ---- a whole annealing step in one submission: the accept decision rides with the batch ----------------------------
+ * lvbgpu_chains_step_submit is lvbgpu_chains_submit plus, per draw, the RULE by which that chain accepts (Solve.c:303-378):
+ * candidate j of the draw (in order) is taken if its length is <= cur_length, or with probability
+ * exp(-deltah / temperature), deltah = min_len_tree / cur_length - min_len_tree / length capped at 1, and never once
+ * -deltah < temperature * log(1e-11); its uniform draw is a function of (accept_seed, j).  The chain's pick is the FIRST
+ * taken candidate; it is committed at once (lvbgpu_chains_commit's work) - where the batch allows it the device decides
+ * (the scoring walk's watcher waves apply the rule the moment a length is complete) and commit walk, table rebuild and
+ * the moves' way to the host are enqueued WITH the batch, so that no host round trip lies between a step's scoring and
+ * its commit; otherwise the library decides at the collect, by the same function (lvb_amd/csrc/decide.h).
+ * lvbgpu_chains_step_collect hands over the lengths (as lvbgpu_chains_collect) and picks_out[i] = index of the accepted
+ * candidate within draw i, or -1; lvbgpu_chains_step_edits(i) = the accepted move's rewrites (waits for them if they are
+ * still on their way).  A slot holds one step at a time; a step and plain batches may not be in flight together. */
+typedef struct
+{
+    int64_t cur_length;
+    double temperature;
+    double min_len_tree;
+    uint64_t accept_seed;
+} lvbgpu_chain_rule;
+int lvbgpu_chains_step_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws,
+                              const lvbgpu_chain_rule *rules);
+int lvbgpu_chains_step_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out, int32_t *picks_out);
+int lvbgpu_chains_step_edits(lvbgpu_ctx *ctx, int32_t i, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits);
+
 /* counts of the LAST device-built batch (as lvbgpu_batch_get_stats gives for host-built ones; candidates that
  * overflowed are left out): reads the batch's descriptors back - for measurement, not for the search */
 int lvbgpu_proposal_stats(lvbgpu_ctx *ctx, lvbgpu_batch_stats *out);

@@ -38,6 +38,8 @@ MOVE_DTYPE = np.dtype([("kind", np.int32), ("a", np.int32), ("b", np.int32), ("c
 DRAW_DTYPE = np.dtype([("chain", np.int32), ("count", np.int32), ("kind", np.int32), ("mix_a", np.uint32), ("mix_b", np.uint32),
                        ("_pad", np.uint32), ("seed", np.uint64)])  # lvbgpu_chain_draw (seed 8-byte aligned)
 PICK_DTYPE = np.dtype([("chain", np.int32), ("b", np.int32)])  # lvbgpu_chain_pick
+RULE_DTYPE = np.dtype([("cur_length", np.int64), ("temperature", np.float64), ("min_len_tree", np.float64),
+                       ("accept_seed", np.uint64)])  # lvbgpu_chain_rule
 
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
@@ -81,6 +83,9 @@ SIGNATURES = {
     "lvbgpu_chains_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "lvbgpu_chains_reroot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "lvbgpu_chains_picked_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lvbgpu_chains_step_submit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lvbgpu_chains_step_collect": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i32p]),
+    "lvbgpu_chains_step_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_proposal_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
     "lvbgpu_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
@@ -265,6 +270,27 @@ class FitchContext:
         out = np.zeros(int(np.sum(counts)), dtype=np.int64)
         self._chk(self.lib.lvbgpu_chains_collect(self.h, int(slot), out))
         return np.split(out, np.cumsum(counts)[:-1])
+
+    def chains_step(self, draws, rules, slot: int = 0):
+        """One annealing step for the listed chains: draws as chains_propose_score, rules = (cur_length, temperature,
+        min_len_tree, accept_seed) per draw -> (lengths per draw, picks per draw [-1: nothing accepted]); the accepted
+        moves are committed."""
+        d = self._draws(draws)
+        r = np.zeros(len(d), dtype=RULE_DTYPE)
+        for i, row in enumerate(rules):
+            r[i]["cur_length"], r[i]["temperature"], r[i]["min_len_tree"], r[i]["accept_seed"] = row
+        self._chk(self.lib.lvbgpu_chains_step_submit(self.h, int(slot), len(d), d.ctypes.data, r.ctypes.data))
+        out = np.zeros(int(d["count"].sum()), dtype=np.int64)
+        picks = np.zeros(len(d), dtype=np.int32)
+        self._chk(self.lib.lvbgpu_chains_step_collect(self.h, int(slot), out, picks))
+        return np.split(out, np.cumsum(d["count"])[:-1]), picks
+
+    def chains_step_edits(self, i: int) -> np.ndarray:
+        cap = 2 * self.nbranches + 8
+        buf = np.zeros(cap, dtype=EDIT_DTYPE)
+        ne = C.c_int32()
+        self._chk(self.lib.lvbgpu_chains_step_edits(self.h, int(i), buf.ctypes.data, cap, C.byref(ne)))
+        return buf[: ne.value].copy()
 
     def chains_reroot(self, reqs) -> None:
         """reqs: (chain, new_root_leaf) - re-root those chains in one commit walk."""

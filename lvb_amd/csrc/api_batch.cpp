@@ -341,6 +341,15 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         a.host_flag = b->watch_flag;
         a.step_seq = b->watch_seq;
         a.watcher = 1; // (launch_walk turns it off again for launches it does not fit)
+        if (b->rules) // the watcher waves also decide (lvbgpu_chains_step_submit made sure this launch fits the watcher)
+        {
+            a.rules = b->rules;
+            a.d_pick_out = b->d_pick;
+            a.host_pick = b->host_pick;
+            a.watch_done = b->watch_done;
+            a.npick_chains = b->npick_chains;
+            memcpy(a.pick_chain, b->pick_chain, sizeof a.pick_chain);
+        }
     }
     const bool timed = ctx->walk_timing && (ctx->wt_seen++ % ctx->wt_every) == 0;
     if (timed)

@@ -196,13 +196,20 @@ const char *move_defect(const Topology &t, const lvbgpu_move &m)
 // tree); lengths_out holds the segments one after the other.  `moves` (host-named moves): k == 1 only.
 // Two halves: submit (everything up to the lengths' read-back is enqueued; returns at once) and collect (waits for
 // that batch alone and hands the lengths over).  Two batches may be in flight, in slots 0 and 1.
-int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws, const lvbgpu_move *moves)
+int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const uint32_t *where, const int32_t *chains, uint64_t chain_mask,
+                   const uint32_t *d_pick, int *slot_out, uint32_t *seq_out, bool *tables_on_device_out);
+
+int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws, const lvbgpu_move *moves,
+                   const lvbgpu_chain_rule *rules = nullptr)
 {
-    if (!ctx || slot < 0 || slot >= lvbgpu_ctx::PROP_SLOTS || k < 1 || k > (int32_t)MAX_GEN_SEGS || !draws || (moves && k != 1))
+    if (!ctx || slot < 0 || slot >= lvbgpu_ctx::PROP_SLOTS || k < 1 || k > (int32_t)MAX_GEN_SEGS || !draws || (moves && k != 1) ||
+        (moves && rules))
         return LVBGPU_E_ARG;
     lvbgpu_ctx::PropSlot &ps = ctx->pslot[slot];
     if (ps.in_flight)
         return ctx->fail(LVBGPU_E_STATE, "that slot's batch has not been collected yet");
+    if (ctx->pslot[1 - slot].in_flight && (rules || ctx->pslot[1 - slot].step))
+        return ctx->fail(LVBGPU_E_STATE, "a step and another batch may not be in flight together");
     if (ctx->n < 5)
         return ctx->fail(LVBGPU_E_ARG, "rearrangements need at least 5 taxa");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -336,6 +343,59 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
             d_moves = (const lvbgpu_move_dev *)ctx->d_moves.p;
         }
     }
+    static const bool allow_watcher = [] {
+        const char *e = getenv("LVBGPU_WATCHER");
+        return !(e && e[0] == '0');
+    }();
+    // (pipelined batches of a small launch - below WATCH_PIPELINED_MAX_ITEMS waves - take the watcher too: the copy
+    // stream's two events and its copy cost such a step more than the hand-over lengthens its walk: 64 x 10k NNI,
+    // B = 1024: 34 -> 61 M candidates/s; 500 x 50k, B = 256: 8.2 -> 9.4, B = 1024: +4 %; at B = 4096 the two are equal
+    // within 1 % and the walk is 1.6 us shorter without the hand-over)
+    constexpr uint64_t WATCH_PIPELINED_MAX_ITEMS = 32768;
+    const uint32_t groups_now = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
+    ps.watched = allow_watcher && groups_now <= WATCH_MAX_GROUPS &&
+                 (!ctx->pslot[1 - slot].in_flight || (uint64_t)B * groups_now < WATCH_PIPELINED_MAX_ITEMS);
+    // A STEP: the rule by which every chain accepts rides with the batch.  Where this launch fits the watcher (always, for
+    // a lone batch of these shapes) and the chains' tables follow on the device, the device decides: the generator resets
+    // the chains' picks, the walk's watcher waves apply the rules, and commit walk, table rebuild and the moves' way to
+    // the host are enqueued right behind the walk (below) - else the host decides at the collect with the same function.
+    ps.step = rules != nullptr;
+    ps.step_decided = false;
+    ps.host_rules.clear();
+    uint32_t seg_where[MAX_CHAINS];
+    int32_t seg_chain[MAX_CHAINS];
+    if (rules)
+    {
+        uint32_t st = 0;
+        for (int32_t i = 0; i < k; i++)
+        {
+            ps.host_rules.push_back(DecideRule{(long long)rules[i].cur_length, rules[i].temperature, rules[i].min_len_tree,
+                                               (unsigned long long)rules[i].accept_seed, st, (uint32_t)draws[i].count});
+            seg_where[i] = st;
+            seg_chain[i] = draws[i].chain;
+            st += (uint32_t)draws[i].count;
+        }
+        const char *dd = getenv("LVBGPU_DEVICE_DECIDE"); // =0: the host decides (A/B runs, tests of the fallback; read per step)
+        const bool allow_device = !(dd && dd[0] == '0');
+        bool on_device = allow_device && ps.watched && (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
+        for (int32_t i = 0; i < k && on_device; i++)
+            on_device = ctx->parked[(size_t)draws[i].chain].d_topo_version == ctx->parked[(size_t)draws[i].chain].topo_version;
+        if (on_device)
+        {
+            HIPCHK(ctx, ps.h_rules.reserve((size_t)MAX_CHAINS * sizeof(DecideRule)));
+            HIPCHK(ctx, ps.h_pickout.reserve((size_t)MAX_CHAINS * 4));
+            const size_t old = ps.d_pick.cap;
+            HIPCHK(ctx, ps.d_pick.reserve((size_t)(MAX_CHAINS + 1) * 4));
+            if (ps.d_pick.cap != old) // once per slot: the watcher waves' finished-count starts at zero
+            {
+                HIPCHK(ctx, hipMemsetAsync(ps.d_pick.p, 0, ps.d_pick.cap, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            for (int32_t i = 0; i < k; i++)
+                ((DecideRule *)ps.h_rules.p)[draws[i].chain] = ps.host_rules[(size_t)i];
+            ps.step_decided = true;
+        }
+    }
     GenArgs ga{};
     ga.tables = ctx->d_topo4.p;
     ga.idx_bytes = ctx->gen_idx_bytes;
@@ -350,6 +410,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     ga.cands = (CandDesc *)bt->d_prog.p;
     ga.info = (ProposalInfo *)ps.d_pinfo.p;
     ga.len_out = (unsigned long long *)bt->d_len.p;
+    ga.pick_out = ps.step_decided ? (uint32_t *)ps.d_pick.p : nullptr;
     ga.moves = d_moves;
     static const bool gen_profile = getenv("LVBGPU_GEN_PROFILE") != nullptr;
     if (gen_profile)
@@ -393,35 +454,51 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     // beside the next batch's generator: in the main stream it held that generator back for 21 us, 34 -> 38.6 M
     // candidates/s), and the walk stays 1.6 us shorter without its hand-over.  LVBGPU_WATCHER=0: always the copy (A/B
     // runs); launches of more than WATCH_MAX_GROUPS tile groups keep it too.
-    static const bool allow_watcher = [] {
-        const char *e = getenv("LVBGPU_WATCHER");
-        return !(e && e[0] == '0');
-    }();
-    // (pipelined batches of a small launch - below WATCH_PIPELINED_MAX_ITEMS waves - take the watcher too: the copy
-    // stream's two events and its copy cost such a step more than the hand-over lengthens its walk: 64 x 10k NNI,
-    // B = 1024: 34 -> 61 M candidates/s; 500 x 50k, B = 256: 8.2 -> 9.4, B = 1024: +4 %; at B = 4096 the two are equal
-    // within 1 % and the walk is 1.6 us shorter without the hand-over)
-    constexpr uint64_t WATCH_PIPELINED_MAX_ITEMS = 32768;
-    const uint32_t groups_now = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
-    ps.watched = allow_watcher && groups_now <= WATCH_MAX_GROUPS &&
-                 (!ctx->pslot[1 - slot].in_flight || (uint64_t)B * groups_now < WATCH_PIPELINED_MAX_ITEMS);
     if (ps.watched)
     {
         if (!ps.h_flag.p)
         {
-            HIPCHK(ctx, ps.h_flag.reserve(WATCH_WAVES * 4));
-            memset(ps.h_flag.p, 0, WATCH_WAVES * 4);
+            HIPCHK(ctx, ps.h_flag.reserve((WATCH_WAVES + 1) * 4)); // one word per watcher wave + one behind the picks of a step
+            memset(ps.h_flag.p, 0, (WATCH_WAVES + 1) * 4);
         }
         bt->watch_flag = (uint32_t *)ps.h_flag.p;
         bt->watch_seq = ++ps.seq == 0xFFFFFFFFu ? (ps.seq = 1) : ps.seq; // 0xFFFFFFFF is the watcher's "gave up"
     }
     else
         bt->watch_flag = nullptr;
+    bt->rules = nullptr;
+    if (ps.step_decided)
+    {
+        bt->rules = (const DecideRule *)ps.h_rules.p;
+        bt->d_pick = (uint32_t *)ps.d_pick.p;
+        bt->watch_done = (uint32_t *)ps.d_pick.p + MAX_CHAINS;
+        bt->host_pick = (uint32_t *)ps.h_pickout.p;
+        bt->npick_chains = (uint32_t)k;
+        for (int32_t i = 0; i < k; i++)
+            bt->pick_chain[i] = (uint8_t)draws[i].chain;
+    }
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
     {
         ps.segs.clear();
         return rc;
+    }
+    if (ps.step_decided)
+    {
+        // right behind the walk, with no host round trip in between: what the accepted candidates need (every kernel
+        // adds its chain's pick itself and does nothing for a chain that accepted nothing)
+        // (gather and table rebuild run on the side stream: they read the picks, so this once they have to wait for the
+        // walk that decides them)
+        HIPCHK(ctx, hipEventRecord(ps.walk_ev, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->side_stream, ps.walk_ev, 0));
+        rc = enqueue_accept(ctx, ps, k, seg_where, seg_chain, seen, (const uint32_t *)ps.d_pick.p, &ps.step_pick_slot, &ps.step_seq,
+                            &ps.step_tables_on_device);
+        if (rc != LVBGPU_OK)
+        {
+            ps.segs.clear();
+            return rc;
+        }
+        ctx->pick_use_ord[ps.step_pick_slot] = ctx->submits + 1; // its readers run behind THIS batch's walk (take_pick_slot)
     }
     if (!ps.watched)
     {
@@ -608,6 +685,8 @@ extern "C" int lvbgpu_chains_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, co
 
 extern "C" int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
 {
+    if (ctx && slot >= 0 && slot < lvbgpu_ctx::PROP_SLOTS && ctx->pslot[slot].in_flight && ctx->pslot[slot].step)
+        return ctx->fail(LVBGPU_E_STATE, "that slot holds a step: collect it with lvbgpu_chains_step_collect");
     return propose_collect(ctx, slot, lengths_out);
 }
 
@@ -635,11 +714,14 @@ int resolve_follow(lvbgpu_ctx *ctx)
         if ((spins & 1023u) == 0 && clock.expired())
         {
             for (int32_t j = 0; j < f.k; j++) // the device may or may not have walked them: not trustworthy any more
-                ctx->parked[(size_t)f.chains[j]].have_tree = false;
+                if (f.has[j])
+                    ctx->parked[(size_t)f.chains[j]].have_tree = false;
             return ctx->fail_wait("lvbgpu_chains_commit: the picked moves' gather", clock.waited());
         }
     for (int32_t j = 0; j < f.k; j++)
     {
+        if (!f.has[j])
+            continue;
         const char *rec = h + o_out + (size_t)j * out_stride;
         const ProposalInfo pi = *(const ProposalInfo *)rec;
         ChainSlot &cs = ctx->parked[(size_t)f.chains[j]];
@@ -721,6 +803,111 @@ hipError_t order_rebuild_after_readers(lvbgpu_ctx *ctx, uint64_t chain_mask)
 } // namespace lvbgpu_detail
 
 
+namespace lvbgpu_detail
+{
+// What accepted candidates of the batch in `ps` need on the device, enqueued (nothing is waited for): their descriptors
+// and rewrites on the way into a pinned slot (gather), the generator's tables of their chains rebuilt (side stream), and
+// their own device-built programs walked in commit form (main stream).  where[j] is the batch position of pick j - or,
+// with d_pick != null (the picks are being decided on the device, lvbgpu_chains_step_submit), the position of the FIRST
+// candidate of chain chains[j], to which every kernel adds d_pick[chain] itself (doing nothing for a chain that
+// accepted nothing).
+int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const uint32_t *where, const int32_t *chains, uint64_t chain_mask,
+                   const uint32_t *d_pick, int *slot_out, uint32_t *seq_out, bool *tables_on_device_out)
+{
+    lvbgpu_batch *bt = ps.batch;
+    // a pinned slot: [flag][picks][k x (descriptor + rewrites)]
+    const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
+    const size_t o_out = 64 + align16((size_t)MAX_CHAINS * 4); // (the flag, a gap the picks used to lie in, the records)
+    int slot = 0;
+    HIPCHK(ctx, take_pick_slot(ctx, &slot));
+    HIPCHK(ctx, ctx->h_pick[slot].reserve(o_out + (size_t)MAX_CHAINS * out_stride));
+    char *h = (char *)ctx->h_pick[slot].p;
+    uint32_t *flag = (uint32_t *)h;
+    const uint32_t seq = ++ctx->pick_seq;
+    const size_t old_done = ctx->d_done.cap;
+    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
+    if (ctx->d_done.cap != old_done) // once per context: both streams below use it
+    {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint32_t *done = (uint32_t *)ctx->d_done.p;
+    // 1. what the host needs to follow the moves (so that it can work while the walk runs): descriptors and rewrites
+    //    are complete - the batch's lengths have been read - and nothing here touches state sets, so the gather runs
+    //    beside the commit walk; as the first workgroups of the table rebuild's launch where there is one (1b), else
+    //    as a launch of its own
+    GatherArgs gat{};
+    memcpy(gat.pick_idx, where, (size_t)k * 4);
+    gat.d_pick = d_pick;
+    for (int32_t j = 0; j < k; j++)
+        gat.pick_chain[j] = (uint8_t)chains[j];
+    gat.k = (uint32_t)k;
+    gat.info = (const ProposalInfo *)ps.d_pinfo.p;
+    gat.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
+    gat.stride_e = ctx->p_stride_e;
+    gat.out = h + o_out;
+    gat.out_stride = out_stride;
+    gat.flag = flag;
+    gat.seq = seq;
+    gat.arrived = done + MAX_CHAINS;
+    // 1b. the generator's tables of the picked chains follow their moves on the device (they describe the trees the
+    //     candidates were drawn from: the picks were checked against the chains' versions above)
+    bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
+    for (int32_t j = 0; j < k && tables_on_device; j++)
+        tables_on_device = ctx->parked[(size_t)chains[j]].d_topo_version == ctx->parked[(size_t)chains[j]].topo_version;
+    if (tables_on_device)
+    {
+        RebuildArgs ra{};
+        ra.tables = ctx->d_topo4.p;
+        ra.table_stride = ctx->gen_table_stride;
+        ra.idx_bytes = ctx->gen_idx_bytes;
+        ra.n = (int32_t)ctx->n;
+        ra.nb = ctx->nb;
+        ra.K = ctx->gen_kmax;
+        ra.leaf_order_len = (uint32_t)ctx->n;
+        memcpy(ra.pick_idx, where, (size_t)k * 4);
+        ra.d_pick = d_pick;
+        for (int32_t j = 0; j < k; j++)
+            ra.pick_chain[j] = (uint8_t)chains[j];
+        ra.cands = (const CandDesc *)bt->d_prog.p;
+        ra.info = (const ProposalInfo *)ps.d_pinfo.p;
+        ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
+        ra.stride_e = ctx->p_stride_e;
+        HIPCHK(ctx, order_rebuild_after_readers(ctx, chain_mask));
+        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream, &gat));
+        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
+        ctx->side_pending = true;
+    }
+    else
+        HIPCHK(ctx, launch_gather_picks(gat, ctx->side_stream));
+    // 2. the picked candidates' own programs in commit form: produced sets and change counts go to their chains'
+    //    rows, every candidate's last wave settles its chain's changes[] and S_all (fused commit)
+    HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
+    if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
+    {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
+        ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
+    }
+    HIPCHK(ctx, ctx->d_len.reserve(8));
+    WalkArgs a = resident_args(ctx, bt->d_prog.p, bt->off_toks, bt->off_dsts, ctx->d_len.p, (uint32_t)k, 1);
+    a.use_pick = d_pick ? 2 : 1;
+    memcpy(a.pick_idx, where, (size_t)k * 4);
+    a.d_pick = d_pick;
+    for (int32_t j = 0; j < k; j++)
+        a.pick_chain[j] = (uint8_t)chains[j];
+    a.s_all_out = (unsigned long long *)ctx->d_scalars;
+    a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
+    a.tmp_stride = (uint32_t)(ctx->nb + 1);
+    a.done_count = done;
+    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+
+    *slot_out = slot;
+    *seq_out = seq;
+    *tables_on_device_out = tables_on_device;
+    return LVBGPU_OK;
+}
+} // namespace lvbgpu_detail
+
 extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_pick *picks)
 {
     if (!ctx || k < 1 || k > MAX_CHAINS || !picks)
@@ -756,82 +943,17 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         if (((const int64_t *)bt->h_len.p)[where[(size_t)j]] >= PROPOSAL_OVERFLOW_LENGTH)
             return ctx->fail(LVBGPU_E_ARG, "pick " + std::to_string(j) + ": that candidate overflowed the per-candidate buffers");
     }
-    // a pinned slot: [flag][picks][k x (descriptor + rewrites)]
-    const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
-    const size_t o_out = 64 + align16((size_t)MAX_CHAINS * 4); // (the flag, a gap the picks used to lie in, the records)
+    std::vector<int32_t> pchains((size_t)k);
+    for (int32_t j = 0; j < k; j++)
+        pchains[(size_t)j] = picks[j].chain;
     int slot = 0;
-    HIPCHK(ctx, take_pick_slot(ctx, &slot));
-    HIPCHK(ctx, ctx->h_pick[slot].reserve(o_out + (size_t)MAX_CHAINS * out_stride));
-    char *h = (char *)ctx->h_pick[slot].p;
-    uint32_t *flag = (uint32_t *)h;
-    const uint32_t seq = ++ctx->pick_seq;
-    const size_t old_done = ctx->d_done.cap;
-    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
-    if (ctx->d_done.cap != old_done) // once per context: both streams below use it
+    uint32_t seq = 0;
+    bool tables_on_device = false;
     {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const int ra = enqueue_accept(ctx, ps, k, where.data(), pchains.data(), seen, nullptr, &slot, &seq, &tables_on_device);
+        if (ra != LVBGPU_OK)
+            return ra;
     }
-    uint32_t *done = (uint32_t *)ctx->d_done.p;
-    // 1. what the host needs to follow the moves (so that it can work while the walk runs): descriptors and rewrites
-    //    are complete - the batch's lengths have been read - and nothing here touches state sets, so the gather runs
-    //    beside the commit walk; as the first workgroups of the table rebuild's launch where there is one (1b), else
-    //    as a launch of its own
-    GatherArgs gat{};
-    memcpy(gat.pick_idx, where.data(), (size_t)k * 4);
-    gat.k = (uint32_t)k;
-    gat.info = (const ProposalInfo *)ps.d_pinfo.p;
-    gat.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
-    gat.stride_e = ctx->p_stride_e;
-    gat.out = h + o_out;
-    gat.out_stride = out_stride;
-    gat.flag = flag;
-    gat.seq = seq;
-    gat.arrived = done + MAX_CHAINS;
-    // 1b. the generator's tables of the picked chains follow their moves on the device (they describe the trees the
-    //     candidates were drawn from: the picks were checked against the chains' versions above)
-    bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES;
-    for (int32_t j = 0; j < k && tables_on_device; j++)
-        tables_on_device = ctx->parked[(size_t)picks[j].chain].d_topo_version == ctx->parked[(size_t)picks[j].chain].topo_version;
-    if (tables_on_device)
-    {
-        RebuildArgs ra{};
-        ra.tables = ctx->d_topo4.p;
-        ra.table_stride = ctx->gen_table_stride;
-        ra.idx_bytes = ctx->gen_idx_bytes;
-        ra.n = (int32_t)ctx->n;
-        ra.nb = ctx->nb;
-        ra.K = ctx->gen_kmax;
-        ra.leaf_order_len = (uint32_t)ctx->n;
-        memcpy(ra.pick_idx, where.data(), (size_t)k * 4);
-        ra.cands = (const CandDesc *)bt->d_prog.p;
-        ra.info = (const ProposalInfo *)ps.d_pinfo.p;
-        ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
-        ra.stride_e = ctx->p_stride_e;
-        HIPCHK(ctx, order_rebuild_after_readers(ctx, seen));
-        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream, &gat));
-        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
-        ctx->side_pending = true;
-    }
-    else
-        HIPCHK(ctx, launch_gather_picks(gat, ctx->side_stream));
-    // 2. the picked candidates' own programs in commit form: produced sets and change counts go to their chains'
-    //    rows, every candidate's last wave settles its chain's changes[] and S_all (fused commit)
-    HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
-    if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
-    {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
-        ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
-    }
-    HIPCHK(ctx, ctx->d_len.reserve(8));
-    WalkArgs a = resident_args(ctx, bt->d_prog.p, bt->off_toks, bt->off_dsts, ctx->d_len.p, (uint32_t)k, 1);
-    a.use_pick = 1;
-    memcpy(a.pick_idx, where.data(), (size_t)k * 4);
-    a.s_all_out = (unsigned long long *)ctx->d_scalars;
-    a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
-    a.tmp_stride = (uint32_t)(ctx->nb + 1);
-    a.done_count = done;
-    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     // 3. the host's topologies follow LATER (ctx->follow): the records are on their way into the pinned slot; versions
     //    move now, so that everything that compares versions (stale picks, stale batches) sees the tree as changed
     ctx->follow.pending = true;
@@ -841,6 +963,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     for (int32_t j = 0; j < k; j++)
     {
         ctx->follow.chains[j] = picks[j].chain;
+        ctx->follow.has[j] = true;
         ChainSlot &cs = ctx->parked[(size_t)picks[j].chain];
         cs.topo_version = ++ctx->version_counter;
         cs.cur_length_stale = true;
@@ -850,7 +973,122 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     forget_named_candidates(ctx, seen);
     ctx->last_pick_slot = slot;
     ctx->last_pick_count = k;
+    for (int32_t j = 0; j < k; j++)
+        ctx->last_pick_has[j] = true;
     return LVBGPU_OK;
+}
+
+// ---- a whole step: submit with rules, collect with picks (include/lvbgpu.h) ------------------------------------------
+extern "C" int lvbgpu_chains_step_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws,
+                                         const lvbgpu_chain_rule *rules)
+{
+    if (!rules)
+        return LVBGPU_E_ARG;
+    if (ctx)
+    {
+        const int rf = settle(ctx); // the step before this one: its moves have long arrived; their pinned slot may come round again
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
+    return propose_submit(ctx, slot, k, draws, nullptr, rules);
+}
+
+extern "C" int lvbgpu_chains_step_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out, int32_t *picks_out)
+{
+    if (!ctx || slot < 0 || slot >= lvbgpu_ctx::PROP_SLOTS || !picks_out)
+        return LVBGPU_E_ARG;
+    lvbgpu_ctx::PropSlot &ps = ctx->pslot[slot];
+    if (!ps.in_flight || !ps.step)
+        return ctx->fail(LVBGPU_E_STATE, "no step was submitted in that slot");
+    int rc = propose_collect(ctx, slot, lengths_out);
+    const int32_t k = (int32_t)ps.host_rules.size();
+    ps.step = false;
+    if (rc != LVBGPU_OK)
+    {
+        if (ps.step_decided) // commits may have been walked for picks nobody has seen: these trees cannot be trusted any more
+        {
+            AllParked guard(ctx);
+            for (const lvbgpu_ctx::PSeg &sg : ps.segs)
+                ctx->parked[(size_t)sg.chain].have_tree = false;
+        }
+        return rc;
+    }
+    ctx->step_map.assign((size_t)k, -1);
+    ctx->last_step_slot = slot;
+    if (!ps.step_decided)
+    {
+        // the host decides, by the same function, and commits as lvbgpu_chains_commit does
+        std::vector<lvbgpu_chain_pick> picks;
+        for (int32_t i = 0; i < k; i++)
+        {
+            const DecideRule &r = ps.host_rules[(size_t)i];
+            picks_out[i] = -1;
+            for (uint32_t j = 0; j < r.count; j++)
+                if (lvb_take(lengths_out[r.start + j] == INT64_MAX ? (long long)LVB_OVERFLOW_LENGTH : (long long)lengths_out[r.start + j], &r, j))
+                {
+                    picks_out[i] = (int32_t)j;
+                    ctx->step_map[(size_t)i] = (int32_t)picks.size();
+                    picks.push_back({ps.segs[(size_t)i].chain, (int32_t)j});
+                    break;
+                }
+        }
+        return picks.empty() ? LVBGPU_OK : lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
+    }
+    // the device has decided: the picks come behind the lengths, under a flag word of their own
+    {
+        const uint32_t *flag = (const uint32_t *)ps.h_flag.p + WATCH_WAVES;
+        const WaitClock clock(ctx->wait_limit_s);
+        for (uint32_t spins = 1; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != ps.seq; spins++)
+            if ((spins & 1023u) == 0 && clock.expired())
+            {
+                AllParked guard(ctx);
+                for (const lvbgpu_ctx::PSeg &sg : ps.segs)
+                    ctx->parked[(size_t)sg.chain].have_tree = false;
+                return ctx->fail_wait("lvbgpu_chains_step_collect: the step's picks", clock.waited());
+            }
+    }
+    AllParked guard(ctx);
+    const uint32_t *hp = (const uint32_t *)ps.h_pickout.p;
+    uint64_t moved = 0;
+    lvbgpu_ctx::Follow &f = ctx->follow; // (settled at the submit: nothing pending)
+    f.pending = false;
+    f.slot = ps.step_pick_slot;
+    f.k = k;
+    f.seq = ps.step_seq;
+    for (int32_t i = 0; i < k; i++)
+    {
+        const uint32_t pk = __atomic_load_n(hp + i, __ATOMIC_RELAXED);
+        const int32_t chain = ps.segs[(size_t)i].chain;
+        f.chains[i] = chain;
+        f.has[i] = pk != PICK_NONE;
+        ctx->last_pick_has[i] = f.has[i];
+        picks_out[i] = f.has[i] ? (int32_t)pk : -1;
+        if (!f.has[i])
+            continue;
+        if (pk >= (uint32_t)ps.segs[(size_t)i].count)
+            return ctx->fail(LVBGPU_E_STATE, "the device picked candidate " + std::to_string(pk) + " of a draw of " + std::to_string(ps.segs[(size_t)i].count));
+        ctx->step_map[(size_t)i] = i;
+        f.pending = true;
+        moved |= 1ull << chain;
+        ChainSlot &cs = ctx->parked[(size_t)chain];
+        cs.topo_version = ++ctx->version_counter;
+        cs.cur_length_stale = true;
+        if (ps.step_tables_on_device)
+            cs.d_topo_version = cs.topo_version; // rebuilt in place behind the walk
+    }
+    forget_named_candidates(ctx, moved);
+    ctx->last_pick_slot = ps.step_pick_slot;
+    ctx->last_pick_count = k;
+    return LVBGPU_OK;
+}
+
+extern "C" int lvbgpu_chains_step_edits(lvbgpu_ctx *ctx, int32_t i, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits)
+{
+    if (!ctx || i < 0)
+        return LVBGPU_E_ARG;
+    if ((size_t)i >= ctx->step_map.size() || ctx->step_map[(size_t)i] < 0)
+        return ctx->fail(LVBGPU_E_ARG, "that draw accepted nothing in the last step (or there was none)");
+    return lvbgpu_chains_picked_edits(ctx, ctx->step_map[(size_t)i], edits, cap, n_edits);
 }
 
 // Re-root several chains in ONE commit walk (arbreroot, TreeOperations.c:639-656, as rewrites along the old-root ..
@@ -1011,6 +1249,8 @@ extern "C" int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edi
         if (rf != LVBGPU_OK)
             return rf;
     }
+    if (!ctx->last_pick_has[j])
+        return ctx->fail(LVBGPU_E_ARG, "that chain accepted nothing in the last step");
     const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
     const char *rec = (const char *)ctx->h_pick[ctx->last_pick_slot].p + 64 + align16((size_t)MAX_CHAINS * 4) + (size_t)j * out_stride;
     const ProposalInfo pi = *(const ProposalInfo *)rec;

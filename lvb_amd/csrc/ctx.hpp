@@ -230,6 +230,16 @@ struct lvbgpu_ctx
         uint32_t seq = 0;
         bool watched = false;         // this batch's lengths come through the watcher, not a copy
         bool in_flight = false;
+        // a STEP (lvbgpu_chains_step_submit): the accept decision rides with the batch
+        bool step = false;            // rules were given
+        bool step_decided = false;    // ... and the device decides (else the host does, at the collect, with the same rule)
+        std::vector<DecideRule> host_rules; // by draw index
+        PinBuf h_rules;               // DecideRule[MAX_CHAINS] by chain: what the watcher waves read
+        DevBuf d_pick;                // uint32[MAX_CHAINS] by chain + the watcher waves' finished-count
+        PinBuf h_pickout;             // uint32[MAX_CHAINS] by draw index: the picks as the host reads them
+        int step_pick_slot = 0;       // pinned slot the accepted moves' records go to
+        uint32_t step_seq = 0;
+        bool step_tables_on_device = false;
     };
     static constexpr int PROP_SLOTS = 2;
     PropSlot pslot[PROP_SLOTS];
@@ -263,6 +273,9 @@ struct lvbgpu_ctx
     int pick_slot = 0;
     uint32_t pick_seq = 0;
     int last_pick_slot = 0, last_pick_count = 0; // what lvbgpu_chains_picked_edits reads
+    bool last_pick_has[MAX_CHAINS] = {};         // ... and which of those records exist
+    int last_step_slot = 0;                      // the slot of the last lvbgpu_chains_step_collect
+    std::vector<int32_t> step_map;               // ... its draws -> record index of lvbgpu_chains_picked_edits (-1: nothing accepted)
     DevBuf d_done; // per picked candidate: finished-wave count of a multi-chain commit (zero between launches)
     // The host side of the last lvbgpu_chains_commit, not done yet: the picked moves' descriptors and rewrites are on
     // their way into pinned slot `slot` (flag = seq), and the chains' host topologies follow when somebody needs them
@@ -276,6 +289,7 @@ struct lvbgpu_ctx
         int32_t k = 0;
         uint32_t seq = 0;
         int32_t chains[MAX_CHAINS];
+        bool has[MAX_CHAINS]; // record j exists (a step decided on the device writes none for a chain that accepted nothing)
     } follow;
     PinBuf h_pin;
     // direct steps: small batches whose programs the walk reads straight from h_pin and whose lengths its last
@@ -365,6 +379,11 @@ struct lvbgpu_batch
     // to watch_seq (pinned; null: no watcher, the caller copies the lengths back)
     uint32_t *watch_flag = nullptr;
     uint32_t watch_seq = 0;
+    // ... and, for a step decided on the device, apply these rules and leave the picks (kernels.hpp WalkArgs::rules)
+    const DecideRule *rules = nullptr;
+    uint32_t *d_pick = nullptr, *host_pick = nullptr, *watch_done = nullptr;
+    uint32_t npick_chains = 0;
+    uint8_t pick_chain[MAX_CHAINS] = {};
     bool spans_chains = false; // device-built batch over several chains: every program names its own chain
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)
     int32_t chain = 0;         // ... and which chain's tree that is

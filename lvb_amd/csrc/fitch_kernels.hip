@@ -172,6 +172,16 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                 const uint32_t i = base + lane;
                 if (i < a.B)
                 {
+                    // the accept decision (kernels.hpp WalkArgs::rules): the candidate's chain says which rule (fetched now,
+                    // over the host link, while the walking waves are still at it), the rule where the chain's candidates
+                    // start; the chain's pick is the smallest taken index
+                    uint32_t ch = 0;
+                    DecideRule rule{};
+                    if (a.rules)
+                    {
+                        ch = a.cands[i].flags >> CAND_CHAIN_SHIFT;
+                        rule = a.rules[ch];
+                    }
                     unsigned long long v;
                     uint32_t budget = 1u << 24; // ~ seconds: every walking wave finishes on its own, this is a backstop
                     while ((((v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & count_mask) >>
@@ -180,13 +190,36 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
                         __builtin_amdgcn_s_sleep(8);
                     gave_up |= budget == 0u;
                     __hip_atomic_store(a.host_len + i, v & ~count_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (a.rules && budget != 0u && lvb_take((long long)(v & ~count_mask), &rule, i - rule.start))
+                        atomicMin(a.d_pick_out + ch, i - rule.start);
                 }
             }
-            atomics_acknowledged(); // the wave's stores (all lanes) before its flag
+            atomics_acknowledged(); // the wave's stores and picks (all lanes) before its flag
             // every watcher wave has a flag word of its own (the host waits for all 32): no counter for them to meet at
             if (lane == 0)
                 __hip_atomic_store(a.host_flag + wid, __builtin_amdgcn_ballot_w64(gave_up) != 0ull ? 0xFFFFFFFFu : a.step_seq,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.rules)
+            {
+                // the picks go to the host once EVERY watcher wave has had its say: the last one to tick (all the others'
+                // atomics were acknowledged before their ticks were sent) copies them and sets the flag behind the waves'
+                uint32_t last = 0;
+                if (lane == 0)
+                    last = atomicAdd(a.watch_done, 1u) == WATCHERS - 1u ? 1u : 0u;
+                if (__builtin_amdgcn_readfirstlane(last))
+                {
+                    if (lane < a.npick_chains)
+                        __hip_atomic_store(a.host_pick + lane,
+                                           __hip_atomic_load(a.d_pick_out + a.pick_chain[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    atomics_acknowledged();
+                    if (lane == 0)
+                    {
+                        __hip_atomic_store(a.watch_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.host_flag + WATCHERS, a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
             return;
         }
     // a.flip: every other launch walks each XCD's share of the tile-major list from its far end.  A tree block beyond
@@ -214,7 +247,20 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     const uint32_t tile_begin = group * a.tiles_per + (group < a.tiles_rem ? group : a.tiles_rem);
     const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
 
-    const CandDesc cd = a.cands[(COMMIT && a.use_pick) ? a.pick_idx[cand] : cand];
+    uint32_t which = cand;
+    if constexpr (COMMIT)
+    {
+        if (a.use_pick == 2u) // decided on the device: this chain's pick, or nothing to do for any wave of this candidate
+        {
+            const uint32_t pk = a.d_pick[a.pick_chain[cand]];
+            if (pk == PICK_NONE)
+                return;
+            which = a.pick_idx[cand] + pk;
+        }
+        else if (a.use_pick)
+            which = a.pick_idx[cand];
+    }
+    const CandDesc cd = a.cands[which];
     // which resident tree: node numbers from bias_from on (the internal nodes) move by the chain's row block
     const uint32_t chain = cd.flags >> CAND_CHAIN_SHIFT;
     const uint32_t row_bias = chain * a.chain_rows;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "program.hpp"
+#include "decide.h"
 
 namespace lvbgpu
 {
@@ -30,6 +31,7 @@ constexpr uint64_t FLIP_MIN_BYTES = 64ull << 20;  // tree blocks beyond this alt
 // "length" the device generator gives a candidate it could not represent (per-candidate buffers
 // too short, no admissible move): the host turns anything this large into INT64_MAX
 constexpr long long PROPOSAL_OVERFLOW_LENGTH = 1ll << 61;
+static_assert(PROPOSAL_OVERFLOW_LENGTH == LVB_OVERFLOW_LENGTH, "decide.h restates it for C");
 constexpr uint32_t CAND_RESIDENT_BASE = 1u;       // base += *s_all - sum(node_changes[dst])
 // CandDesc::flags bits 8..: the CHAIN (resident tree slot) the candidate belongs to.  Programs name nodes by their
 // numbers in ONE tree (0..2n-4); the state sets of several resident trees share the leaf rows and keep their internal
@@ -41,6 +43,7 @@ constexpr uint32_t WATCH_COUNT_SHIFT = 48;
 constexpr uint32_t WATCH_MAX_GROUPS = 2047;
 constexpr uint32_t WATCH_WAVES = 8u * WALK_WAVES; // eight extra workgroups
 constexpr int32_t MAX_CHAINS = 64;
+constexpr uint32_t PICK_NONE = LVB_PICK_NONE; // decide.h: "this chain accepted nothing"
 
 struct CandDesc
 {
@@ -113,9 +116,23 @@ struct WalkArgs
     // waves settles that candidate.  A single commit is j = 0, tmp_stride irrelevant.  The picks travel IN the kernel
     // arguments: from pinned host memory every commit wave (and the table rebuild, and the gather) began with a read
     // over the host link.
+    // use_pick == 2: the picks are not known to the host yet - the scoring walk's watcher waves decide them (below) and
+    // leave them in d_pick[chain]; launch candidate j belongs to chain pick_chain[j], whose candidates start at
+    // pick_idx[j], and walks cands[pick_idx[j] + d_pick[chain]] - or nothing at all if that chain accepted nothing
     uint32_t use_pick;
     uint32_t pick_idx[MAX_CHAINS];
+    uint8_t pick_chain[MAX_CHAINS];
+    const uint32_t *d_pick;
     uint32_t tmp_stride;
+    // the accept decision on the device (watcher launches, rules != null): every watcher wave, once a candidate's length
+    // is complete, applies the chain's rule (pinned host memory, indexed by chain) and lowers d_pick[chain] to the
+    // candidate's index if it is taken; the LAST watcher wave to finish copies the npick_chains picks listed in
+    // pick_chain[] to host_pick[] and sets host_flag[WATCH_WAVES]
+    const DecideRule *rules;
+    uint32_t *d_pick_out;
+    uint32_t *host_pick;
+    uint32_t npick_chains;
+    uint32_t *watch_done; // device word, zero between launches
     uint32_t flip; // walk each XCD's share of the items from its far end (filled by launch_walk)
     // COMMIT: produced sets and their counts wait in LDS, this many per wave, and go out in bursts (filled by
     // launch_walk, >= 1 for COMMIT).  A store or atomic inside the chain makes every wait for a
@@ -193,6 +210,7 @@ struct GenArgs
     CandDesc *cands;
     ProposalInfo *info;
     unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
+    uint32_t *pick_out;          // [MAX_CHAINS] picks of a step decided on the device: the generator resets its chains' (null: none)
     const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
     unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
     int32_t use_lds;              // filled by launch_propose
@@ -218,6 +236,10 @@ struct RebuildArgs
     int32_t n, nb, K;
     uint32_t leaf_order_len;
     uint32_t pick_idx[MAX_CHAINS]; // batch positions of the picked candidates (in the kernel arguments, see WalkArgs)
+    // d_pick != null: picks decided on the device - pick j is pick_idx[j] (its chain's first candidate) + d_pick[pick_chain[j]],
+    // nothing to do if that is PICK_NONE
+    const uint32_t *d_pick;
+    uint8_t pick_chain[MAX_CHAINS];
     const CandDesc *cands;   // their descriptors (flags carry the chain)
     const ProposalInfo *info;
     const lvbgpu_edit_dev *edits;

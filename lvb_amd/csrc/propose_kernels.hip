@@ -634,6 +634,8 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
         g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 5u] = t_enter;
         g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 6u] = __builtin_readcyclecounter();
     }
+    if (g.pick_out && blk_local == 0u && threadIdx.x == 0u)
+        g.pick_out[sg.chain] = PICK_NONE; // this step's accept decision starts from "nothing accepted" (WalkArgs::rules)
     for (uint32_t bl = blk_local * GEN_WAVES + wave; bl < sg.count; bl += seg_blocks * GEN_WAVES)
         generate_one(t, g, sg, bl, lane);
 }
@@ -658,7 +660,14 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
         return;
     }
     const uint32_t j = blockIdx.x - ga.k;
-    const uint32_t cand = g.ext ? 0u : g.pick_idx[j];
+    uint32_t cand = g.ext ? 0u : g.pick_idx[j];
+    if (!g.ext && g.d_pick)
+    {
+        const uint32_t pk = g.d_pick[g.pick_chain[j]];
+        if (pk == PICK_NONE)
+            return; // this chain accepted nothing: its tables stand (uniform for the workgroup: no barrier is skipped by some)
+        cand += pk;
+    }
     const uint32_t chain = g.ext ? (uint32_t)g.ext[j].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
     IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
     const int32_t n = g.n, nb = g.nb, K = g.K;

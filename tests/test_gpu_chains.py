@@ -583,3 +583,112 @@ def test_cfg2_chains_step_equals_single_chain_steps(mods):
             assert np.array_equal(got[c], ref.propose_score(B, 0, base + c)), (slot, c)
     multi.close()
     ref.close()
+
+
+def _take(length, cur, t, minlen, seed, j):
+    """lvb_amd/csrc/decide.h, restated: -> (taken?, margin) - margin = |u - p| where a draw decides (borderline cases may
+    differ by an ulp of exp between host and device)"""
+    import math
+    M = (1 << 64) - 1
+    if length <= 0 or length >= (1 << 61):
+        return False, 1.0
+    if length <= cur:
+        return True, 1.0
+    deltah = min(1.0, minlen / cur - minlen / length)
+    if -deltah < t * -25.328436022934504:
+        return False, 1.0
+    z = (seed + 0x9E3779B97F4A7C15 * (j + 1)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    u = (z >> 11) * (1.0 / 9007199254740992.0)
+    p = math.exp(-deltah / t)
+    return u < p, abs(u - p)
+
+
+@pytest.mark.parametrize("device_decide", [True, False])
+def test_a_step_decides_and_commits_like_the_host_would(mods, device_decide, monkeypatch):
+    """lvbgpu_chains_step_*: the accept decision rides with the batch.  Lengths are the plain step's; every chain's pick is
+    the FIRST candidate decide.h's rule takes (checked against a restatement of the rule here); the accepted moves are
+    committed - resident lengths, per-node changes, node sets, topologies and the next neighbourhoods equal a reference
+    context that committed the same picks through lvbgpu_chains_commit; the moves' rewrites are the candidates' own.  Both
+    ways: decided by the walk's watcher waves on the device, and by the library on the host (LVBGPU_DEVICE_DECIDE=0)."""
+    api, host = mods
+    monkeypatch.setenv("LVBGPU_DEVICE_DECIDE", "1" if device_decide else "0")
+    n, m, R = 60, 5000, 5
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 41))
+    ctx, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
+    cur = []
+    for c_ in (ctx, ref):
+        c_.set_chains(R)
+    for c in range(R):
+        t = host.HostTree(n, seed=900 + c)
+        for c_ in (ctx, ref):
+            c_.select_chain(c)
+            length = t.upload(c_)
+        cur.append(length)
+    rng = np.random.default_rng(5)
+    accepted = nothing = 0
+    for step in range(40):
+        active = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
+        draws = [(c, int(rng.integers(1, 90)), [0, 1, 2, -1][(step + c) % 4], 7000 * step + c) for c in active]
+        # temperatures from "nothing worse is ever taken" to "nearly everything is"
+        # (every third rule claims a current length of 1: everything is worse and, that cold, nothing is taken)
+        rules = [(1, 1e-12, float(min_len), 5) if (step + c) % 3 == 0 else
+                 (cur[c], [1e-9, 1e-5, 3e-4, 5e-2][(step + 2 * c) % 4], float(min_len), 111 * step + c) for c in active]
+        lens, picks = ctx.chains_step(draws, rules)
+        want_lens = ref.chains_propose_score(draws)
+        commit = []
+        for i, (c, count, kind, seed) in enumerate(draws):
+            assert np.array_equal(lens[i], want_lens[i]), (step, c)
+            first, sure = -1, True
+            for j in range(count):
+                take, margin = _take(int(lens[i][j]) if lens[i][j] < np.iinfo(np.int64).max else 1 << 61, *rules[i], j)
+                if margin < 1e-9:
+                    sure = False                      # an ulp of exp could turn this one: accept the device's word
+                    break
+                if take:
+                    first = j
+                    break
+            if sure:
+                assert picks[i] == first, (step, c, picks[i], first)
+            if picks[i] >= 0:
+                accepted += 1
+                commit.append((c, int(picks[i])))
+                cur[c] = int(lens[i][picks[i]])
+            else:
+                nothing += 1
+        if commit:
+            ref.chains_commit(commit)
+        for i, (c, count, kind, seed) in enumerate(draws):
+            if picks[i] >= 0:
+                e = ctx.chains_step_edits(i)
+                assert len(e) >= 2
+            else:
+                with pytest.raises(api.LvbGpuError):
+                    ctx.chains_step_edits(i)
+        for c in range(R):
+            ctx.select_chain(c)
+            ref.select_chain(c)
+            assert ctx.current_length() == ref.current_length() == cur[c], (step, c)
+            assert np.array_equal(ctx.changes(), ref.changes())
+            pm, pr = ctx.topology(), ref.topology()
+            assert all(np.array_equal(a, b) for a, b in zip(pm[:3], pr[:3])) and pm[3] == pr[3]
+            if step % 8 == 7:
+                assert np.array_equal(ctx.all_sets(), ref.all_sets())
+                assert np.array_equal(ctx.propose_score(20, -1, 5 + c), ref.propose_score(20, -1, 5 + c))
+    assert accepted > 20 and nothing > 10                 # both outcomes were exercised
+    # a step's slot cannot be collected as a plain batch, and a plain batch not as a step
+    ctx.select_chain(0)
+    d = ctx._draws([(0, 8, 1, 1)])
+    r = np.zeros(1, dtype=api.RULE_DTYPE)
+    r[0]["cur_length"], r[0]["temperature"], r[0]["min_len_tree"], r[0]["accept_seed"] = cur[0], 1e-9, float(min_len), 3
+    ctx._chk(ctx.lib.lvbgpu_chains_step_submit(ctx.h, 0, 1, d.ctypes.data, r.ctypes.data))
+    out, pk = np.zeros(8, dtype=np.int64), np.zeros(1, dtype=np.int32)
+    assert ctx.lib.lvbgpu_chains_collect(ctx.h, 0, out) == -5
+    ctx._chk(ctx.lib.lvbgpu_chains_step_collect(ctx.h, 0, out, pk))
+    ctx.chains_submit(0, [(0, 8, 1, 2)])
+    assert ctx.lib.lvbgpu_chains_step_collect(ctx.h, 0, out, pk) == -5
+    ctx.chains_collect(0, [8])
+    ctx.close()
+    ref.close()
