@@ -213,10 +213,12 @@ int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, i
  * candidate j of the draw (in order) is taken if its length is <= cur_length, or with probability
  * exp(-deltah / temperature), deltah = min_len_tree / cur_length - min_len_tree / length capped at 1, and never once
  * -deltah < temperature * log(1e-11); its uniform draw is a function of (accept_seed, j).  The chain's pick is the FIRST
- * taken candidate; it is committed at once (lvbgpu_chains_commit's work) - where the batch allows it the device decides
- * (the scoring walk's watcher waves apply the rule the moment a length is complete) and commit walk, table rebuild and
- * the moves' way to the host are enqueued WITH the batch, so that no host round trip lies between a step's scoring and
- * its commit; otherwise the library decides at the collect, by the same function (lvb_amd/csrc/decide.h).
+ * taken candidate; it is committed at once (lvbgpu_chains_commit's work).  By default the library decides at the collect
+ * (lvb_amd/csrc/decide.h); with LVBGPU_DEVICE_DECIDE=1, where the batch allows it, the DEVICE decides - the scoring
+ * walk's watcher waves apply the same function the moment a length is complete - and commit walk, table rebuild and the
+ * moves' way to the host are enqueued WITH the batch, so that no host round trip lies between a step's scoring and its
+ * commit (same picks, same trajectories; on MI355X / ROCm 7.2 the extra launch and event calls cost more than the
+ * round trip they save).
  * lvbgpu_chains_step_collect hands over the lengths (as lvbgpu_chains_collect) and picks_out[i] = index of the accepted
  * candidate within draw i, or -1; lvbgpu_chains_step_edits(i) = the accepted move's rewrites (waits for them if they are
  * still on their way).  A slot holds one step at a time; a step and plain batches may not be in flight together. */

@@ -4,14 +4,16 @@
 // device that could run a hundred such chains at once, and while most proposals are accepted a step carries only a
 // handful of candidates.  The remedy the reference's design offers is the one north_star names for GPUs: independent
 // restarts.  Here R of them live in one context (lvbgpu_set_chains: the alignment once, R resident trees) and every
-// device step serves all of them: ONE generator launch draws every chain's candidates, ONE walk scores them, the
-// lengths come back together, every chain consumes its own candidates exactly as the serial loop would (Solve.c:300-378),
-// and ONE commit walk applies every chain's accepted move.  The step's latency is paid once, not R times.
+// device step serves all of them: ONE generator launch draws every chain's candidates, ONE walk scores them, every chain's
+// first acceptable candidate - the one the serial loop would stop at (Solve.c:300-378) - is picked where the lengths are
+// (lvbgpu_chains_step_*: the rule rides with the batch) and ONE commit walk applies every chain's accepted move.  The
+// step's latency is paid once, not R times.
 //
 // Each chain is the loop of anneal.cpp / the reference's Anneal() and StartingTemperature() turned into a state
 // machine: plan() says how many candidates of which kinds the chain wants next (speculation depth from its own
-// acceptance rate; never across a cooling step or a re-root tick), consume() eats the lengths in order up to the first
-// acceptance, after_commit() finishes that proposal once the tree has moved.  A chain's decisions depend on its own
+// acceptance rate; never across a cooling step or a re-root tick) and by which rule it accepts (current length,
+// temperature, a seed for the step's Metropolis draws), consume() books the lengths in order up to the accepted candidate
+// the step reports, after_commit() finishes that proposal.  A chain's decisions depend on its own
 // state and random stream only, so its trajectory is the same whatever R is (tests/test_gpu_chains.py).
 #include "../../include/lvbhost.h"
 
@@ -39,22 +41,6 @@ constexpr double DBL_EPS = 2.220446049250313e-16;
 using Clock = std::chrono::steady_clock;
 inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
-// Metropolis decision of Solve.c:303-378 for a proposal that is worse than the current tree
-inline bool accept_worse(double deltah, double t, Rng &rng)
-{
-    static const double log_eps = std::log(LVB_EPS);
-    if (-deltah < t * log_eps)
-    {
-        (void)rng.uniform(); // the reference draws here too (Solve.c:352-355)
-        return false;
-    }
-    return rng.uniform() < std::exp(-deltah / t);
-}
-inline double energy_delta(double minlen, int64_t cur, int64_t prop)
-{
-    double d = minlen / (double)cur - minlen / (double)prop;
-    return d > 1.0 ? 1.0 : d;
-}
 inline uint32_t scaled(double p) { return (uint32_t)std::min(4294967295.0, std::max(0.0, p) * 4294967296.0); }
 
 struct ChainRun
@@ -133,8 +119,9 @@ struct ChainRun
         tree->best.insert(tree->topo); // the initial tree is initially the best (Solve.c:208)
     }
 
-    // what the chain wants scored next; false: nothing (done, or an error in rc)
-    bool plan(lvbgpu_chain_draw &d)
+    // what the chain wants scored next, and the rule by which it accepts (Solve.c:303-378: lvb_amd/csrc/decide.h); false:
+    // nothing (done, or an error in rc)
+    bool plan(lvbgpu_chain_draw &d, lvbgpu_chain_rule &rule)
     {
         if (phase == DONE)
             return false;
@@ -191,6 +178,10 @@ struct ChainRun
         }
         d.count = B;
         d.seed = tree->rng.next();
+        rule.cur_length = cur;
+        rule.temperature = phase == START_TEMP ? st_t : t;
+        rule.min_len_tree = minlen;
+        rule.accept_seed = tree->rng.next();
         consumed_now = accepted_now = 0;
         res->device_steps++;
         res->scored += B;
@@ -263,27 +254,28 @@ struct ChainRun
             begin_anneal(st_t - 0.00001);
     }
 
-    // eat this step's lengths in order; returns the index of the accepted candidate (the rest is stale then), or -1
-    int consume(const int64_t *lens)
+    // Book this step's lengths in order, up to the candidate the step accepted (`pick`, -1: none) - the rest is stale then.
+    // The decision itself was made where the lengths are (lvbgpu_chains_step_*); what is counted here is what the serial
+    // loop counts (Solve.c:300-378, StartingTemperature.c:128-166).  Returns pick.
+    int consume(const int64_t *lens, int32_t pick)
     {
+        const int upto = pick >= 0 ? pick + 1 : B;
         if (phase == START_TEMP)
         {
-            for (int b = 0; b < B; b++)
+            for (int b = 0; b < upto; b++)
             {
                 st_iter++;
                 st_total++;
                 const int64_t len = lens[b];
                 if (len == INT64_MAX)
                     continue; // a device candidate that did not fit its buffers: not a proposal
-                bool take = len <= cur;
-                if (!take)
+                if (len > cur)
                 {
                     st_prop_pos++;
-                    take = accept_worse(energy_delta(minlen, cur, len), st_t, tree->rng);
-                    if (take)
+                    if (b == pick)
                         st_acc_pos++;
                 }
-                if (take)
+                if (b == pick)
                 {
                     pending_len = len;
                     return b;
@@ -293,7 +285,7 @@ struct ChainRun
                 end_of_start_temperature_sample();
             return -1;
         }
-        for (int b = 0; b < B && phase == ANNEAL; b++)
+        for (int b = 0; b < upto && phase == ANNEAL; b++)
         {
             const int64_t len = lens[b];
             if (len == INT64_MAX)
@@ -303,16 +295,24 @@ struct ChainRun
             if (p.algorithm == 2) // the kinds of device-drawn candidates stay on the device: expected gain under the probabilities
                 for (int i = 0; i < 3; i++)
                     counter[i] += 0.5 * (1.0 - probs[i]);
-            const bool take = len <= cur || accept_worse(energy_delta(minlen, cur, len), t, tree->rng);
-            if (take)
+            if (b == pick)
             {
                 accepted_now++;
                 pending_stack = len <= cur && len <= best; // ties or beats the best (Solve.c:309)
                 pending_len = len;
                 return b;
             }
-            if (after_proposal())
-                break; // new temperature: start a fresh batch
+            if (after_proposal()) // new temperature: start a fresh batch
+            {
+                if (pick > b)
+                {
+                    // (cannot happen: plan() never lets a batch reach past a cooling step, so the temperature can only
+                    // change behind the batch's last proposal - the step's rule was the old temperature's)
+                    rc = LVBGPU_E_STATE;
+                    return -1;
+                }
+                break;
+            }
         }
         end_of_step();
         return -1;
@@ -339,7 +339,7 @@ struct ChainRun
     {
         fetched.resize((size_t)2 * tree->topo.nb + 8);
         int32_t ne = 0;
-        rc = lvbgpu_chains_picked_edits(ctx, pick_index, fetched.data(), (int32_t)fetched.size(), &ne);
+        rc = lvbgpu_chains_step_edits(ctx, pick_index, fetched.data(), (int32_t)fetched.size(), &ne);
         if (rc == LVBGPU_OK)
             rc = lvbhost_tree_apply(tree, fetched.data(), ne, -1);
     }
@@ -466,8 +466,10 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         if (g < global_best)
         {
             global_best = g;
-            if (log_seconds && log_best && nlog < log_cap)
+            if (log_seconds && log_best && log_cap > 0)
             {
+                if (nlog == log_cap)
+                    nlog--; // a full log keeps its last entry current: the log always ends at the best length reached
                 log_seconds[nlog] = since(wall0);
                 log_best[nlog] = g;
                 nlog++;
@@ -476,32 +478,24 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     };
     log_point();
 
-    // The chains can be stepped as two groups taking turns (LVBHOST_CHAIN_GROUPS=2): while the device draws and scores
-    // one group's candidates, the host consumes the other group's lengths, picks, commits and plans.  Measured on
-    // MI355X it LOSES (R = 16: 8.0 -> 6.5 M candidates/s, R = 32: 9.0 -> 8.2): a step is mostly fixed device latency
-    // (generator, walk, commit walk one after the other), and two half-sized groups pay it twice.  One group is the
-    // default.  Which group a chain is in changes nothing for the chain.
+    // (Stepping the chains as two groups taking turns - the host working on one group's lengths while the device draws and
+    // scores the other's - was measured in rounds 2 and 3 and LOSES on MI355X (R = 32: 1.345 -> 1.578 s): a step is mostly
+    // fixed device latency and two half-sized groups pay it twice on one in-order stream.  Groups side by side on streams
+    // of their own: lvbhost_anneal_chain_groups.)
     struct Flight
     {
         std::vector<lvbgpu_chain_draw> draws;
+        std::vector<lvbgpu_chain_rule> rules;
         std::vector<int32_t> who;
         std::vector<int64_t> lens;
+        std::vector<int32_t> picks;
         size_t total = 0;
         bool active = false;
-        int slot = 0;
-    };
-    static const int want_groups = [] {
-        const char *e = getenv("LVBHOST_CHAIN_GROUPS");
-        return e && atoi(e) == 2 ? 2 : 1;
-    }();
-    const int ngroups = R >= 2 ? want_groups : 1;
-    Flight flight[2];
-    std::vector<lvbgpu_chain_pick> picks;
+    } f;
     std::vector<lvbgpu_chain_root> roots;
-    std::vector<int32_t> picked;
     int64_t steps = 0;
     double dev_seconds = 0.0;
-    double t_plan = 0, t_score = 0, t_consume = 0, t_commit = 0, t_after = 0; // LVBHOST_PROFILE=1 prints them
+    double t_plan = 0, t_score = 0, t_consume = 0, t_after = 0; // LVBHOST_PROFILE=1 prints them
     double t_submit = 0, t_reroot = 0; // ... and, of those, the submit call (part of propose_score) and the re-roots (part of plan)
     const bool profile = getenv("LVBHOST_PROFILE") != nullptr;
     int64_t p_sc = 0, p_co = 0, p_ac = 0, p_cs = 0;
@@ -515,22 +509,22 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     if (lockstep && params[0].max_device_steps <= 0)
         return LVBGPU_E_ARG;
 
-    // plan the group's chains and enqueue their candidates (nothing if every chain of the group is done)
-    auto submit_group = [&](int g) -> int {
-        Flight &f = flight[g];
+    // plan the chains and enqueue their step (nothing if every chain is done)
+    auto submit_step = [&]() -> int {
         f.draws.clear();
+        f.rules.clear();
         f.who.clear();
         f.total = 0;
         f.active = false;
         auto tp = Clock::now();
         for (ChainRun &r : runs)
         {
-            if (r.chain % ngroups != g)
-                continue;
             lvbgpu_chain_draw d{};
-            if (r.plan(d))
+            lvbgpu_chain_rule rule{};
+            if (r.plan(d, rule))
             {
                 f.draws.push_back(d);
+                f.rules.push_back(rule);
                 f.who.push_back(r.chain);
                 f.total += (size_t)d.count;
             }
@@ -561,9 +555,9 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         if (f.draws.empty())
             return LVBGPU_OK;
         f.lens.resize(f.total);
+        f.picks.resize(f.draws.size());
         auto td = Clock::now();
-        f.slot = g;
-        const int r = lvbgpu_chains_submit(ctx, f.slot, (int32_t)f.draws.size(), f.draws.data());
+        const int r = lvbgpu_chains_step_submit(ctx, 0, (int32_t)f.draws.size(), f.draws.data(), f.rules.data());
         dev_seconds += since(td);
         t_score += since(td);
         t_submit += since(td);
@@ -571,10 +565,10 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         return r;
     };
     // the trees of the chains that accepted in the step before follow their moves now, while the device works
-    auto follow_group = [&](int g) -> int {
+    auto follow_all = [&]() -> int {
         auto tf = Clock::now();
         for (ChainRun &r : runs)
-            if (r.chain % ngroups == g && r.deferred_pick >= 0)
+            if (r.deferred_pick >= 0)
             {
                 r.finish_follow();
                 if (r.rc != LVBGPU_OK)
@@ -583,63 +577,45 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         t_after += since(tf);
         return LVBGPU_OK;
     };
-    // the group's lengths are back (or are waited for): consume, commit the accepted moves, finish those proposals
-    auto finish_group = [&](int g, bool discard) -> int {
-        Flight &f = flight[g];
+    // the step's lengths and picks are back (or are waited for): every chain books its own; the accepted moves are
+    // committed already (lvbgpu_chains_step_*)
+    auto finish_step = [&]() -> int {
         if (!f.active)
             return LVBGPU_OK;
         f.active = false;
         auto td = Clock::now();
-        int r = lvbgpu_chains_collect(ctx, f.slot, f.lens.data());
+        int r = lvbgpu_chains_step_collect(ctx, 0, f.lens.data(), f.picks.data());
         dev_seconds += since(td);
         t_score += since(td);
-        if (r != LVBGPU_OK || discard)
+        if (r != LVBGPU_OK)
             return r;
-        picks.clear();
-        picked.clear();
         size_t off = 0;
         auto tp = Clock::now();
         for (size_t i = 0; i < f.draws.size(); i++)
         {
             ChainRun &cr = runs[(size_t)f.who[i]];
-            const int b = cr.consume(f.lens.data() + off);
+            const int b = cr.consume(f.lens.data() + off, f.picks[i]);
             off += (size_t)f.draws[i].count;
+            if (cr.rc != LVBGPU_OK)
+                return cr.rc;
             if (b >= 0)
             {
-                picks.push_back({cr.chain, b});
-                picked.push_back(cr.chain);
-            }
-        }
-        t_consume += since(tp);
-        if (!picks.empty())
-        {
-            td = Clock::now();
-            r = lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
-            dev_seconds += since(td);
-            t_commit += since(td);
-            if (r != LVBGPU_OK)
-                return r;
-            tp = Clock::now();
-            for (size_t j = 0; j < picked.size(); j++)
-            {
-                ChainRun &cr = runs[(size_t)picked[j]];
-                (void)cr.after_commit((int32_t)j);
+                (void)cr.after_commit((int32_t)i);
                 if (cr.rc != LVBGPU_OK)
                     return cr.rc;
             }
-            t_after += since(tp);
         }
+        t_consume += since(tp);
         log_point(); // R comparisons: nothing next to a device step
         return LVBGPU_OK;
     };
 
-    for (int g = 0; g < ngroups && rc == LVBGPU_OK; g++)
-        rc = submit_group(g);
-    for (int g = 0; rc == LVBGPU_OK; g = (g + 1) % ngroups)
+    rc = submit_step();
+    while (rc == LVBGPU_OK)
     {
-        if (!lockstep && !flight[0].active && !flight[1].active)
+        if (!lockstep && !f.active)
             break;
-        rc = finish_group(g, false);
+        rc = finish_step();
         if (rc != LVBGPU_OK)
             break;
         steps++;
@@ -681,27 +657,20 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         }
         if (stop)
             break;
-        rc = submit_group(g);
+        rc = submit_step();
         if (rc == LVBGPU_OK)
-            rc = follow_group(g);
+            rc = follow_all();
     }
-    for (int g = 0; g < ngroups && rc == LVBGPU_OK; g++)
-        rc = follow_group(g); // (a run that stopped right after a commit)
-    // leave nothing in flight
-    for (int g = 0; g < ngroups; g++)
-    {
-        const int r = finish_group(g, true);
-        if (rc == LVBGPU_OK)
-            rc = r;
-    }
+    if (rc == LVBGPU_OK)
+        rc = follow_all(); // (a run that stopped right after a step)
     if (rc != LVBGPU_OK)
         return rc;
     const double secs = since(wall0);
     if (getenv("LVBHOST_PROFILE"))
-        fprintf(stderr, "[anneal_chains] R=%d steps=%lld  per step (us): plan %.1f (re-roots %.1f)  propose_score %.1f (submit %.1f)  "
-                        "consume %.1f  commit %.1f  after_commit %.1f  total %.1f\n",
+        fprintf(stderr, "[anneal_chains] R=%d steps=%lld  per step (us): plan %.1f (re-roots %.1f)  step submit + collect %.1f (submit %.1f)  "
+                        "consume + bookkeeping %.1f  trees following %.1f  total %.1f\n",
                 R, (long long)steps, 1e6 * t_plan / steps, 1e6 * t_reroot / steps, 1e6 * t_score / steps, 1e6 * t_submit / steps,
-                1e6 * t_consume / steps, 1e6 * t_commit / steps, 1e6 * t_after / steps, 1e6 * secs / steps);
+                1e6 * t_consume / steps, 1e6 * t_after / steps, 1e6 * secs / steps);
     for (ChainRun &r : runs)
     {
         const int64_t keep_global = r.res->global_best_length;

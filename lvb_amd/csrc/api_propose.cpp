@@ -375,8 +375,13 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
             seg_chain[i] = draws[i].chain;
             st += (uint32_t)draws[i].count;
         }
-        const char *dd = getenv("LVBGPU_DEVICE_DECIDE"); // =0: the host decides (A/B runs, tests of the fallback; read per step)
-        const bool allow_device = !(dd && dd[0] == '0');
+        // LVBGPU_DEVICE_DECIDE=1 (read per step).  The default is the HOST's decision at the collect: measured on MI355X
+        // / ROCm 7.2 the device's is slower - one chain 45.8 us per step with the host deciding, 54.7 us with the device
+        // (same trajectories): what the step saves in host round trips it pays twice over in launch and event calls of
+        // one submit (24 us instead of 10) and in two cross-stream hand-overs (walk -> rebuild on the side stream ->
+        // next generator) on its critical path.  profiles/experiments/r03_anneal_step.md
+        const char *dd = getenv("LVBGPU_DEVICE_DECIDE");
+        const bool allow_device = dd && dd[0] == '1';
         bool on_device = allow_device && ps.watched && (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
         for (int32_t i = 0; i < k && on_device; i++)
             on_device = ctx->parked[(size_t)draws[i].chain].d_topo_version == ctx->parked[(size_t)draws[i].chain].topo_version;
@@ -984,12 +989,9 @@ extern "C" int lvbgpu_chains_step_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t 
 {
     if (!rules)
         return LVBGPU_E_ARG;
-    if (ctx)
-    {
-        const int rf = settle(ctx); // the step before this one: its moves have long arrived; their pinned slot may come round again
-        if (rf != LVBGPU_OK)
-            return rf;
-    }
+    // (the host side of the step before this one - its accepted moves' way into the host topologies - is NOT waited for
+    // here: the moves may still be on their way, and on the accept path the host is what the device waits for; the
+    // collect settles it before it records this step's)
     return propose_submit(ctx, slot, k, draws, nullptr, rules);
 }
 
@@ -1048,9 +1050,14 @@ extern "C" int lvbgpu_chains_step_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t
             }
     }
     AllParked guard(ctx);
+    {
+        const int rf = resolve_follow(ctx); // the step before this one: long arrived (its pinned slot is not this step's)
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
     const uint32_t *hp = (const uint32_t *)ps.h_pickout.p;
     uint64_t moved = 0;
-    lvbgpu_ctx::Follow &f = ctx->follow; // (settled at the submit: nothing pending)
+    lvbgpu_ctx::Follow &f = ctx->follow;
     f.pending = false;
     f.slot = ps.step_pick_slot;
     f.k = k;

@@ -564,6 +564,76 @@ int lvbgpu_chains_picked_edits(lvbgpu_ctx *c, int32_t j, lvbgpu_edit *e, int32_t
     return LVBGPU_OK;
 }
 
+/* a whole step (include/lvbgpu.h lvbgpu_chains_step_*): the rule rides with the batch; the double decides at the
+ * collect with the product's own rule function (lvb_amd/csrc/decide.h: plain C) and commits the picks */
+#include "../../lvb_amd/csrc/decide.h"
+static __thread struct
+{
+    int32_t k;
+    DecideRule rule[DBL_MAX_CHAINS];
+    int32_t map[DBL_MAX_CHAINS];
+    int active;
+} STEP;
+
+int lvbgpu_chains_step_submit(lvbgpu_ctx *c, int32_t s, int32_t k, const lvbgpu_chain_draw *d, const lvbgpu_chain_rule *r)
+{
+    if (!r)
+        return LVBGPU_E_ARG;
+    const int rc = lvbgpu_chains_submit(c, s, k, d);
+    if (rc != LVBGPU_OK)
+        return rc;
+    uint32_t at = 0;
+    STEP.k = k;
+    for (int32_t i = 0; i < k; i++)
+    {
+        STEP.rule[i].cur = r[i].cur_length;
+        STEP.rule[i].t = r[i].temperature;
+        STEP.rule[i].minlen = r[i].min_len_tree;
+        STEP.rule[i].seed = r[i].accept_seed;
+        STEP.rule[i].start = at;
+        STEP.rule[i].count = (uint32_t)d[i].count;
+        at += (uint32_t)d[i].count;
+    }
+    STEP.active = 1;
+    return LVBGPU_OK;
+}
+
+int lvbgpu_chains_step_collect(lvbgpu_ctx *c, int32_t s, int64_t *l, int32_t *picks)
+{
+    if (!STEP.active || !picks)
+        return LVBGPU_E_STATE;
+    STEP.active = 0;
+    int rc = lvbgpu_chains_collect(c, s, l);
+    if (rc != LVBGPU_OK)
+        return rc;
+    lvbgpu_chain_pick pk[DBL_MAX_CHAINS];
+    int32_t np = 0;
+    const dbl_slot *sl = &G.slot[s];
+    for (int32_t i = 0; i < STEP.k; i++)
+    {
+        picks[i] = -1;
+        STEP.map[i] = -1;
+        for (uint32_t j = 0; j < STEP.rule[i].count; j++)
+            if (lvb_take(l[STEP.rule[i].start + j] == INT64_MAX ? LVB_OVERFLOW_LENGTH : (long long)l[STEP.rule[i].start + j], &STEP.rule[i], j))
+            {
+                picks[i] = (int32_t)j;
+                STEP.map[i] = np;
+                pk[np].chain = sl->chain[i];
+                pk[np].b = (int32_t)j;
+                np++;
+                break;
+            }
+    }
+    return np ? lvbgpu_chains_commit(c, np, pk) : LVBGPU_OK;
+}
+
+int lvbgpu_chains_step_edits(lvbgpu_ctx *c, int32_t i, lvbgpu_edit *e, int32_t cap, int32_t *n)
+{
+    if (i < 0 || i >= DBL_MAX_CHAINS || STEP.map[i] < 0)
+        return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d (i %d k %d)\n", __LINE__, i, STEP.k) : 0, LVBGPU_E_ARG);
+    return lvbgpu_chains_picked_edits(c, STEP.map[i], e, cap, n);
+}
+
 int lvbgpu_chains_reroot(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_root *r)
 {
     adopt(c);
