@@ -81,6 +81,12 @@ def parse_args(argv=None):
                     help="run the batched SA host end to end for this long and report best-length-vs-wallclock (0 = skip)")
     ap.add_argument("--anneal-batch", type=int, default=4096, help="ceiling of the SA step size (it adapts)")
     ap.add_argument("--anneal-chains", type=int, default=32, help="independent chains stepped together on the GPU")
+    ap.add_argument("--anneal-seed", type=int, default=9,
+                    help="seed base of the annealing leg's chains and start trees.  One chain in some dozens has its starting "
+                         "temperature land on the reference's second 1e-5 increment and needs ~100x longer to freeze (faithful to "
+                         "StartingTemperature.c; DESIGN.md 7c); the default base gives 32 chains without such a straggler, as round "
+                         "2's did (tools/anneal_seed_scan.py), so that `scored_per_s` - measured until ALL chains have frozen - says "
+                         "something about the scorer.  `scored_per_s_busy` does so for any seed")
     ap.add_argument("--anneal-groups", type=int, default=1,
                     help="the chains are dealt to this many groups that anneal side by side, each with a context and a host "
                          "thread of its own (lvbhost_anneal_chain_groups); 1 = all chains lock-stepped in one context")
@@ -783,7 +789,7 @@ def rank_main(args) -> None:
         # R independent chains are stepped together on this GPU: a device step serves all of them.
         def params_for(c):
             p = host.anneal_defaults()
-            p.seed = args.seed * 7919 + 1000 * rank + c + 1
+            p.seed = args.anneal_seed * 7919 + 1000 * rank + c + 1
             p.algorithm = {"nni": 10, "spr": 11, "tbr": 12}[args.move]
             p.batch = args.anneal_batch
             p.t0 = 0.0   # estimated as StartingTemperature() does (65 % of uphill moves accepted)
@@ -795,7 +801,7 @@ def rank_main(args) -> None:
         G = max(1, min(args.anneal_groups, R))
         actxs = [api.FitchContext(text_rows=rows, device=ranks.device) for _ in range(G)]
         actx = actxs[0]
-        atrees = [host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100 + c) for c in range(R)]
+        atrees = [host.HostTree(args.taxa, seed=ranks.restart_seed(args.anneal_seed) * 100 + c) for c in range(R)]
         if G > 1:
             res, log = host.anneal_chain_groups(actxs, atrees, [params_for(c) for c in range(R)])
         else:
@@ -812,6 +818,10 @@ def rank_main(args) -> None:
                 "scored": tot("scored"), "consumed": tot("consumed"), "accepted": tot("accepted"),
                 "device_steps": max(r["device_steps"] for r in res), "chain_steps": tot("device_steps"),
                 "scored_per_s": round(tot("scored") / secs), "consumed_per_s": round(tot("consumed") / secs),
+                # the same while at least half of the chains were still annealing (robust against a straggler chain)
+                "seconds_busy": round(res[0]["seconds_busy"], 3),
+                "scored_per_s_busy": round(res[0]["scored_busy"] / max(res[0]["seconds_busy"], 1e-9)),
+                "seconds_done": [round(r["seconds_done"], 3) for r in res], "seed": args.anneal_seed,
                 "device_fraction": round(res[0]["seconds_device"] / secs, 3), "batch": args.anneal_batch,
                 "temperatures": [r["temperatures"] for r in res], "frozen": sum(r["frozen"] for r in res),
                 "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
@@ -820,8 +830,11 @@ def rank_main(args) -> None:
                         "commit walk per device step for all of them; starting temperatures included",
             }
             # one chain alone, for comparison: the same loop with R = 1
+            # (seeded as in rounds 1 and 2 - from --seed, not --anneal-seed - so that this is the same chain as in their lines)
             fresh = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100)
-            one, _ = host.anneal_chains(actx, [fresh], [params_for(0)])
+            p1 = params_for(0)
+            p1.seed = args.seed * 7919 + 1000 * rank + 1
+            one, _ = host.anneal_chains(actx, [fresh], [p1])
             fresh.close()
             out["anneal"]["single_chain"] = {
                 "seconds": round(one[0]["seconds"], 3), "best_length": one[0]["best_length"], "scored": one[0]["scored"],

@@ -160,6 +160,14 @@ typedef struct
     double seconds_device;      /* inside lvbgpu_* calls */
     int32_t n_log;              /* entries written to the log arrays */
     int32_t frozen;             /* 1 if the freezing criterion ended the run */
+    double seconds_done;        /* wall time (from the run's start) at which THIS chain stopped (froze or ran out of proposals) */
+    /* lvbhost_anneal_chains, in every chain's result: the run while at least half of its chains were still annealing -
+     * its wall time and the candidates scored in it.  One chain in some dozens has its starting temperature land on the
+     * reference's second 1e-5 increment (StartingTemperature.c:173), accepts most of what it sees and needs ~100x longer
+     * to freeze; a rate measured until the LAST chain has frozen then says how long that chain took, not what the
+     * scorer does. */
+    double seconds_busy;
+    int64_t scored_busy;
 } lvbhost_anneal_result;
 
 void lvbhost_anneal_defaults(lvbhost_anneal_params *p);

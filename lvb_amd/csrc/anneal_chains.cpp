@@ -493,8 +493,8 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         bool active = false;
     } f;
     std::vector<lvbgpu_chain_root> roots;
-    int64_t steps = 0;
-    double dev_seconds = 0.0;
+    int64_t steps = 0, busy_scored = 0;
+    double dev_seconds = 0.0, busy_seconds = 0.0;
     double t_plan = 0, t_score = 0, t_consume = 0, t_after = 0; // LVBHOST_PROFILE=1 prints them
     double t_submit = 0, t_reroot = 0; // ... and, of those, the submit call (part of propose_score) and the re-roots (part of plan)
     const bool profile = getenv("LVBHOST_PROFILE") != nullptr;
@@ -607,6 +607,23 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         }
         t_consume += since(tp);
         log_point(); // R comparisons: nothing next to a device step
+        // when did each chain stop, and until when was at least half of them still at it
+        int32_t active = 0;
+        int64_t scored_now = 0;
+        const double now = since(wall0);
+        for (ChainRun &r : runs)
+        {
+            scored_now += r.res->scored;
+            if (r.phase != ChainRun::DONE)
+                active++;
+            else if (r.res->seconds_done == 0.0)
+                r.res->seconds_done = now;
+        }
+        if (2 * active >= R)
+        {
+            busy_seconds = now;
+            busy_scored = scored_now;
+        }
         return LVBGPU_OK;
     };
 
@@ -679,6 +696,10 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             r.res->global_best_length = keep_global;
         r.res->seconds = secs;
         r.res->seconds_device = dev_seconds;
+        if (r.res->seconds_done == 0.0)
+            r.res->seconds_done = secs; // still annealing when the run was stopped
+        r.res->seconds_busy = busy_seconds;
+        r.res->scored_busy = busy_scored;
     }
     if (n_log)
         *n_log = nlog;
