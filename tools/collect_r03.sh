@@ -10,4 +10,7 @@ bash profiles/collect.sh r03${S}_cfg5_b1024 --taxa 2000 --sites 200000 --move tb
 bash profiles/collect.sh r03${S}_cfg5_b4096 --taxa 2000 --sites 200000 --move tbr --batch 4096 > gpurun_out/collect_r03${S}_cfg5_b4096.log 2>&1; echo "cfg5 b4096 done"
 export TMPDIR=/tmp; R=$(pwd); cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03${S}_chains32 -- python3 $R/tools/chains_probe.py --quiet 32 > $R/gpurun_out/collect_r03${S}_chains32.log 2>&1; echo "chains32 done"
-cd $R; du -sh gpurun_out/prof_r03${S}*
+cd $R
+# what comes back is capped at 64 MiB: the summaries need the stats tables and the counter collections, not the traces
+find gpurun_out/prof_r03${S}* -name "*_kernel_trace.csv" -delete
+du -sh gpurun_out/prof_r03${S}*
