@@ -3,6 +3,11 @@
 
 extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
 {
+    if (b)
+    {
+        b->d_pairs.release();
+        b->h_pairs.release();
+    }
     if (!b)
         return;
     if (b->ctx)
@@ -197,7 +202,53 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     // cost 7 % at B = 16 384).  Candidate b's descriptor (and so its length slot) moves to position slot_of[b];
     // lvbgpu_batch_lengths undoes it.
     bt->slot_of.clear();
-    if (B >= LPT_MIN_B && ctx->lpt_order)
+    // two candidates per wave (fitch_walk_pair): candidates sorted by their program READ BACKWARDS - neighbours in that
+    // order share the longest suffixes - and taken two by two; programs of more than one 64-token chunk walk alone.  The
+    // pairs replace the longest-first layout (a wave's time is its two programs' private parts plus the shared one).
+    const bool pair_up = ctx->pair_min > 0 && B >= ctx->pair_min && !job.full;
+    bt->npairs = 0;
+    std::vector<uint32_t> pair_list;
+    if (pair_up)
+    {
+        std::vector<const uint32_t *> tokp((size_t)B);
+        std::vector<uint32_t> ntok_of((size_t)B);
+        {
+            size_t b = 0;
+            for (int t = 0; t < T; t++)
+                for (const CandDesc &c : ctx->workers[t].cands)
+                {
+                    tokp[b] = ctx->workers[t].prog.toks.data() + c.tok_off;
+                    ntok_of[b++] = c.ntok;
+                }
+        }
+        std::vector<uint32_t> shorts, longs;
+        for (uint32_t b = 0; b < (uint32_t)B; b++)
+            (ntok_of[b] >= 1u && ntok_of[b] <= 64u ? shorts : longs).push_back(b);
+        std::sort(shorts.begin(), shorts.end(), [&](uint32_t x, uint32_t y) {
+            const uint32_t nx = ntok_of[x], ny = ntok_of[y];
+            for (uint32_t i = 1; i <= nx && i <= ny; i++)
+                if (tokp[x][nx - i] != tokp[y][ny - i])
+                    return tokp[x][nx - i] < tokp[y][ny - i];
+            return nx != ny ? nx < ny : x < y;
+        });
+        for (size_t i = 0; i + 1 < shorts.size(); i += 2)
+        {
+            pair_list.push_back(shorts[i]);
+            pair_list.push_back(shorts[i + 1]);
+        }
+        if (shorts.size() & 1u)
+        {
+            pair_list.push_back(shorts.back());
+            pair_list.push_back(PICK_NONE);
+        }
+        for (uint32_t b : longs)
+        {
+            pair_list.push_back(b);
+            pair_list.push_back(PICK_NONE);
+        }
+        bt->npairs = (uint32_t)(pair_list.size() / 2);
+    }
+    if (B >= LPT_MIN_B && ctx->lpt_order && !pair_up)
     {
         std::vector<uint32_t> ntok_of((size_t)B);
         {
@@ -250,10 +301,22 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     // small recycled steps: lengths return through the walk's last wave, and a small enough batch of
     // programs is read where it lies (pinned, device-visible) instead of being copied first
     const uint32_t ngroups = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
-    bt->direct = bt->recycled && ctx->direct_steps && (uint64_t)B * ngroups <= DIRECT_STEP_MAX_ITEMS;
+    bt->direct = bt->recycled && ctx->direct_steps && (uint64_t)B * ngroups <= DIRECT_STEP_MAX_ITEMS && !pair_up;
     bt->in_place = bt->direct && total * ngroups <= DIRECT_READ_MAX_BYTES;
     if (!bt->in_place)
         HIPCHK(ctx, hipMemcpyAsync(bt->d_prog.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+    if (bt->npairs)
+    {
+        const size_t pbytes = pair_list.size() * 4;
+        if (pbytes > bt->h_pairs.cap) // (the pinned copy the upload reads: grown only when the stream holds nothing of it)
+        {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, bt->h_pairs.reserve(pbytes));
+        }
+        HIPCHK(ctx, bt->d_pairs.reserve(pbytes));
+        memcpy(bt->h_pairs.p, pair_list.data(), pbytes);
+        HIPCHK(ctx, hipMemcpyAsync(bt->d_pairs.p, bt->h_pairs.p, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     // h_pin is reused by the next upload.  A recycled step batch is read back (and the stream
     // drained) by lvbgpu_batch_lengths before anything can build again: no need to wait here.
     if (!bt->recycled)
@@ -350,6 +413,12 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
             a.npick_chains = b->npick_chains;
             memcpy(a.pick_chain, b->pick_chain, sizeof a.pick_chain);
         }
+    }
+    if (b->npairs && !b->direct)
+    {
+        a.pairs = (const uint32_t *)b->d_pairs.p;
+        a.npairs = b->npairs;
+        a.nitems = b->npairs * a.ngroups;
     }
     const bool timed = ctx->walk_timing && (ctx->wt_seen++ % ctx->wt_every) == 0;
     if (timed)

@@ -121,6 +121,8 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
         ctx->direct_steps = ds[0] != '0';
     if (const char *lp = getenv("LVBGPU_LPT"))
         ctx->lpt_order = lp[0] != '0';
+    if (const char *pr = getenv("LVBGPU_PAIR"))
+        ctx->pair_min = std::max(0, atoi(pr));
     if (const char *pl = getenv("LVBGPU_PIPELINE"))
         ctx->pipeline_steps = pl[0] != '0';
     static_assert(lvbgpu_ctx::STEP_PIPELINE == 4, "lvbgpu_destroy lists the step batches");

@@ -298,6 +298,7 @@ struct lvbgpu_ctx
     uint32_t step_seq = 0;
     bool direct_steps = true; // env LVBGPU_DIRECT_STEPS=0 turns them off (A/B measurements)
     bool lpt_order = true;    // env LVBGPU_LPT=0: keep big batches in the caller's order on the device
+    int pair_min = 0;         // env LVBGPU_PAIR=n: batches of n candidates and more are walked two candidates per wave (0: never)
     DevBuf d_tmp_changes;     // fused commits: per-combine accumulators, zero between launches
     size_t tmp_changes_zeroed_cap = 0; // capacity of d_tmp_changes when it was last cleared (0: never)
     DevBuf d_cin, d_cout; // strict-compat arenas
@@ -388,6 +389,10 @@ struct lvbgpu_batch
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)
     int32_t chain = 0;         // ... and which chain's tree that is
     std::vector<int32_t> slot_of; // big batches: candidate b sits at position slot_of[b] (longest program first)
+    // two candidates per wave (kernels.hpp WalkArgs::pairs): who walks with whom, npairs == 0: one candidate per wave
+    DevBuf d_pairs;
+    PinBuf h_pairs;
+    uint32_t npairs = 0;
 };
 
 // steps up to this many candidates finish within a few hundred microseconds: poll for them instead of

@@ -37,6 +37,7 @@
 //
 // No MFMA: bitwise integer streaming, bound by the L2 -> CU path.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <cstdlib>
 #include <stdint.h>
 
@@ -133,6 +134,72 @@ struct OffVec
     uint32_t lo, hi; // one 64-bit value per lane, split over two VGPRs
 };
 
+// The watcher waves of a launch (WalkArgs::watcher; eight extra blocks at the end of the grid, wave `wid` of WATCH_WAVES):
+// wait until every length slot of this wave's chunks has its ngroups arrivals, hand the lengths to the host - and, for
+// a step decided on the device, apply the chains' rules (WalkArgs::rules).  Shared by fitch_walk and fitch_walk_pair.
+__device__ __forceinline__ void watcher_block(const WalkArgs &a, const uint32_t wid, const uint32_t lane)
+{
+    // all 32 waves of the eight extra blocks watch: wave w takes the 64-candidate chunks w, w + 32, ... (one
+    // wave alone would take B / 64 dependent round trips AFTER the last walking wave: 35 us at B = 4096)
+    constexpr uint32_t WATCHERS = WATCH_WAVES;
+    const unsigned long long want = (unsigned long long)a.ngroups;
+    const unsigned long long count_mask = 0xFFFull << WATCH_COUNT_SHIFT;
+    bool gave_up = false;
+    for (uint32_t base = wid * 64u; base < a.B; base += WATCHERS * 64u)
+    {
+        const uint32_t i = base + lane;
+        if (i < a.B)
+        {
+            // the accept decision (kernels.hpp WalkArgs::rules): the candidate's chain says which rule (fetched now,
+            // over the host link, while the walking waves are still at it), the rule where the chain's candidates
+            // start; the chain's pick is the smallest taken index
+            uint32_t ch = 0;
+            DecideRule rule{};
+            if (a.rules)
+            {
+                ch = a.cands[i].flags >> CAND_CHAIN_SHIFT;
+                rule = a.rules[ch];
+            }
+            unsigned long long v;
+            uint32_t budget = 1u << 24; // ~ seconds: every walking wave finishes on its own, this is a backstop
+            while ((((v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & count_mask) >>
+                    WATCH_COUNT_SHIFT) != want &&
+                   --budget)
+                __builtin_amdgcn_s_sleep(8);
+            gave_up |= budget == 0u;
+            __hip_atomic_store(a.host_len + i, v & ~count_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.rules && budget != 0u && lvb_take((long long)(v & ~count_mask), &rule, i - rule.start))
+                atomicMin(a.d_pick_out + ch, i - rule.start);
+        }
+    }
+    atomics_acknowledged(); // the wave's stores and picks (all lanes) before its flag
+    // every watcher wave has a flag word of its own (the host waits for all 32): no counter for them to meet at
+    if (lane == 0)
+        __hip_atomic_store(a.host_flag + wid, __builtin_amdgcn_ballot_w64(gave_up) != 0ull ? 0xFFFFFFFFu : a.step_seq,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.rules)
+    {
+        // the picks go to the host once EVERY watcher wave has had its say: the last one to tick (all the others'
+        // atomics were acknowledged before their ticks were sent) copies them and sets the flag behind the waves'
+        uint32_t last = 0;
+        if (lane == 0)
+            last = atomicAdd(a.watch_done, 1u) == WATCHERS - 1u ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane(last))
+        {
+            if (lane < a.npick_chains)
+                __hip_atomic_store(a.host_pick + lane,
+                                   __hip_atomic_load(a.d_pick_out + a.pick_chain[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            atomics_acknowledged();
+            if (lane == 0)
+            {
+                __hip_atomic_store(a.watch_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.host_flag + WATCHERS, a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 // WIDE: row offsets kept as 64-bit byte counts in two vectors (tree blocks of 64 GiB and more).  The
 // narrow form - offsets in 16-byte units, 32 bits, the shift folded into the address add - saves three
 // instructions per token: 2.3 % of the launch (the loop sits within 7 % of what the L2 -> CU path delivers,
@@ -160,66 +227,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     if constexpr (WATCH)
         if (blockIdx.x >= nblk)
         {
-            // all 32 waves of the eight extra blocks watch: wave w takes the 64-candidate chunks w, w + 32, ... (one
-            // wave alone would take B / 64 dependent round trips AFTER the last walking wave: 35 us at B = 4096)
-            constexpr uint32_t WATCHERS = WATCH_WAVES;
-            const uint32_t wid = (blockIdx.x - nblk) * WALK_WAVES + wave;
-            const unsigned long long want = (unsigned long long)a.ngroups;
-            const unsigned long long count_mask = 0xFFFull << WATCH_COUNT_SHIFT;
-            bool gave_up = false;
-            for (uint32_t base = wid * 64u; base < a.B; base += WATCHERS * 64u)
-            {
-                const uint32_t i = base + lane;
-                if (i < a.B)
-                {
-                    // the accept decision (kernels.hpp WalkArgs::rules): the candidate's chain says which rule (fetched now,
-                    // over the host link, while the walking waves are still at it), the rule where the chain's candidates
-                    // start; the chain's pick is the smallest taken index
-                    uint32_t ch = 0;
-                    DecideRule rule{};
-                    if (a.rules)
-                    {
-                        ch = a.cands[i].flags >> CAND_CHAIN_SHIFT;
-                        rule = a.rules[ch];
-                    }
-                    unsigned long long v;
-                    uint32_t budget = 1u << 24; // ~ seconds: every walking wave finishes on its own, this is a backstop
-                    while ((((v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & count_mask) >>
-                            WATCH_COUNT_SHIFT) != want &&
-                           --budget)
-                        __builtin_amdgcn_s_sleep(8);
-                    gave_up |= budget == 0u;
-                    __hip_atomic_store(a.host_len + i, v & ~count_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (a.rules && budget != 0u && lvb_take((long long)(v & ~count_mask), &rule, i - rule.start))
-                        atomicMin(a.d_pick_out + ch, i - rule.start);
-                }
-            }
-            atomics_acknowledged(); // the wave's stores and picks (all lanes) before its flag
-            // every watcher wave has a flag word of its own (the host waits for all 32): no counter for them to meet at
-            if (lane == 0)
-                __hip_atomic_store(a.host_flag + wid, __builtin_amdgcn_ballot_w64(gave_up) != 0ull ? 0xFFFFFFFFu : a.step_seq,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (a.rules)
-            {
-                // the picks go to the host once EVERY watcher wave has had its say: the last one to tick (all the others'
-                // atomics were acknowledged before their ticks were sent) copies them and sets the flag behind the waves'
-                uint32_t last = 0;
-                if (lane == 0)
-                    last = atomicAdd(a.watch_done, 1u) == WATCHERS - 1u ? 1u : 0u;
-                if (__builtin_amdgcn_readfirstlane(last))
-                {
-                    if (lane < a.npick_chains)
-                        __hip_atomic_store(a.host_pick + lane,
-                                           __hip_atomic_load(a.d_pick_out + a.pick_chain[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    atomics_acknowledged();
-                    if (lane == 0)
-                    {
-                        __hip_atomic_store(a.watch_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(a.host_flag + WATCHERS, a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                }
-            }
+            watcher_block(a, (blockIdx.x - nblk) * WALK_WAVES + wave, lane);
             return;
         }
     // a.flip: every other launch walks each XCD's share of the tile-major list from its far end.  A tree block beyond
@@ -648,6 +656,310 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two candidates per wave (scoring launches; WalkArgs::pairs).  Candidates whose programs END alike - the same clean rows
+// with the same flags from some token on to the root: moves whose dirty paths run together - are handed to ONE wave,
+// which walks A's private part, then B's, then the common suffix ONCE with two states (accumulator, operand stack,
+// counters): every row of the suffix is loaded once and combined twice.  The walk is bound by what the L2 -> CU path
+// feeds a wave, and a pure-load probe with this shape - half the waves, as many loads fewer as
+// the pairs share - takes proportionally less time (tools/pair_probe.py: 4096 x 28 loads 90.9 us, 2048 x 40 loads
+// 64.7 us).  Who is paired with whom is the producer's business (host: sorted by the program read backwards; device:
+// sorted by a key of the paths' preorder numbers); the wave finds the suffix itself by comparing the two token vectors
+// from the end.  Programs longer than one 64-token chunk are walked alone (b = NONE, or no sharing).
+struct WalkState
+{
+    uint4 acc;
+    uint32_t nonempty, nonempty_rare, sp;
+};
+
+template <bool WIDE, bool WATCH>
+__global__ __launch_bounds__(WALK_THREADS) void fitch_walk_pair(const WalkArgs a)
+{
+    extern __shared__ uint4 lds_stack[]; // operand stacks: [wave][state][level][lane]
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nblk = WATCH ? gridDim.x - 8u : gridDim.x;
+    if constexpr (WATCH)
+        if (blockIdx.x >= nblk)
+        {
+            watcher_block(a, (blockIdx.x - nblk) * WALK_WAVES + wave, lane);
+            return;
+        }
+    const uint32_t in_xcd = a.flip ? (nblk >> 3) - 1u - (blockIdx.x >> 3) : (blockIdx.x >> 3);
+    const uint32_t pos = (blockIdx.x & 7u) * (nblk >> 3) + in_xcd;
+    const uint32_t item = pos * WALK_WAVES + wave;
+    if (item >= a.nitems)
+        return;
+    // an item = (tile group, pair); inv_B was made for npairs by launch_walk
+    uint32_t group = __umulhi(item, a.inv_B), pair = item - group * a.npairs;
+    if (pair >= a.npairs)
+    {
+        group++;
+        pair -= a.npairs;
+    }
+    const uint32_t tile_begin = group * a.tiles_per + (group < a.tiles_rem ? group : a.tiles_rem);
+    const uint32_t tile_end = tile_begin + a.tiles_per + (group < a.tiles_rem ? 1u : 0u);
+
+    // (everything about the pair is wave-uniform and belongs in scalar registers: the indices come from memory, so the
+    // compiler cannot know - told so explicitly; with both descriptors in vector registers the walk spilled)
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uniform_desc = [&](uint32_t idx) {
+        const CandDesc v = a.cands[idx];
+        CandDesc u;
+        u.tok_off = uni(v.tok_off);
+        u.ntok = uni(v.ntok);
+        u.dst_off = uni(v.dst_off);
+        u.ncomb = uni(v.ncomb);
+        u.base = (long long)(((unsigned long long)uni((uint32_t)((unsigned long long)v.base >> 32)) << 32) | uni((uint32_t)v.base));
+        u.flags = uni(v.flags);
+        u.nfresh = uni(v.nfresh);
+        return u;
+    };
+    const uint32_t ia = uni(a.pairs[2u * pair]), ib = uni(a.pairs[2u * pair + 1u]);
+    const bool two = ib != PICK_NONE;
+    const CandDesc cdA = uniform_desc(ia);
+    CandDesc cdB{};
+    if (two)
+        cdB = uniform_desc(ib);
+    const uint32_t *__restrict__ tkA = a.toks + cdA.tok_off;
+    const uint32_t *__restrict__ tkB = a.toks + cdB.tok_off;
+    const uint32_t chainA = cdA.flags >> CAND_CHAIN_SHIFT, chainB = cdB.flags >> CAND_CHAIN_SHIFT;
+
+    // Both token vectors are fetched NOW, together (programs within one chunk): a wave's time is its chain of dependent
+    // round trips, and every phase below would otherwise begin with one of its own.
+    const bool preA = cdA.ntok <= 64u, preB = cdB.ntok <= 64u;
+    uint32_t tokA = 0u, tokB = 0u;
+    if (preA && lane < cdA.ntok)
+        tokA = tkA[lane];
+    if (two && preB && lane < cdB.ntok)
+        tokB = tkB[lane];
+    // the common suffix: tokens compared from the end, one per lane (the vectors turned round over the LDS crossbar)
+    uint32_t k = 0;
+    if (two && preA && preB && cdA.ntok != 0u && cdB.ntok != 0u && chainA == chainB)
+    {
+        uint32_t ra_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((cdA.ntok - 1u - lane) & 63u) << 2), (int)tokA);
+        uint32_t rb_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((cdB.ntok - 1u - lane) & 63u) << 2), (int)tokB);
+        ra_ = lane < cdA.ntok ? ra_ : 0xFFFFFFFEu;
+        rb_ = lane < cdB.ntok ? rb_ : 0xFFFFFFFDu;
+        const uint64_t differ = ~__builtin_amdgcn_ballot_w64(ra_ == rb_);
+        k = differ ? (uint32_t)__builtin_ctzll(differ) : 64u;
+        const uint32_t shortest = cdA.ntok < cdB.ntok ? cdA.ntok : cdB.ntok;
+        k = k < shortest ? k : shortest;
+    }
+
+    const char *__restrict__ in = reinterpret_cast<const char *>(a.rows_in) + (uint64_t)tile_begin * a.in_tile_bytes + lane * 16u;
+    global_cp lane_ptr = (global_cp)in;
+    auto load_row = [&](uint64_t off) -> uint4 {
+        asm volatile("" : "+v"(lane_ptr));
+        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(lane_ptr + off);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    auto load_row16 = [&](uint32_t off16) -> uint4 {
+        asm volatile("" : "+v"(lane_ptr));
+        const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(lane_ptr + ((uint64_t)off16 << 4));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    uint4 *const stackA = lds_stack + (size_t)(wave * 2u) * a.stack_depth * 64u + lane;
+    uint4 *const stackB = stackA + (size_t)a.stack_depth * 64u;
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+
+    // what the lengths' bases need (the cached changes of the candidates' dirty nodes, S_all), requested with the token
+    // vectors and reduced to wave-uniform values at once: nothing of it is carried through the walk in vector registers
+    long long baseA = cdA.base, baseB = cdB.base;
+    if (group == 0)
+    {
+        auto resident_base = [&](const CandDesc &cd, uint32_t chain) -> long long {
+            if (!(cd.flags & CAND_RESIDENT_BASE))
+                return 0;
+            const int32_t *ds = a.dsts + cd.dst_off;
+            const uint32_t bias = chain * a.chain_rows;
+            long long sub = 0;
+            for (uint32_t i = lane; i < cd.ncomb; i += 64u)
+            {
+                const int32_t dst = ds[i];
+                if (dst >= 0)
+                    sub += a.node_changes[(uint32_t)dst >= a.bias_from ? (uint32_t)dst + bias : (uint32_t)dst];
+            }
+            for (int off = 32; off > 0; off >>= 1)
+                sub += __shfl_xor(sub, off);
+            const long long s_all = a.s_all[4u * chain];
+            const long long v = s_all - sub;
+            return (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)v));
+        };
+        baseA += resident_base(cdA, chainA);
+        if (two)
+            baseB += resident_base(cdB, chainB);
+    }
+
+    // tokens [lo, hi) of the program at `tk` (ntok tokens), for one state (S2 == nullptr-like: DUAL false) or for two that
+    // share every load (DUAL true: the tokens are the same for both; lo .. hi lie within one chunk then)
+    auto run = [&](auto dual_tag, const uint32_t *__restrict__ tk, const uint32_t ntok, const uint32_t lo, const uint32_t hi,
+                   const uint32_t row_bias, WalkState &P, uint4 *const stP, WalkState &Q, uint4 *const stQ, const bool have_tok,
+                   const uint32_t the_tok) __attribute__((always_inline)) {
+        constexpr bool DUAL = decltype(dual_tag)::value;
+        for (uint32_t c0 = lo & ~63u; c0 < hi; c0 += 64u)
+        {
+            const uint32_t cnt = (ntok - c0 < 64u) ? ntok - c0 : 64u;
+            uint32_t mytok = have_tok ? the_tok : ((lane < cnt) ? tk[c0 + lane] : 0u);
+            // (opaque: what follows - three lane-shifted offset vectors per phase - is made HERE, per phase and tile, not
+            // hoisted out of the tile loop and kept alive through the other phases: the walk spilled its row pointer)
+            asm volatile("" : "+v"(mytok));
+            const uint32_t r0 = mytok & TOK_ROW_MASK;
+            const uint32_t myrow = r0 >= a.bias_from ? r0 + row_bias : r0;
+            const uint64_t myoff64 = WIDE ? (uint64_t)myrow * ((uint64_t)a.in_stride4 << 4) : (uint64_t)(myrow * a.in_stride4);
+            OffVec o0{(uint32_t)myoff64, (uint32_t)(myoff64 >> 32)};
+            auto down = [&](const OffVec &v, uint32_t d) {
+                const int sel = (int)(((lane + d) & 63u) << 2);
+                return OffVec{(uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v.lo),
+                              WIDE ? (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)v.hi) : 0u};
+            };
+            const OffVec o1 = down(o0, 1u), o2 = down(o0, 2u), o3 = down(o0, 3u);
+            auto row_at = [&](const OffVec &v, uint32_t j) -> uint4 {
+                const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)v.lo, (int)j);
+                if constexpr (!WIDE)
+                    return load_row16(lo32);
+                const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)v.hi, (int)j);
+                return load_row(((uint64_t)hi32 << 32) | lo32);
+            };
+            const uint64_t freshm = __builtin_amdgcn_ballot_w64((mytok & TOK_FRESH) != 0u);
+            const uint64_t mergem = __builtin_amdgcn_ballot_w64(((mytok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK) != 0u);
+            const uint64_t postm = mergem | (freshm >> 1);
+            auto tok_at = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)mytok, (int)j); };
+            auto post = [&](uint32_t j) __attribute__((always_inline)) {
+                const uint32_t tok = tok_at(j);
+                for (uint32_t m = (tok >> TOK_MERGE_SHIFT) & TOK_MERGE_MASK; m != 0; m--)
+                {
+                    P.sp--;
+                    P.acc = fitch_planes(stP[(size_t)P.sp * 64u], P.acc, P.nonempty_rare);
+                    if constexpr (DUAL)
+                    {
+                        Q.sp--;
+                        Q.acc = fitch_planes(stQ[(size_t)Q.sp * 64u], Q.acc, Q.nonempty_rare);
+                    }
+                }
+                if (j < 63u && ((freshm >> (j + 1u)) & 1u)) // the next token (of this chunk) starts a chain
+                {
+                    if (tok_at(j + 1u) & TOK_PUSH)
+                    {
+                        stP[(size_t)P.sp * 64u] = P.acc;
+                        P.sp++;
+                        if constexpr (DUAL)
+                        {
+                            stQ[(size_t)Q.sp * 64u] = Q.acc;
+                            Q.sp++;
+                        }
+                    }
+                    P.acc = ones;
+                    if constexpr (DUAL)
+                        Q.acc = ones;
+                }
+            };
+            auto step = [&](uint32_t j, uint32_t flagged, const uint4 cur) __attribute__((always_inline)) {
+                P.acc = fitch_planes(P.acc, cur, P.nonempty);
+                if constexpr (DUAL)
+                    Q.acc = fitch_planes(Q.acc, cur, Q.nonempty);
+                if (__builtin_expect(flagged != 0u, 0))
+                    post(j);
+            };
+            const uint32_t jb = lo > c0 ? lo - c0 : 0u;                  // first token of the range in this chunk
+            const uint32_t je = hi - c0 < cnt ? hi - c0 : cnt;           // one past its last
+            if (c0 != 0u && jb == 0u && (freshm & 1u)) // a chunk of a long program that opens with a chain start (one state only)
+            {
+                if (tok_at(0) & TOK_PUSH)
+                {
+                    stP[(size_t)P.sp * 64u] = P.acc;
+                    P.sp++;
+                }
+                P.acc = ones;
+            }
+            const uint32_t n = je - jb;
+            if (n < 4u)
+            {
+                for (uint32_t j = jb; j < je; j++)
+                    step(j, (uint32_t)(postm >> j) & 1u, row_at(o0, j));
+                continue;
+            }
+            // 4-slot ring: slot q holds the row of token j + q (as in fitch_walk, from token jb on)
+            uint4 ra = row_at(o0, jb), rb = row_at(o1, jb), rc = row_at(o2, jb), rd = row_at(o3, jb);
+            uint32_t jl = jb + 4u; // first token not yet in the ring
+            uint64_t fm = postm >> jb;
+#define LVB_PGROUP(F, J0, JL)                                                                                 \
+    step((J0), (F) & 1u, ra);                                                                                 \
+    ra = row_at(o0, (JL));                                                                                    \
+    step((J0) + 1u, (F) & 2u, rb);                                                                            \
+    rb = row_at(o1, (JL));                                                                                    \
+    step((J0) + 2u, (F) & 4u, rc);                                                                            \
+    rc = row_at(o2, (JL));                                                                                    \
+    step((J0) + 3u, (F) & 8u, rd);                                                                            \
+    rd = row_at(o3, (JL));
+            for (; jl + 8u <= je; jl += 8u, fm >>= 8)
+            {
+                const uint32_t f = (uint32_t)fm;
+                LVB_PGROUP(f, jl - 4u, jl)
+                LVB_PGROUP(f >> 4, jl, jl + 4u)
+            }
+            if (jl + 4u <= je)
+            {
+                const uint32_t f = (uint32_t)fm;
+                LVB_PGROUP(f, jl - 4u, jl)
+                jl += 4u;
+                fm >>= 4;
+            }
+#undef LVB_PGROUP
+            const uint32_t left = je - (jl - 4u); // 4..7 tokens left, the first four already in the ring
+            const uint32_t f = (uint32_t)fm;
+            step(jl - 4u, f & 1u, ra);
+            if (left > 4u)
+                ra = row_at(o0, jl);
+            step(jl - 3u, f & 2u, rb);
+            if (left > 5u)
+                rb = row_at(o1, jl);
+            step(jl - 2u, f & 4u, rc);
+            if (left > 6u)
+                rc = row_at(o2, jl);
+            step(jl - 1u, f & 8u, rd);
+            if (left > 4u)
+                step(jl, f & 16u, ra);
+            if (left > 5u)
+                step(jl + 1u, f & 32u, rb);
+            if (left > 6u)
+                step(jl + 2u, f & 64u, rc);
+        }
+    };
+
+    WalkState A{ones, 0u, 0u, 0u}, B{ones, 0u, 0u, 0u};
+    const uint32_t biasA = chainA * a.chain_rows, biasB = chainB * a.chain_rows;
+    for (uint32_t tile = tile_begin; tile < tile_end; tile++, lane_ptr += a.in_tile_bytes)
+    {
+        A.acc = ones;
+        B.acc = ones;
+        A.sp = B.sp = 0u;
+        run(std::false_type{}, tkA, cdA.ntok, 0u, cdA.ntok - k, biasA, A, stackA, A, stackA, preA, tokA);
+        if (two)
+            run(std::false_type{}, tkB, cdB.ntok, 0u, cdB.ntok - k, biasB, B, stackB, B, stackB, preB, tokB);
+        if (k)
+            run(std::true_type{}, tkA, cdA.ntok, cdA.ntok - k, cdA.ntok, biasA, A, stackA, B, stackB, true, tokA);
+    }
+
+    // the two lengths: changes of a lane = 32 sites per combine (and per chain start) minus the non-empty ones
+    const uint32_t ntiles_here = tile_end - tile_begin;
+    auto finish = [&](const CandDesc &cd, const WalkState &S, long long base, uint32_t cand) {
+        uint32_t wsum = 32u * (cd.ncomb + cd.nfresh) * ntiles_here - S.nonempty - S.nonempty_rare;
+        for (int off = 32; off > 0; off >>= 1)
+            wsum += (uint32_t)__shfl_xor((int)wsum, off);
+        unsigned long long total = wsum;
+        if (group == 0)
+            total += (unsigned long long)base;
+        if (lane == 0)
+            atomicAdd(a.len_out + cand, total + (WATCH ? 1ull << WATCH_COUNT_SHIFT : 0ull));
+    };
+    finish(cdA, A, baseA, ia);
+    if (two)
+        finish(cdB, B, baseB, ib);
+}
+
+// ---------------------------------------------------------------------------------------------
 // small helpers around the walk
 
 // descriptors and rewrites of the picked candidates of a device-built batch -> pinned host memory (one wave per
@@ -902,8 +1214,9 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream, ui
 {
     if (args.nitems == 0)
         return hipSuccess;
-    if (args.ngroups == 0 || args.ngroups > args.ntiles || args.nitems != args.B * args.ngroups ||
-        args.nitems >= (1u << 31))
+    const bool paired = args.pairs != nullptr && !commit;
+    if (args.ngroups == 0 || args.ngroups > args.ntiles || args.nitems != (paired ? args.npairs : args.B) * args.ngroups ||
+        args.nitems >= (1u << 31) || (paired && (args.npairs == 0 || (args.host_len && !args.watcher))))
         return hipErrorInvalidValue;
     WalkArgs a = args;
     // alternate the direction of big scoring launches whose rows do not fit the L2s (LVBGPU_FLIP=0: never)
@@ -920,10 +1233,13 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream, ui
     a.tiles_rem = a.ntiles % a.ngroups;
     // floor(2^32 / B): mulhi(item, inv_B) is floor(item / B) or one less for item < 2^31 (the kernel
     // fixes up once).  B == 1 would need 2^32: 2^32 - 1 gives item - 1 (0 for item 0), same fix-up.
-    a.inv_B = a.B == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / a.B);
+    {
+        const uint32_t per_group = paired ? a.npairs : a.B; // items per tile group
+        a.inv_B = per_group == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / per_group);
+    }
     uint32_t nblk = (a.nitems + WALK_WAVES - 1) / WALK_WAVES;
     nblk = (nblk + 7u) & ~7u; // the XCD remap needs a multiple of 8
-    size_t lds = (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4);
+    size_t lds = (size_t)WALK_WAVES * a.stack_depth * 64u * sizeof(uint4) * (paired ? 2u : 1u); // a paired wave keeps two operand stacks
     a.defer_slots = 0;
     if (commit)
     {
@@ -958,6 +1274,23 @@ hipError_t launch_walk(const WalkArgs &args, bool commit, hipStream_t stream, ui
     if (commit || !a.host_len || a.ngroups > WATCH_MAX_GROUPS)
         a.watcher = 0;
     const dim3 grid(a.watcher ? nblk + 8u : nblk), block(WALK_THREADS);
+    if (paired)
+    {
+        if (lds > MAX_LDS_BYTES)
+            return hipErrorInvalidValue;
+        if (a.watcher)
+        {
+            if (wide)
+                hipLaunchKernelGGL((fitch_walk_pair<true, true>), grid, block, lds, stream, a);
+            else
+                hipLaunchKernelGGL((fitch_walk_pair<false, true>), grid, block, lds, stream, a);
+        }
+        else if (wide)
+            hipLaunchKernelGGL((fitch_walk_pair<true, false>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((fitch_walk_pair<false, false>), grid, block, lds, stream, a);
+        return hipGetLastError();
+    }
     if (commit)
     {
         if (wide)
@@ -1019,7 +1352,11 @@ hipError_t raise_lds_limit()
                           reinterpret_cast<const void *>(&fitch_walk<false, true, 1>),
                           reinterpret_cast<const void *>(&fitch_walk<false, false, 1>),
                           reinterpret_cast<const void *>(&fitch_walk<false, true, 2>),
-                          reinterpret_cast<const void *>(&fitch_walk<false, false, 2>)})
+                          reinterpret_cast<const void *>(&fitch_walk<false, false, 2>),
+                          reinterpret_cast<const void *>(&fitch_walk_pair<true, true>),
+                          reinterpret_cast<const void *>(&fitch_walk_pair<false, true>),
+                          reinterpret_cast<const void *>(&fitch_walk_pair<true, false>),
+                          reinterpret_cast<const void *>(&fitch_walk_pair<false, false>)})
     {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         if (e != hipSuccess)

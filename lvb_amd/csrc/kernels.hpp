@@ -134,6 +134,10 @@ struct WalkArgs
     uint32_t npick_chains;
     uint32_t *watch_done; // device word, zero between launches
     uint32_t flip; // walk each XCD's share of the items from its far end (filled by launch_walk)
+    // two candidates per wave (fitch_walk_pair; scoring launches): pairs[2 p], pairs[2 p + 1] = the candidates of pair p
+    // (the second PICK_NONE: walked alone); an item is then (tile group, pair) and nitems = npairs * ngroups
+    const uint32_t *pairs;
+    uint32_t npairs;
     // COMMIT: produced sets and their counts wait in LDS, this many per wave, and go out in bursts (filled by
     // launch_walk, >= 1 for COMMIT).  A store or atomic inside the chain makes every wait for a
     // row a full drain of the memory counter (reads and writes return out of order with respect to each other),
