@@ -121,6 +121,12 @@ struct ChainRun
 
     // what the chain wants scored next, and the rule by which it accepts (Solve.c:303-378: lvb_amd/csrc/decide.h); false:
     // nothing (done, or an error in rc)
+    static double spec_factor()
+    {
+        static const double f = [] { const char *e = getenv("LVBHOST_SPEC_FACTOR"); const double v = e ? atof(e) : 3.0; return v > 0.1 ? v : 3.0; }();
+        return f;
+    }
+
     bool plan(lvbgpu_chain_draw &d, lvbgpu_chain_rule &rule)
     {
         if (phase == DONE)
@@ -142,8 +148,11 @@ struct ChainRun
         else
         {
             // Speculation depth follows the acceptance rate: when most proposals are accepted, all but the first few
-            // of a batch would be thrown away; when acceptances are rare the whole batch is consumed
-            int64_t room = std::min<int64_t>(p.batch, std::max<int64_t>(8, (int64_t)std::ceil(2.0 / accept_rate)));
+            // of a batch would be thrown away; when acceptances are rare the whole batch is consumed.  3 / rate leaves
+            // one step in twenty without an acceptance (e^-3); measured 500 x 50 000, SPR: factor 2 / 3 / 4 / 6 reach
+            // the reference program's 20 s length after 0.270-0.284 / 0.248 / 0.251 / 0.252 s with one chain and
+            // 0.466-0.472 / 0.463 / 0.468 / 0.451 s with 32 (LVBHOST_SPEC_FACTOR)
+            int64_t room = std::min<int64_t>(p.batch, std::max<int64_t>(8, (int64_t)std::ceil(spec_factor() / accept_rate)));
             if (p.reroot_interval > 0)
             {
                 const int64_t to_tick = p.reroot_interval - (current_iter % p.reroot_interval);

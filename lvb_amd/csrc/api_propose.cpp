@@ -416,6 +416,22 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     ga.info = (ProposalInfo *)ps.d_pinfo.p;
     ga.len_out = (unsigned long long *)bt->d_len.p;
     ga.pick_out = ps.step_decided ? (uint32_t *)ps.d_pick.p : nullptr;
+    // two candidates per wave (fitch_walk_pair): big launches only - a small one is a chain of latencies, not of loads -
+    // and only where every segment's keys fit the sorting workgroup's LDS and preorder numbers fit 16 bits
+    bool pair_up = ctx->pair_min > 0 && B >= ctx->pair_min && ctx->gen_idx_bytes == 2;
+    for (int32_t i = 0; i < k && pair_up; i++)
+        pair_up = (uint32_t)draws[i].count <= PAIR_SEG_MAX;
+    bt->npairs = 0;
+    if (pair_up)
+    {
+        uint32_t np = 0;
+        for (int32_t i = 0; i < k; i++)
+            np += ((uint32_t)draws[i].count + 1u) / 2u;
+        HIPCHK(ctx, ps.d_keys.reserve((size_t)B * 4));
+        HIPCHK(ctx, bt->d_pairs.reserve((size_t)np * 8));
+        ga.keys = (uint32_t *)ps.d_keys.p;
+        bt->npairs = np;
+    }
     ga.moves = d_moves;
     static const bool gen_profile = getenv("LVBGPU_GEN_PROFILE") != nullptr;
     if (gen_profile)
@@ -450,6 +466,28 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     // hold LDS and wave slots - and the step gains nothing over queueing behind it; with that stream at the lowest
     // priority a step takes 161 us.  profiles/experiments/r02_walk_and_step.md)
     HIPCHK(ctx, launch_propose(ga, ctx->stream));
+    if (pair_up)
+    {
+        PairArgs pa{};
+        pa.keys = ga.keys;
+        pa.pairs = (uint32_t *)bt->d_pairs.p;
+        pa.nseg = (uint32_t)k;
+        uint32_t bits = 1;
+        while ((1u << bits) < (uint32_t)ctx->nb + 1u)
+            bits++;
+        pa.major_bits = bits > 12u ? 12u : bits; // buckets by preorder number (coarser for very large trees)
+        pa.major_shift = bits > 12u ? bits - 12u : 0u;
+        uint32_t st = 0, pb = 0;
+        for (int32_t i = 0; i < k; i++)
+        {
+            pa.seg_start[i] = st;
+            pa.seg_count[i] = (uint32_t)draws[i].count;
+            pa.pair_base[i] = pb;
+            st += (uint32_t)draws[i].count;
+            pb += ((uint32_t)draws[i].count + 1u) / 2u;
+        }
+        HIPCHK(ctx, launch_pair_sort(pa, ctx->stream));
+    }
     bt->len_zeroed = true; // by the generator
     // Only the lengths come back per step (a move's descriptor and edits are fetched when, and only when, the caller
     // wants that candidate - lvbgpu_proposal_edits - or accepts it - lvbgpu_chains_commit).  One batch at a time the

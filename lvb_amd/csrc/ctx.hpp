@@ -219,6 +219,7 @@ struct lvbgpu_ctx
     {
         lvbgpu_batch *batch = nullptr;
         DevBuf d_pedits, d_pinfo;   // the candidates' rewrites and descriptors
+        DevBuf d_keys;              // their sort keys (two candidates per wave: who walks with whom)
         std::vector<PSeg> segs;     // the segments of the batch (lvbgpu_chains_commit picks from them)
         int32_t p_B = 0;            // candidates lvbgpu_proposal_edits may name (single chain, selected; 0: none)
         int32_t B = 0;

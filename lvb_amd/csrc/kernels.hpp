@@ -215,6 +215,7 @@ struct GenArgs
     ProposalInfo *info;
     unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
     uint32_t *pick_out;          // [MAX_CHAINS] picks of a step decided on the device: the generator resets its chains' (null: none)
+    uint32_t *keys;              // [B] sort keys for pairing the candidates (pair_kernel; null: none; needs 16-bit tables)
     const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
     unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
     int32_t use_lds;              // filled by launch_propose
@@ -223,6 +224,21 @@ struct GenArgs
 };
 static_assert(sizeof(GenArgs) <= 4000, "GenArgs travels as a kernel argument");
 hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
+
+// who walks with whom (fitch_walk_pair): every segment's candidates ordered by their keys and handed out two by two
+constexpr uint32_t PAIR_THREADS = 1024;
+constexpr uint32_t PAIR_SEG_MAX = 4096; // candidates of one segment whose keys and order fit LDS beside the histogram (longer: no pairing)
+struct PairArgs
+{
+    const uint32_t *keys; // [B] (GenArgs::keys)
+    uint32_t *pairs;      // [2 * npairs]: segment s's pairs from pair_base[s] on, ceil(count / 2) of them
+    uint32_t nseg;
+    uint32_t major_bits, major_shift; // buckets of the counting sort: (key >> 16) >> major_shift, below 2^major_bits
+    uint32_t seg_start[MAX_GEN_SEGS], seg_count[MAX_GEN_SEGS], pair_base[MAX_GEN_SEGS];
+    uint32_t blk_start[MAX_GEN_SEGS]; // first workgroup of each segment, and what a workgroup's LDS arrays hold (filled by launch_pair_sort)
+    uint32_t cap;
+};
+hipError_t launch_pair_sort(const PairArgs &args, hipStream_t stream);
 
 // rebuild the generator's tables of the picked candidates' chains on the device (one workgroup per pick)
 constexpr uint32_t REBUILD_THREADS = 1024;

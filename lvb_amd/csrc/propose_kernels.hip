@@ -279,6 +279,8 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
     // (the move's description as scalars: as a struct filled field by field it lived in scratch memory)
     int32_t pi_a = -1, pi_b = -1, pi_c = -1, pi_flag = 0;
     bool unusable = false;
+    // where the program's LAST chain starts, and its first (GenArgs::keys): candidates that agree on these end alike
+    int32_t key_major = -1, key_minor = -1;
 
     if (kind == 0)
     {
@@ -289,6 +291,7 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
         const int32_t keep = swap_right ? a : bb, moved = swap_right ? bb : a;
         pi_a = u;
         pi_flag = swap_right ? 1 : 0;
+        key_major = u;
         // edits: v trades c for `moved` (same side), u holds (keep, c)
         {
             const int32_t vl = (int32_t)t.left[v], vr = (int32_t)t.right[v];
@@ -471,6 +474,7 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                 if (dest != ss && t.inside(dest, ss))
                 {
                     // (1) dest below the sister: one chain sp, dp .. ss, then pp .. (sp's old place is skipped)
+                    key_major = dest;
                     LVB_HEAD_SP();
                     e.run(dp, 0u, (uint32_t)(t.dep(dp) - t.dep(ss)) + 1u, oc_dp, -1, -1, false);
                     if (pp != root)
@@ -484,6 +488,8 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                 else if (pp != root && t.inside(pp, dest))
                 {
                     // (2) dest is pp or above it: one chain from pp through dest, sp (new place), dp ..
+                    key_major = pp;
+                    key_minor = src;
                     const uint32_t up_to_dest = (uint32_t)(t.dep(pp) - t.dep(dest)); // nodes above pp up to dest
                     e.head2(ss, have_acc ? TOK_PUSH : 0u, oc_pp, pp, have_acc && up_to_dest == 0u);
                     e.run(pp, 1u, up_to_dest, -1, -1, -1, have_acc);
@@ -506,6 +512,7 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                     if (pp == root || m == pp)
                     {
                         // pp is the root or lies on the path from dp: one chain; where it passes pp, sp's place holds ss
+                        key_major = dest;
                         LVB_HEAD_SP();
                         if (dp != root)
                         {
@@ -520,6 +527,8 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                         const uint32_t dm = m == root ? 0u : (uint32_t)t.dep(m);
                         const uint32_t len_a = dp == root ? 0u : (uint32_t)t.dep(dp) - dm; // dp .. below M (0: M is dp)
                         const uint32_t len_b = (uint32_t)t.dep(pp) - dm;                     // pp .. below M (>= 1)
+                        key_major = pp;
+                        key_minor = dest;
                         LVB_HEAD_SP();
                         e.run(dp, 0u, len_a, oc_dp, -1, -1, false);
                         e.head2(ss, TOK_PUSH, oc_pp, pp, len_b == 1u);
@@ -561,6 +570,9 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
         g.cands[b] = cd;
         g.len_out[b] = 0ull; // the walk accumulates into it: cleared here, so a step needs no clearing pass of its own
         g.info[b] = ProposalInfo{kind, pi_a, pi_b, pi_c, pi_flag, (int32_t)e.o.nedit, overflow ? 1 : 0, (int32_t)e.o.ndst};
+        if (g.keys) // preorder numbers of the two chain starts: neighbours in this order end alike (pair_kernel)
+            g.keys[b] = (overflow || key_major < 0) ? 0xFFFFFFFFu
+                                                    : ((uint32_t)t.tin[key_major] << 16) | (key_minor >= 0 ? (uint32_t)t.tin[key_minor] & 0xFFFFu : 0u);
     }
     stamp(4);
 }
@@ -796,6 +808,163 @@ hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t s
         hipLaunchKernelGGL(rebuild_tables_kernel<uint16_t>, dim3(k + ga.k), dim3(REBUILD_THREADS), lds, stream, g, ga);
     else
         hipLaunchKernelGGL(rebuild_tables_kernel<int32_t>, dim3(k + ga.k), dim3(REBUILD_THREADS), lds, stream, g, ga);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Who walks with whom (fitch_walk_pair): a segment's candidates are put in order of their keys - the preorder number of
+// the node the program's LAST chain starts at, then of the one its first chain starts at: programs that agree on these
+// share their ends - and pair p is whoever stands at places 2p and 2p + 1.  The order is made by several workgroups per
+// segment that never talk to each other: workgroup r of a segment's R owns the r-th range of major keys; it reads ALL
+// the segment's keys (a few KB from L2), counts how many fall below its range - that is where its output starts - and
+// sorts the ones inside: counting sort by major key (LDS atomics; the order inside a bucket is whatever the atomics
+// gave), then every candidate finds its own place in its bucket by counting who comes before it in (key, index) order
+// (buckets hold a handful: four candidates per node at B = 4096, n = 500), so the result does not depend on timing.
+// One workgroup sorting a whole segment of 4096 took 10 us - more than the paired walk saves.
+__global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(const PairArgs g)
+{
+    extern __shared__ uint32_t lds_u32[];
+    // which segment, which range of it
+    uint32_t s = 0;
+    while (s + 1u < g.nseg && blockIdx.x >= g.blk_start[s + 1u])
+        s++;
+    const uint32_t r = blockIdx.x - g.blk_start[s];
+    const uint32_t R = (s + 1u < g.nseg ? g.blk_start[s + 1u] : gridDim.x) - g.blk_start[s];
+    const uint32_t start = g.seg_start[s], count = g.seg_count[s];
+    uint32_t *out = g.pairs + 2u * g.pair_base[s];
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t NB = 1u << g.major_bits;
+    auto bucket_of = [&](uint32_t key) { return key == 0xFFFFFFFFu ? NB - 1u : (key >> 16) >> g.major_shift; };
+    const uint32_t b_lo = (uint32_t)((uint64_t)NB * r / R), b_hi = (uint32_t)((uint64_t)NB * (r + 1u) / R); // my buckets
+    const uint32_t nbk = b_hi - b_lo;
+    // LDS: mine[cap] keys | idx[cap] | order[cap] | sorted[cap] | hist[nbk + 1] | scan scratch[64] | counters[2]
+    const uint32_t cap = g.cap;
+    uint32_t *mkey = lds_u32, *midx = mkey + cap, *order = midx + cap, *sorted = order + cap, *hist = sorted + cap,
+             *part = hist + nbk + 1u, *ctr = part + 64u;
+    for (uint32_t b = tid; b <= nbk; b += nt)
+        hist[b] = 0u;
+    if (tid < 2u)
+        ctr[tid] = 0u;
+    __syncthreads();
+    // one pass over all keys: how many lie below my range, and mine into LDS
+    uint32_t below = 0;
+    for (uint32_t i = tid; i < count; i += nt)
+    {
+        const uint32_t k = g.keys[start + i], b = bucket_of(k);
+        below += b < b_lo ? 1u : 0u;
+        if (b >= b_lo && b < b_hi)
+        {
+            const uint32_t at = atomicAdd(&ctr[1], 1u);
+            if (at < cap)
+            {
+                mkey[at] = k;
+                midx[at] = i;
+                atomicAdd(&hist[b - b_lo + 1u], 1u);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        below += (uint32_t)__shfl_xor((int)below, off);
+    if ((tid & 63u) == 0u)
+        atomicAdd(&ctr[0], below);
+    __syncthreads();
+    const uint32_t base = ctr[0], mine = ctr[1] < cap ? ctr[1] : cap; // (cap = the segment's length: never exceeded)
+    // exclusive scan of my buckets' counts (hist[b + 1] becomes bucket b's start): buckets dealt to the threads, the
+    // threads' sums scanned inside the waves by shuffles and across them through LDS
+    {
+        const uint32_t per = (nbk + nt - 1u) / nt;
+        const uint32_t b0 = tid * per;
+        uint32_t sum = 0;
+        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
+            sum += hist[b + 1u];
+        const uint32_t ln = tid & 63u, wv = tid >> 6, nwv = (nt + 63u) >> 6;
+        uint32_t incl = sum;
+        for (uint32_t d = 1; d < 64u; d <<= 1)
+        {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, (int)d);
+            if (ln >= d)
+                incl += v;
+        }
+        if (ln == 63u)
+            part[wv] = incl;
+        __syncthreads();
+        if (tid < 64u)
+        {
+            const uint32_t w = tid < nwv ? part[tid] : 0u;
+            uint32_t wi = w;
+            for (uint32_t d = 1; d < 64u; d <<= 1)
+            {
+                const uint32_t v = (uint32_t)__shfl_up((int)wi, (int)d);
+                if (tid >= d)
+                    wi += v;
+            }
+            part[tid] = wi - w; // exclusive
+        }
+        __syncthreads();
+        uint32_t run = part[wv] + incl - sum;
+        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
+        {
+            const uint32_t c = hist[b + 1u];
+            hist[b + 1u] = run;
+            run += c;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < mine; i += nt) // scatter: hist[b + 1] is bucket b's cursor, afterwards its end
+        order[atomicAdd(&hist[bucket_of(mkey[i]) - b_lo + 1u], 1u)] = i;
+    __syncthreads();
+    for (uint32_t pos = tid; pos < mine; pos += nt)
+    {
+        const uint32_t x = order[pos], b = bucket_of(mkey[x]) - b_lo;
+        const uint32_t lo = b ? hist[b] : 0u, hi = hist[b + 1u];
+        const uint64_t kx = ((uint64_t)mkey[x] << 32) | midx[x];
+        uint32_t before = 0;
+        for (uint32_t j = lo; j < hi; j++)
+        {
+            const uint32_t y = order[j];
+            before += ((((uint64_t)mkey[y]) << 32) | midx[y]) < kx ? 1u : 0u;
+        }
+        sorted[lo + before] = start + midx[x];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < mine; i += nt)
+        out[base + i] = sorted[i];
+    if (r == R - 1u && tid == 0u && (count & 1u))
+        out[count] = PICK_NONE; // an odd segment's last candidate walks alone
+}
+
+hipError_t launch_pair_sort(const PairArgs &args, hipStream_t stream)
+{
+    if (args.nseg == 0)
+        return hipSuccess;
+    PairArgs g = args;
+    // workgroups per segment: one per ~512 candidates, at most 8; each must be able to hold the whole segment in the
+    // worst case (every key in one range)
+    uint32_t nblk = 0, longest = 0, most_buckets = 0;
+    const uint32_t NB = 1u << g.major_bits;
+    for (uint32_t s = 0; s < g.nseg; s++)
+    {
+        if (g.seg_count[s] > PAIR_SEG_MAX)
+            return hipErrorInvalidValue; // the caller does not pair such batches
+        const uint32_t R = std::max(1u, std::min(8u, g.seg_count[s] / 512u));
+        g.blk_start[s] = nblk;
+        nblk += R;
+        longest = std::max(longest, g.seg_count[s]);
+        most_buckets = std::max(most_buckets, (NB + R - 1u) / R + 1u);
+    }
+    g.cap = longest;
+    const size_t lds = ((size_t)4 * longest + most_buckets + 1 + 64 + 2) * 4;
+    static bool raised_on[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised_on[dev])
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        raised_on[dev] = true;
+    }
+    if (lds > MAX_LDS_BYTES)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pair_kernel, dim3(nblk), dim3(PAIR_THREADS), lds, stream, g);
     return hipGetLastError();
 }
 

@@ -44,3 +44,28 @@ for i in range(100):
 wms, k = ctx.walk_timing_read()
 ctx.walk_timing(0)
 print(f"device-built    B={B}: {1e3*wms/k:.1f} us per walk")
+# ... and the whole pipelined step (generator [+ pair sort] + walk, two in flight), as bench.py's headline measures it
+import time
+draw = np.zeros(1, dtype=api.DRAW_DTYPE)
+draw[0]["chain"], draw[0]["count"], draw[0]["kind"] = 0, B, 1
+outs = [np.zeros(B, dtype=np.int64), np.zeros(B, dtype=np.int64)]
+def submit(slot, seed):
+    draw[0]["seed"] = seed
+    ctx._chk(ctx.lib.lvbgpu_chains_submit(ctx.h, slot, 1, draw.ctypes.data))
+def run(n, s0):
+    for j in range(2):
+        submit(j, s0 + j)
+    for i in range(n):
+        ctx._chk(ctx.lib.lvbgpu_chains_collect(ctx.h, i % 2, outs[i % 2]))
+        if i + 2 < n:
+            submit(i % 2, s0 + i + 2)
+run(300, 10)
+ctx.walk_timing(4)
+t0 = time.perf_counter()
+run(200, 1000)
+dt = time.perf_counter() - t0
+wms, k = ctx.walk_timing_read()
+ctx.walk_timing(0)
+print(f"pipelined step  B={B}: {1e6 * dt / 200:.1f} us per step = {B * 200 / dt / 1e6:.1f} M candidates/s, walk {1e3 * wms / k:.1f} us")
+chk = ctx.propose_score(B, 1, 4242)
+print("checksum", int(chk.sum()), int(chk.min()))
