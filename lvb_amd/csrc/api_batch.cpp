@@ -419,6 +419,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         a.pairs = (const uint32_t *)b->d_pairs.p;
         a.npairs = b->npairs;
         a.nitems = b->npairs * a.ngroups;
+        ctx->paired_walks++;
     }
     const bool timed = ctx->walk_timing && (ctx->wt_seen++ % ctx->wt_every) == 0;
     if (timed)

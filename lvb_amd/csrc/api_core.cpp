@@ -928,6 +928,15 @@ extern "C" int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds)
 
 // test hook for the wait limit: keeps the context's stream busy for about `ms` milliseconds (bounded: <= 2000) with a
 // kernel that does nothing but watch the clock, so that a step enqueued behind it cannot complete before then
+// test hook: how many scoring walks this context has launched two candidates per wave (LVBGPU_PAIR)
+extern "C" int lvbgpu_debug_paired_walks(lvbgpu_ctx *ctx, int64_t *launches)
+{
+    if (!ctx || !launches)
+        return LVBGPU_E_ARG;
+    *launches = ctx->paired_walks;
+    return LVBGPU_OK;
+}
+
 extern "C" int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms)
 {
     if (!ctx || ms < 1 || ms > 2000)

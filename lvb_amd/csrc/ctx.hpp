@@ -299,6 +299,7 @@ struct lvbgpu_ctx
     uint32_t step_seq = 0;
     bool direct_steps = true; // env LVBGPU_DIRECT_STEPS=0 turns them off (A/B measurements)
     bool lpt_order = true;    // env LVBGPU_LPT=0: keep big batches in the caller's order on the device
+    int64_t paired_walks = 0; // scoring walks launched two candidates per wave (lvbgpu_debug_paired_walks)
     int pair_min = 0;         // env LVBGPU_PAIR=n: batches of n candidates and more are walked two candidates per wave (0: never)
     DevBuf d_tmp_changes;     // fused commits: per-combine accumulators, zero between launches
     size_t tmp_changes_zeroed_cap = 0; // capacity of d_tmp_changes when it was last cleared (0: never)
