@@ -352,9 +352,13 @@ def kernel_only(ctx, tree, B: int, kind: int, nbatches: int, steps: int, warmup:
 def roofline_block(ctx, B: int, alg_bytes: float, launch_ms: float, mean_dirty: float, traffic, probe_reps: int = 20):
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     probe = ctx.probe_l2(B, max(8, int(round(mean_dirty + 3))), probe_reps)
+    # which variant the pipelined loop launches: small launches (B x tiles < 32768 waves) hand their lengths over through
+    # watcher waves (<.., 2>, api_propose.cpp WATCH_PIPELINED_MAX_ITEMS), the others are copied back (<.., 0>)
+    ntiles = (int(ctx.nwords) + 127) // 128
+    kernel = KERNEL if ("pair" in KERNEL or B * ntiles >= 32768) else KERNEL.replace(", 0>", ", 2>")
     out = {
         "bound": "l2", "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
-        "traffic": traffic, "kernel": KERNEL, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
+        "traffic": traffic, "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
         "probe": {"value": probe, "unit": "GB/s", "frac": achieved / probe if probe > 0 else None,
                   "source": "lvbgpu_probe_l2 in this process: pure loads, the walk's geometry and access pattern"},
         "note": "algorithmic bytes = (D+3) clean rows x nwords x 8 per candidate (SURVEY.md 8d), D measured on the "

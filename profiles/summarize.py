@@ -40,18 +40,23 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
     stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], ROOT / "profiles" / f"{tag}_kernel_stats.csv")
-    counters = defaultdict(list)
+    # <COMMIT = false, WIDE, HANDOVER>: the summary is of ONE variant of the scoring walk - the one the profiled run
+    # launched most (the plain walk <.., 0> of the bench's pipelined loop; small shapes, whose steps all qualify as lone
+    # steps, run the watcher variant <.., 2>); the handful of launches of the others are left out
+    by_variant = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(str(src / "pmc_*" / "*" / "*_counter_collection.csv")):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].split("(")[0]
-                # <COMMIT = false, WIDE, HANDOVER>: the direct-step and watcher variants (lone steps: a handful of launches
-                # of the profiled run) are left out - the summary is of the plain scoring walk the bench's roofline quotes
-                # (r02t: <.., true>; later: <.., 1> / <.., 2>)
-                if KERNEL in name and not (name.count(",") == 2 and not name.endswith((", 0>", ", false>"))):
-                    counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if KERNEL in name:
+                    by_variant[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    variant = max(by_variant, key=lambda v: sum(len(x) for x in by_variant[v].values()), default=None)
+    counters = by_variant[variant] if variant else {}
     if not counters and not stats:
         raise SystemExit(f"nothing under {src} matches the scoring kernel: no summary written")
+    if not counters:
+        print(f"no counter rows of the scoring kernel under {src}: kernel stats copied, no PMC summary written")
+        return
     summary = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in sorted(counters.items())}
     mean = lambda k: summary[k]["mean_per_launch"] if k in summary else None
     derived = {}
@@ -74,7 +79,7 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
                                          ("active(SQ_ACTIVE_INST_ANY)", "SQ_ACTIVE_INST_ANY")) if mean(c) is not None}
     doc = {"command": f"rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 40 --warmup 5 "
                       f"--headline-only {' '.join(extra)}  (one pass per counter set, profiles/collect.sh {tag})",
-           "kernel": f"lvbgpu::{KERNEL}", "counters": summary, "derived": derived}
+           "kernel": variant, "counters": summary, "derived": derived}
     (ROOT / "profiles" / f"{tag}_pmc_summary.json").write_text(json.dumps(doc, indent=1) + "\n")
     if "hbm_read_bytes_per_launch_corrected" in derived:
         # traffic.json: one entry per measured workload (bench.py picks the one that matches its arguments)
