@@ -898,6 +898,12 @@ int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const u
     bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
     for (int32_t j = 0; j < k && tables_on_device; j++)
         tables_on_device = ctx->parked[(size_t)chains[j]].d_topo_version == ctx->parked[(size_t)chains[j]].topo_version;
+    // Which first?  Both are launches of this call; the one enqueued second starts ~8 us later (a launch and an event
+    // record of host time).  The commit walk is the longer one when many chains accept together (32 picks: 28 us against
+    // the rebuild's 16), the rebuild when one chain does (8-20 us against 7-15).
+    static const int commit_first_env = [] { const char *e = getenv("LVBGPU_COMMIT_FIRST"); return e ? atoi(e) : -1; }();
+    const bool commit_first = commit_first_env >= 0 ? commit_first_env != 0 : k >= 4;
+    auto side_part = [&]() -> int {
     if (tables_on_device)
     {
         RebuildArgs ra{};
@@ -923,6 +929,9 @@ int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const u
     }
     else
         HIPCHK(ctx, launch_gather_picks(gat, ctx->side_stream));
+        return LVBGPU_OK;
+    };
+    auto commit_part = [&]() -> int {
     // 2. the picked candidates' own programs in commit form: produced sets and change counts go to their chains'
     //    rows, every candidate's last wave settles its chain's changes[] and S_all (fused commit)
     HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
@@ -943,6 +952,17 @@ int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const u
     a.tmp_stride = (uint32_t)(ctx->nb + 1);
     a.done_count = done;
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+
+        return LVBGPU_OK;
+    };
+    {
+        const int r1 = commit_first ? commit_part() : side_part();
+        if (r1 != LVBGPU_OK)
+            return r1;
+        const int r2 = commit_first ? side_part() : commit_part();
+        if (r2 != LVBGPU_OK)
+            return r2;
+    }
 
     *slot_out = slot;
     *seq_out = seq;
