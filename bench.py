@@ -94,6 +94,8 @@ def parse_args(argv=None):
                          "thread of its own (lvbhost_anneal_chain_groups); 1 = all chains lock-stepped in one context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 / 16 384 and uniform-alignment legs")
+    ap.add_argument("--single-chain-levels", type=int, default=3,
+                    help="run_levels of the single-chain annealing leg (0: device-drawn throughout, as a chain among others)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip BASELINE.json's other single-GPU configurations (cfg2 64 x 10k NNI, cfg5 2000 x 200k TBR)")
     ap.add_argument("--headline-only", action="store_true",
@@ -840,12 +842,16 @@ def rank_main(args) -> None:
             fresh = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100)
             p1 = params_for(0)
             p1.seed = args.seed * 7919 + 1000 * rank + 1
+            p1.run_levels = args.single_chain_levels   # a lone chain: runs of acceptances in one step while it is hot
             one, _ = host.anneal_chains(actx, [fresh], [p1])
             fresh.close()
             out["anneal"]["single_chain"] = {
                 "seconds": round(one[0]["seconds"], 3), "best_length": one[0]["best_length"], "scored": one[0]["scored"],
                 "consumed": one[0]["consumed"], "device_steps": one[0]["device_steps"],
-                "scored_per_s": round(one[0]["scored"] / one[0]["seconds"]), "frozen": one[0]["frozen"]}
+                "scored_per_s": round(one[0]["scored"] / one[0]["seconds"]), "frozen": one[0]["frozen"],
+                "run_levels": args.single_chain_levels,
+                "what": "one chain alone in its context; run_levels > 0: while it accepts most of what it sees its candidates are "
+                        "cumulative (host-drawn, up to that many accepted moves per scoring walk: lvbhost_anneal_params::run_levels)"}
         for t in atrees:
             t.close()
         for c in actxs:

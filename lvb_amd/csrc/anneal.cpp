@@ -207,7 +207,7 @@ extern "C" void lvbhost_anneal_defaults(lvbhost_anneal_params *p)
     p->sync_every = 0;
     p->log_cap = 0;
     p->device_proposals = 2;
-    p->reserved = 0;
+    p->run_levels = 0;
 }
 
 extern "C" int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost_anneal_params *p,

@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "decide.h"
 #include "host_tree.hpp"
 
 using namespace lvbgpu;
@@ -70,6 +71,8 @@ struct ChainRun
     int64_t accepted = 0, proposed = 0, failedcnt = 0, t_n = 0, iter = 0, current_iter = 0;
     double probs[3] = {0, 0, 0}, counter[3] = {1, 1, 1};
     double accept_rate = 0.5;
+    double rate_p = 0.5; // acceptances per consumed proposal (a moving average over ~64 proposals): a function of the trajectory alone
+    void saw(bool taken) { rate_p += ((taken ? 1.0 : 0.0) - rate_p) * (1.0 / 64.0); }
     // the step in flight
     int B = 0;
     int consumed_now = 0, accepted_now = 0;
@@ -304,6 +307,7 @@ struct ChainRun
             if (p.algorithm == 2) // the kinds of device-drawn candidates stay on the device: expected gain under the probabilities
                 for (int i = 0; i < 3; i++)
                     counter[i] += 0.5 * (1.0 - probs[i]);
+            saw(b == pick);
             if (b == pick)
             {
                 accepted_now++;
@@ -412,6 +416,240 @@ struct ChainRun
         return improved;
     }
 
+    // ------------------------------------------------------------------------------------------------------------
+    // RUNS OF ACCEPTANCES IN ONE STEP (one chain per context; lvbhost_anneal_params::run_levels).  While a chain accepts
+    // most of what it sees, a device step advances it by ONE move: the candidates behind the accepted one were drawn on
+    // the tree before it.  Here the step's candidates are CUMULATIVE: level 1 holds K alternatives drawn on the current
+    // tree T (proposals i, i + 1, ..), level 2 K alternatives drawn on T + the first alternative of level 1 (proposals
+    // i + 1, i + 2, .. of the run in which proposal i was accepted), and so on: L levels, every candidate given to the
+    // scorer as its rewrites relative to T (lvbgpu_score_batch takes any set of rewrites), all scored by one walk.
+    // Consumed in order exactly as the serial loop would (Solve.c:300-378): while the FIRST alternative of a level is
+    // accepted the next level continues the run; an accepted later alternative, or a level without an acceptance, ends
+    // the step.  Proposal i's draw is a function of (seed, i, the tree it is drawn on) and so is its Metropolis draw,
+    // so the chain's trajectory does not depend on L or K (tests/test_anneal_chains_cpu.py).  The neighbours are drawn
+    // by the host's generators here (proposals.hpp), not by the device's: a chain is in this mode while its acceptance
+    // rate is high, and only then.
+    bool hot = false; // in the host-drawn mode (with hysteresis: entered at 0.30 acceptances per proposal, left at 0.15)
+    std::vector<Topology> prefix;
+    std::vector<Edit> spine, alt, all_edits;
+    std::vector<int32_t> offs;
+    std::vector<int64_t> lens_h;
+    bool wants_host_step(int levels)
+    {
+        if (levels <= 0 || phase != ANNEAL)
+            return hot = false;
+        hot = hot ? rate_p >= 0.15 : rate_p >= 0.30;
+        return hot;
+    }
+    static void merge_edits(std::vector<Edit> &into, const Edit *add, size_t n)
+    {
+        for (size_t i = 0; i < n; i++)
+        {
+            bool found = false;
+            for (Edit &e : into)
+                if (e.node == add[i].node)
+                {
+                    e = add[i];
+                    found = true;
+                }
+            if (!found)
+                into.push_back(add[i]);
+        }
+    }
+    int kind_of(uint64_t index, Rng &r, const double *pr) const
+    {
+        switch (p.algorithm)
+        {
+        case 0: return (index & 1u) ? MOVE_SPR : MOVE_NNI; // Solve.c:288-297
+        case 10: return MOVE_NNI;
+        case 11: return MOVE_SPR;
+        case 12: return MOVE_TBR;
+        default: // Solve.c:262-283
+        {
+            const double u = r.uniform();
+            return u < pr[0] ? MOVE_NNI : (u < pr[0] + pr[1] ? MOVE_SPR : MOVE_TBR);
+        }
+        }
+    }
+    // -a 2 (Solve.c:253-259, 452-466): the probabilities follow the move counters, refreshed per proposal in this mode
+    // (the device-drawn mode refreshes them per batch); every consumed proposal adds its expected gain, whatever its
+    // fate, so the probabilities of proposal i + j are known when proposal i's step is drawn
+    static void counters_step(double *cnt, double *pr)
+    {
+        const long total = (long)(cnt[0] + cnt[1] + cnt[2]);
+        for (int i = 0; i < 3; i++)
+            pr[i] = cnt[i] / total;
+        for (int i = 0; i < 3; i++)
+            cnt[i] += 0.5 * (1.0 - pr[i]);
+    }
+    // one step of the host-drawn mode, start to finish (nothing stays in flight); false: nothing could be done (rc)
+    bool host_step(int levels)
+    {
+        finish_follow();
+        if (rc != LVBGPU_OK)
+            return false;
+        int64_t room = INT64_MAX;
+        if (p.reroot_interval > 0)
+        {
+            int64_t to_tick = p.reroot_interval - (current_iter % p.reroot_interval);
+            if (to_tick == 1) // the reference re-roots when the incremented counter hits a multiple (Solve.c:238-242)
+            {
+                ask_reroot();
+                const lvbgpu_chain_root rq{chain, pending_root};
+                rc = lvbgpu_chains_reroot(ctx, 1, &rq);
+                if (rc == LVBGPU_OK)
+                    rc = rerooted();
+                if (rc != LVBGPU_OK)
+                    return false;
+                to_tick = p.reroot_interval + 1;
+            }
+            room = to_tick - 1;
+        }
+        if (p.max_proposals > 0)
+            room = std::min(room, std::max<int64_t>(1, p.max_proposals - iter));
+        // alternatives per level: so many that a level goes without an acceptance one time in twenty
+        int K = (int)std::ceil(std::log(0.05) / std::log(1.0 - std::min(0.95, std::max(0.05, rate_p))));
+        K = std::max(2, std::min(K, 8));
+        int L = std::max(1, std::min(levels, 8));
+        while (L > 1 && (int64_t)(L - 1) + K > room)
+            L--;
+        K = (int)std::max<int64_t>(1, std::min<int64_t>(K, room - (L - 1)));
+        // the candidates
+        prefix.resize((size_t)L);
+        prefix[0] = tree->topo;
+        spine.clear();
+        all_edits.clear();
+        offs.assign(1, 0);
+        const uint64_t i0 = (uint64_t)iter;
+        std::string why;
+        // the move probabilities of proposals i0, i0 + 1, ..: constant within a step (a cooling step ends it, below)
+        // except with -a 2, where they follow the counters proposal by proposal
+        double pr_at[16][3];
+        {
+            double cnt[3] = {counter[0], counter[1], counter[2]}, pr[3] = {probs[0], probs[1], probs[2]};
+            for (int o = 0; o < L - 1 + K && o < 16; o++)
+            {
+                if (p.algorithm == 2)
+                    counters_step(cnt, pr);
+                for (int i = 0; i < 3; i++)
+                    pr_at[o][i] = pr[i];
+            }
+        }
+        for (int d = 0; d < L; d++)
+        {
+            const size_t first_off = all_edits.size();
+            size_t first_n = 0;
+            for (int k = 0; k < K; k++)
+            {
+                const uint64_t gi = i0 + (uint64_t)d + (uint64_t)k;
+                Rng r(lvb_mix64(p.seed * 0x9E3779B97F4A7C15ull + gi + 1u));
+                const int kind = kind_of(gi, r, pr_at[d + k]);
+                alt.clear();
+                propose(prefix[(size_t)d], kind, r, alt);
+                const size_t at = all_edits.size();
+                all_edits.insert(all_edits.end(), spine.begin(), spine.end());
+                {
+                    std::vector<Edit> cum(all_edits.begin() + (long)at, all_edits.end());
+                    merge_edits(cum, alt.data(), alt.size());
+                    all_edits.resize(at);
+                    all_edits.insert(all_edits.end(), cum.begin(), cum.end());
+                }
+                offs.push_back((int32_t)all_edits.size());
+                if (k == 0)
+                    first_n = all_edits.size() - at;
+            }
+            if (d + 1 < L) // the run goes on from the first alternative
+            {
+                spine.assign(all_edits.begin() + (long)first_off, all_edits.begin() + (long)(first_off + first_n));
+                prefix[(size_t)d + 1] = tree->topo;
+                if (!tree->pb.apply_edits(prefix[(size_t)d + 1], spine.data(), (int32_t)spine.size(), -1, &why))
+                {
+                    rc = LVBGPU_E_TOPOLOGY;
+                    return false;
+                }
+            }
+        }
+        const int32_t ncand = L * K;
+        lens_h.resize((size_t)ncand);
+        rc = lvbgpu_select_chain(ctx, chain);
+        if (rc == LVBGPU_OK)
+            rc = lvbgpu_score_batch(ctx, ncand, offs.data(), reinterpret_cast<const lvbgpu_edit *>(all_edits.data()), nullptr, lens_h.data());
+        if (rc != LVBGPU_OK)
+            return false;
+        res->device_steps++;
+        res->scored += ncand;
+        // consumed in order
+        consumed_now = accepted_now = 0;
+        int acc = -1; // the candidate the step ends on (its rewrites are the step's commit)
+        DecideRule rule{};
+        rule.minlen = minlen;
+        rule.seed = lvb_mix64(p.seed ^ 0xACCE97EDull);
+        Topology taken;
+        bool cooled = false;
+        for (int d = 0; d < L && phase == ANNEAL; d++)
+        {
+            bool run_goes_on = false;
+            for (int k = 0; k < K && phase == ANNEAL; k++)
+            {
+                const int c = d * K + k;
+                const int64_t len = lens_h[(size_t)c];
+                current_iter++;
+                consumed_now++;
+                if (p.algorithm == 2)
+                    counters_step(counter, probs);
+                rule.cur = cur;
+                rule.t = t;
+                const bool take = lvb_take((long long)len, &rule, (uint32_t)(i0 + (uint64_t)d + (uint64_t)k)) != 0;
+                saw(take);
+                if (rate_p < 0.15) // the chain has cooled off: device-drawn steps from the next proposal on - at the same
+                    cooled = true; // proposal whatever the step's shape
+                if (!take)
+                {
+                    if (after_proposal()) // a cooling step: what follows was drawn under the old temperature's probabilities
+                        cooled = true;
+                    if (cooled)
+                        break;
+                    continue;
+                }
+                accepted_now++;
+                res->accepted++;
+                if (len <= cur && len <= best) // ties or beats the best (Solve.c:309-319): the treestack needs the tree
+                {
+                    taken = tree->topo;
+                    if (!tree->pb.apply_edits(taken, all_edits.data() + offs[(size_t)c], offs[(size_t)c + 1] - offs[(size_t)c], -1, &why))
+                    {
+                        rc = LVBGPU_E_TOPOLOGY;
+                        return false;
+                    }
+                    if (len < best)
+                        tree->best.clear();
+                    if (tree->best.insert(taken))
+                        accepted++;
+                }
+                cur = len;
+                if (cur < best)
+                    best = cur;
+                acc = c;
+                if (after_proposal())
+                    cooled = true;
+                run_goes_on = k == 0 && !cooled;
+                break;
+            }
+            if (!run_goes_on || cooled)
+                break;
+        }
+        accept_rate = std::max(1e-4, rate_p); // (what the device-drawn steps size their batches by: not a function of this step's shape)
+        if (acc >= 0)
+        {
+            const lvbgpu_edit *e = reinterpret_cast<const lvbgpu_edit *>(all_edits.data()) + offs[(size_t)acc];
+            const int32_t ne = offs[(size_t)acc + 1] - offs[(size_t)acc];
+            rc = lvbgpu_commit(ctx, ne, e, -1, nullptr); // (the length is known: enqueued, not waited for)
+            if (rc == LVBGPU_OK)
+                rc = lvbhost_tree_apply(tree, e, ne, -1);
+        }
+        return rc == LVBGPU_OK;
+    }
+
     void finish()
     {
         res->best_length = best;
@@ -518,8 +756,22 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     if (lockstep && params[0].max_device_steps <= 0)
         return LVBGPU_E_ARG;
 
+    // one chain alone: runs of acceptances in one step while the chain is hot (ChainRun::host_step)
+    const int levels = R == 1 ? std::max(0, (int)params[0].run_levels) : 0;
+    bool host_stepped = false;
+
     // plan the chains and enqueue their step (nothing if every chain is done)
     auto submit_step = [&]() -> int {
+        if (levels > 0 && runs[0].wants_host_step(levels))
+        {
+            auto td = Clock::now();
+            const bool ok = runs[0].host_step(levels);
+            dev_seconds += since(td);
+            t_score += since(td);
+            f.active = false;
+            host_stepped = ok;
+            return ok ? LVBGPU_OK : (runs[0].rc != LVBGPU_OK ? runs[0].rc : LVBGPU_E_STATE);
+        }
         f.draws.clear();
         f.rules.clear();
         f.who.clear();
@@ -586,6 +838,27 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         t_after += since(tf);
         return LVBGPU_OK;
     };
+    // after every step: the log, when each chain stopped, until when at least half of them were still at it
+    auto account = [&] {
+        log_point(); // R comparisons: nothing next to a device step
+        // when did each chain stop, and until when was at least half of them still at it
+        int32_t active = 0;
+        int64_t scored_now = 0;
+        const double now = since(wall0);
+        for (ChainRun &r : runs)
+        {
+            scored_now += r.res->scored;
+            if (r.phase != ChainRun::DONE)
+                active++;
+            else if (r.res->seconds_done == 0.0)
+                r.res->seconds_done = now;
+        }
+        if (2 * active >= R)
+        {
+            busy_seconds = now;
+            busy_scored = scored_now;
+        }
+    };
     // the step's lengths and picks are back (or are waited for): every chain books its own; the accepted moves are
     // committed already (lvbgpu_chains_step_*)
     auto finish_step = [&]() -> int {
@@ -615,33 +888,21 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             }
         }
         t_consume += since(tp);
-        log_point(); // R comparisons: nothing next to a device step
-        // when did each chain stop, and until when was at least half of them still at it
-        int32_t active = 0;
-        int64_t scored_now = 0;
-        const double now = since(wall0);
-        for (ChainRun &r : runs)
-        {
-            scored_now += r.res->scored;
-            if (r.phase != ChainRun::DONE)
-                active++;
-            else if (r.res->seconds_done == 0.0)
-                r.res->seconds_done = now;
-        }
-        if (2 * active >= R)
-        {
-            busy_seconds = now;
-            busy_scored = scored_now;
-        }
+        account();
         return LVBGPU_OK;
     };
-
     rc = submit_step();
     while (rc == LVBGPU_OK)
     {
-        if (!lockstep && !f.active)
+        if (!lockstep && !f.active && !host_stepped)
             break;
-        rc = finish_step();
+        if (host_stepped) // (the step is complete already)
+        {
+            host_stepped = false;
+            account();
+        }
+        else
+            rc = finish_step();
         if (rc != LVBGPU_OK)
             break;
         steps++;

@@ -23,7 +23,7 @@ def double():
     return lib, new_ctx, free_ctx
 
 
-def run_chains(double, rows, min_len, n, seeds, max_proposals, algorithm, batch=64):
+def run_chains(double, rows, min_len, n, seeds, max_proposals, algorithm, batch=64, run_levels=0):
     from lvb_amd import host
     lib, new_ctx, free_ctx = double
     ctx = new_ctx(rows)
@@ -38,6 +38,7 @@ def run_chains(double, rows, min_len, n, seeds, max_proposals, algorithm, batch=
         p.min_len_tree = min_len
         p.max_proposals = max_proposals
         p.log_cap = 64
+        p.run_levels = run_levels
         params.append(p)
     try:
         res, log = host.anneal_chains(ctx, trees, params, lib=lib)
@@ -134,3 +135,28 @@ def test_chains_run_to_the_freezing_criterion_and_stop(double):
     assert len({r["consumed"] for r in res}) > 1                    # they froze at different times
     assert all(r["best_length"] <= r["start_length"] and r["final_length"] >= r["best_length"] for r in res)
     assert all(f[3] >= 1 for f in final)                            # every chain holds at least its best tree
+
+
+@pytest.mark.parametrize("algorithm", [0, 1, 2])
+def test_runs_of_acceptances_in_one_step_leave_the_trajectory_alone(double, algorithm):
+    """while a lone chain accepts most of what it sees its candidates are cumulative (level d drawn
+    on the tree the first alternatives of the levels before leave: lvbhost_anneal_params::run_levels), so one scoring
+    walk advances it by a RUN of accepted moves.  Proposal i's draw and its Metropolis draw are functions of (seed, i,
+    the tree it is drawn on): the trajectory with runs of up to 3 or 5 moves per step is the one with one move per step
+    (run_levels = 1: the same host-drawn mode, one level) - same counts, same lengths, same trees, same treestack -
+    in fewer steps.  (The device-drawn mode, run_levels = 0, draws by another law: a different, equally valid run.)"""
+    from lvb_amd import host
+    lib = double[0]
+    n, m = 30, 900
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 57), lib)
+    keys = tuple(k for k in KEYS if k not in ("device_steps", "scored"))
+    one, one_final, _ = run_chains(double, rows, min_len, n, [11], 2500, algorithm, run_levels=1)
+    for levels in (3, 5):
+        runs, runs_final, _ = run_chains(double, rows, min_len, n, [11], 2500, algorithm, run_levels=levels)
+        assert {k: runs[0][k] for k in keys} == {k: one[0][k] for k in keys}, levels
+        assert all(np.array_equal(a, b) for a, b in zip(runs_final[0][:2], one_final[0][:2]))
+        assert runs_final[0][2:] == one_final[0][2:]
+        assert runs[0]["device_steps"] < one[0]["device_steps"]                 # runs happened: fewer steps for the same moves
+    assert one[0]["consumed"] == 2500 and one[0]["accepted"] > 50 and one[0]["reroots"] >= 2
+    dev, _, _ = run_chains(double, rows, min_len, n, [11], 2500, algorithm, run_levels=0)
+    assert dev[0]["consumed"] == 2500                                            # the device-drawn law: another valid run

@@ -146,7 +146,7 @@ def test_one_step_over_all_chains_equals_the_chains_stepped_one_by_one(mods, n, 
     ref.close()
 
 
-def _run_chains(api, host, rows, min_len, n, seeds, max_proposals, algorithm):
+def _run_chains(api, host, rows, min_len, n, seeds, max_proposals, algorithm, run_levels=0):
     ctx = api.FitchContext(text_rows=rows)
     trees = [host.HostTree(n, seed=1000 + s) for s in seeds]
     params = []
@@ -159,6 +159,7 @@ def _run_chains(api, host, rows, min_len, n, seeds, max_proposals, algorithm):
         p.min_len_tree = min_len
         p.max_proposals = max_proposals
         p.log_cap = 64
+        p.run_levels = run_levels
         params.append(p)
     res, log = host.anneal_chains(ctx, trees, params)
     final = []
@@ -192,6 +193,30 @@ def test_a_chains_trajectory_does_not_depend_on_how_many_chains_run_beside_it(mo
     assert all(r["consumed"] == 2500 and r["best_length"] <= r["start_length"] for r in many)
     assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)      # the shared log only ever improves
     assert log[-1][1] == min(r["best_length"] for r in many)
+
+
+@pytest.mark.parametrize("algorithm", [0, 2])
+def test_runs_of_acceptances_in_one_step_leave_the_trajectory_alone(mods, algorithm):
+    """One chain with cumulative candidates (lvbhost_anneal_params::run_levels: up to 3 or 6 accepted moves per scoring
+    walk while the chain is hot, host-drawn, scored by lvbgpu_score_batch as rewrites of the resident tree, committed in
+    one commit walk) follows the trajectory it follows with one move per step - same counts, lengths, trees, treestack -
+    in fewer steps; the resident tree, its length and the host's mirror agree at the end (_run_chains), and so does a
+    full evaluation of the final topology on a fresh context.  CPU tier: tests/test_anneal_chains_cpu.py."""
+    api, host = mods
+    n, m = 60, 4000
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 33))
+    keys = ("start_length", "best_length", "final_length", "consumed", "accepted", "temperatures", "reroots", "topologies", "t_final")
+    one, one_final, _ = _run_chains(api, host, rows, min_len, n, [21], 6000, algorithm, run_levels=1)
+    for levels in (3, 6):
+        runs, runs_final, _ = _run_chains(api, host, rows, min_len, n, [21], 6000, algorithm, run_levels=levels)
+        assert {k: runs[0][k] for k in keys} == {k: one[0][k] for k in keys}, levels
+        assert all(np.array_equal(a, b) for a, b in zip(runs_final[0][:2], one_final[0][:2])) and runs_final[0][2:] == one_final[0][2:]
+        assert runs[0]["device_steps"] < one[0]["device_steps"]
+    assert one[0]["consumed"] == 6000 and one[0]["accepted"] > 100 and one[0]["reroots"] >= 5
+    fresh = api.FitchContext(text_rows=rows)
+    l, r, root, _ = one_final[0]
+    assert fresh.set_tree(l, r, root) == one[0]["final_length"]
+    fresh.close()
 
 
 def test_rerooting_several_chains_at_once_equals_rerooting_them_one_by_one(mods):
