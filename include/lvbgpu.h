@@ -204,6 +204,21 @@ typedef struct
     int32_t chain, new_root;
 } lvbgpu_chain_root;
 int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_root *reqs);
+/* fn(i, arg) for i in [0, n) on the context's host threads (the ones that build programs; LVBGPU_THREADS), the caller
+ * among them; returns when all are done.  For host loops that prepare many chains' candidates between two calls. */
+typedef void (*lvbgpu_task_fn)(int32_t index, void *arg);
+int lvbgpu_parallel_for(lvbgpu_ctx *ctx, int32_t n, lvbgpu_task_fn fn, void *arg);
+/* Host-made candidates of several chains in ONE walk: candidate b is a set of child-pair rewrites of chain
+ * chain_of[b]'s resident tree - one move, or the cumulative rewrites of a run of moves (any set that gives a tree);
+ * edit_offsets[B + 1] index `edits`.  What lvbgpu_select_chain + lvbgpu_score_batch does chain by chain
+ * (TreeEvaluation.c:191-264 per candidate).  Keep one chain's candidates adjacent. */
+int lvbgpu_chains_score_edits(lvbgpu_ctx *ctx, int32_t B, const int32_t *chain_of, const int32_t *edit_offsets,
+                              const lvbgpu_edit *edits, int64_t *lengths_out);
+/* ... and accept one such candidate per listed chain (distinct chains) in ONE commit walk, the generator's tables
+ * following on the device: what lvbgpu_select_chain + lvbgpu_commit(n, edits, -1, NULL) does chain by chain (SwapTrees
+ * after getplen, Solve.c:323/370).  Asynchronous: the caller scored the candidates and knows the lengths. */
+int lvbgpu_chains_commit_edits(lvbgpu_ctx *ctx, int32_t k, const int32_t *chains, const int32_t *edit_offsets,
+                               const lvbgpu_edit *edits);
 /* the rewrites of pick j of the LAST lvbgpu_chains_commit (for a host that mirrors the topologies): already on the
  * host, no device access */
 int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits);

@@ -138,14 +138,17 @@ typedef struct
     int32_t device_proposals; /* 0: neighbours are drawn and programmed by this library on the host;
                                  1: on the GPU (lvbgpu_propose_score*); 2: on the GPU for steps of
                                  >= 1024 candidates, on the host for smaller ones (default) */
-    int32_t run_levels;       /* lvbhost_anneal_chains with ONE chain: while the chain accepts most of what it sees (>= 0.30
-                                 acceptances per proposal) its candidates are drawn by the host's generators and are
-                                 CUMULATIVE - level d holds alternatives drawn on the tree the first alternatives of
-                                 levels 1 .. d-1 leave - so that one scoring walk advances the chain by a run of
-                                 accepted moves instead of one.  0: off (default: the chain's
-                                 trajectory is then the one it has among other chains), n >= 1: that many levels (3 is
-                                 a good choice; 1: host-drawn, one move per step).  The trajectory does not depend on
-                                 n >= 1; ignored with more than one chain per context */
+    int32_t run_levels;       /* lvbhost_anneal_chains: while a chain accepts most of what it sees (>= 0.30 acceptances per
+                                 proposal; back to device draws below 0.15) its candidates are drawn by the host's
+                                 generators and are CUMULATIVE - level d holds alternatives drawn on the tree the
+                                 first alternatives of levels 1 .. d-1 leave - so that one scoring walk advances the
+                                 chain by a run of accepted moves instead of one; the hot chains of a step share one
+                                 scoring walk and one commit walk.  0: off (default), n >= 1:
+                                 that many levels (3 is a good choice; 1: host-drawn, one move per step).  The
+                                 trajectory does not depend on n >= 1, nor on the chains beside it; the value of the
+                                 first chain's parameters counts for all.  Pays for one or two chains per context
+                                 (500 x 50 000: 0.36 -> 0.28 s for one, 0.43 -> 0.38 s for two); even at four, a loss
+                                 beyond: the host draws and builds ~10 us of programs per chain and step */
 } lvbhost_anneal_params;
 
 typedef struct

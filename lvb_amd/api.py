@@ -82,6 +82,9 @@ SIGNATURES = {
     "lvbgpu_chains_collect": (C.c_int, [C.c_void_p, C.c_int32, _i64p]),
     "lvbgpu_chains_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "lvbgpu_chains_reroot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "lvbgpu_parallel_for": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lvbgpu_chains_score_edits": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
+    "lvbgpu_chains_commit_edits": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p]),
     "lvbgpu_chains_picked_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_chains_step_submit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "lvbgpu_chains_step_collect": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i32p]),
@@ -303,6 +306,20 @@ class FitchContext:
         """reqs: (chain, new_root_leaf) - re-root those chains in one commit walk."""
         p = np.array([tuple(int(v) for v in row) for row in reqs], dtype=PICK_DTYPE)
         self._chk(self.lib.lvbgpu_chains_reroot(self.h, len(p), p.ctypes.data))
+
+    def chains_score_edits(self, chains, cands) -> np.ndarray:
+        """Host-made candidates of several chains in one walk: cands[b] = rewrites of chain chains[b]'s resident tree."""
+        off, ed, _ = self._pack(cands, None)
+        out = np.zeros(len(cands), dtype=np.int64)
+        ch = np.ascontiguousarray(chains, dtype=np.int32)
+        self._chk(self.lib.lvbgpu_chains_score_edits(self.h, len(cands), ch, off, ed.ctypes.data, out))
+        return out
+
+    def chains_commit_edits(self, chains, cands) -> None:
+        """Accept one host-made candidate per listed chain in one commit walk (asynchronous)."""
+        off, ed, _ = self._pack(cands, None)
+        ch = np.ascontiguousarray(chains, dtype=np.int32)
+        self._chk(self.lib.lvbgpu_chains_commit_edits(self.h, len(cands), ch, off, ed.ctypes.data))
 
     def chains_commit(self, picks) -> None:
         """picks: (chain, b) - candidate b of that chain's draw in the last chains_propose_score call."""

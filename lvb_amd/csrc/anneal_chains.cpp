@@ -429,11 +429,13 @@ struct ChainRun
     // so the chain's trajectory does not depend on L or K (tests/test_anneal_chains_cpu.py).  The neighbours are drawn
     // by the host's generators here (proposals.hpp), not by the device's: a chain is in this mode while its acceptance
     // rate is high, and only then.
+    double hs_draw_s = 0, hs_consume_s = 0; // LVBHOST_PROFILE: where a host-drawn step's time goes (this chain's share)
+    int64_t hs_steps = 0, hs_cands = 0;
     bool hot = false; // in the host-drawn mode (with hysteresis: entered at 0.30 acceptances per proposal, left at 0.15)
     std::vector<Topology> prefix;
     std::vector<Edit> spine, alt, all_edits;
     std::vector<int32_t> offs;
-    std::vector<int64_t> lens_h;
+    Topology taken;
     bool wants_host_step(int levels)
     {
         if (levels <= 0 || phase != ANNEAL)
@@ -482,27 +484,27 @@ struct ChainRun
         for (int i = 0; i < 3; i++)
             cnt[i] += 0.5 * (1.0 - pr[i]);
     }
-    // one step of the host-drawn mode, start to finish (nothing stays in flight); false: nothing could be done (rc)
-    bool host_step(int levels)
+    // A host-drawn step in stages, so that a driver can serve many chains with ONE scoring walk and ONE commit walk:
+    //   hs_wants_reroot()  the re-root tick has come: the driver re-roots all such chains in one walk first
+    //   hs_draw(levels)    the step's candidates into all_edits / offs (hs_ncand of them); touches this chain only
+    //   hs_consume(lens)   books them in order; hs_acc = the candidate the step ends on (-1: none); this chain only
+    //   hs_accepted_edits  its rewrites, for the driver's commit; hs_follow() applies them to the host's tree
+    int32_t hs_ncand = 0, hs_acc = -1, hs_L = 0, hs_K = 0;
+    uint64_t hs_i0 = 0;
+    bool hs_wants_reroot()
     {
-        finish_follow();
-        if (rc != LVBGPU_OK)
+        if (p.reroot_interval <= 0 || p.reroot_interval - (current_iter % p.reroot_interval) != 1)
             return false;
+        ask_reroot(); // the reference re-roots when the incremented counter hits a multiple (Solve.c:238-242)
+        return true;
+    }
+    void hs_draw(int levels, bool rerooted_now)
+    {
+        auto ht0 = Clock::now();
         int64_t room = INT64_MAX;
         if (p.reroot_interval > 0)
         {
-            int64_t to_tick = p.reroot_interval - (current_iter % p.reroot_interval);
-            if (to_tick == 1) // the reference re-roots when the incremented counter hits a multiple (Solve.c:238-242)
-            {
-                ask_reroot();
-                const lvbgpu_chain_root rq{chain, pending_root};
-                rc = lvbgpu_chains_reroot(ctx, 1, &rq);
-                if (rc == LVBGPU_OK)
-                    rc = rerooted();
-                if (rc != LVBGPU_OK)
-                    return false;
-                to_tick = p.reroot_interval + 1;
-            }
+            const int64_t to_tick = rerooted_now ? p.reroot_interval + 1 : p.reroot_interval - (current_iter % p.reroot_interval);
             room = to_tick - 1;
         }
         if (p.max_proposals > 0)
@@ -565,26 +567,32 @@ struct ChainRun
                 if (!tree->pb.apply_edits(prefix[(size_t)d + 1], spine.data(), (int32_t)spine.size(), -1, &why))
                 {
                     rc = LVBGPU_E_TOPOLOGY;
-                    return false;
+                    return;
                 }
             }
         }
-        const int32_t ncand = L * K;
-        lens_h.resize((size_t)ncand);
-        rc = lvbgpu_select_chain(ctx, chain);
-        if (rc == LVBGPU_OK)
-            rc = lvbgpu_score_batch(ctx, ncand, offs.data(), reinterpret_cast<const lvbgpu_edit *>(all_edits.data()), nullptr, lens_h.data());
-        if (rc != LVBGPU_OK)
-            return false;
+        hs_L = L;
+        hs_K = K;
+        hs_i0 = i0;
+        hs_ncand = L * K;
+        hs_acc = -1;
+        hs_draw_s += since(ht0);
+        hs_steps++;
+        hs_cands += hs_ncand;
+    }
+    void hs_consume(const int64_t *lens)
+    {
+        auto ht0 = Clock::now();
+        const int L = hs_L, K = hs_K;
+        const uint64_t i0 = hs_i0;
         res->device_steps++;
-        res->scored += ncand;
-        // consumed in order
+        res->scored += hs_ncand;
         consumed_now = accepted_now = 0;
         int acc = -1; // the candidate the step ends on (its rewrites are the step's commit)
         DecideRule rule{};
         rule.minlen = minlen;
         rule.seed = lvb_mix64(p.seed ^ 0xACCE97EDull);
-        Topology taken;
+        std::string why;
         bool cooled = false;
         for (int d = 0; d < L && phase == ANNEAL; d++)
         {
@@ -592,7 +600,7 @@ struct ChainRun
             for (int k = 0; k < K && phase == ANNEAL; k++)
             {
                 const int c = d * K + k;
-                const int64_t len = lens_h[(size_t)c];
+                const int64_t len = lens[c];
                 current_iter++;
                 consumed_now++;
                 if (p.algorithm == 2)
@@ -619,7 +627,7 @@ struct ChainRun
                     if (!tree->pb.apply_edits(taken, all_edits.data() + offs[(size_t)c], offs[(size_t)c + 1] - offs[(size_t)c], -1, &why))
                     {
                         rc = LVBGPU_E_TOPOLOGY;
-                        return false;
+                        return;
                     }
                     if (len < best)
                         tree->best.clear();
@@ -639,15 +647,16 @@ struct ChainRun
                 break;
         }
         accept_rate = std::max(1e-4, rate_p); // (what the device-drawn steps size their batches by: not a function of this step's shape)
-        if (acc >= 0)
-        {
-            const lvbgpu_edit *e = reinterpret_cast<const lvbgpu_edit *>(all_edits.data()) + offs[(size_t)acc];
-            const int32_t ne = offs[(size_t)acc + 1] - offs[(size_t)acc];
-            rc = lvbgpu_commit(ctx, ne, e, -1, nullptr); // (the length is known: enqueued, not waited for)
-            if (rc == LVBGPU_OK)
-                rc = lvbhost_tree_apply(tree, e, ne, -1);
-        }
-        return rc == LVBGPU_OK;
+        hs_acc = acc;
+        hs_consume_s += since(ht0);
+    }
+    // the host's tree takes the accepted candidate's rewrites (the driver has enqueued their commit)
+    void hs_follow()
+    {
+        if (hs_acc < 0 || rc != LVBGPU_OK)
+            return;
+        rc = lvbhost_tree_apply(tree, reinterpret_cast<const lvbgpu_edit *>(all_edits.data()) + offs[(size_t)hs_acc],
+                                offs[(size_t)hs_acc + 1] - offs[(size_t)hs_acc], -1);
     }
 
     void finish()
@@ -756,22 +765,131 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     if (lockstep && params[0].max_device_steps <= 0)
         return LVBGPU_E_ARG;
 
-    // one chain alone: runs of acceptances in one step while the chain is hot (ChainRun::host_step)
-    const int levels = R == 1 ? std::max(0, (int)params[0].run_levels) : 0;
+    // Runs of acceptances in one step while chains are hot (ChainRun::hs_*): the hot chains of a step are served by the
+    // host part below - their cumulative candidates drawn here (on the context's host threads), ONE scoring walk for all of
+    // them (lvbgpu_chains_score_edits), ONE commit walk for what they accept (lvbgpu_chains_commit_edits) - the others by
+    // the device step as before; a step may have both parts.
+    const int levels = std::max(0, (int)params[0].run_levels);
     bool host_stepped = false;
+    std::vector<ChainRun *> hot;
+    std::vector<uint8_t> hot_rerooted;
+    std::vector<int32_t> h_chain_of, h_offs, h_first, h_commit_chain, h_commit_offs;
+    std::vector<lvbgpu_edit> h_edits, h_commit_edits;
+    std::vector<int64_t> h_lens;
+    double hs_score_s = 0, hs_commit_s = 0, hs_prep_s = 0;
+    int64_t hs_parts = 0;
+    struct HotJob
+    {
+        std::vector<ChainRun *> *hot;
+        std::vector<uint8_t> *rerooted;
+        const int64_t *lens;
+        const int32_t *first;
+        int levels;
+    } hot_job{&hot, &hot_rerooted, nullptr, nullptr, levels};
+    // the host part of a step: everything for the hot chains, start to finish (nothing of it stays in flight)
+    auto host_part = [&]() -> int {
+        auto t0 = Clock::now();
+        // re-roots first (the candidates are drawn on the re-rooted trees), all of them in one walk
+        roots.clear();
+        hot_rerooted.assign(hot.size(), 0);
+        for (size_t i = 0; i < hot.size(); i++)
+        {
+            hot[i]->finish_follow();
+            if (hot[i]->rc != LVBGPU_OK)
+                return hot[i]->rc;
+            if (hot[i]->hs_wants_reroot())
+            {
+                roots.push_back({hot[i]->chain, hot[i]->pending_root});
+                hot_rerooted[i] = 1;
+            }
+        }
+        if (!roots.empty())
+        {
+            int rr = lvbgpu_chains_reroot(ctx, (int32_t)roots.size(), roots.data());
+            for (size_t i = 0; i < hot.size() && rr == LVBGPU_OK; i++)
+                if (hot_rerooted[i])
+                    rr = hot[i]->rerooted();
+            if (rr != LVBGPU_OK)
+                return rr;
+        }
+        int rp = lvbgpu_parallel_for(ctx, (int32_t)hot.size(), [](int32_t i, void *a) {
+            HotJob *j = (HotJob *)a;
+            (*j->hot)[(size_t)i]->hs_draw(j->levels, (*j->rerooted)[(size_t)i] != 0); }, &hot_job);
+        if (rp != LVBGPU_OK)
+            return rp;
+        h_chain_of.clear();
+        h_offs.assign(1, 0);
+        h_edits.clear();
+        h_first.clear();
+        for (ChainRun *r : hot)
+        {
+            if (r->rc != LVBGPU_OK)
+                return r->rc;
+            h_first.push_back((int32_t)h_chain_of.size());
+            const int32_t base = (int32_t)h_edits.size();
+            for (int32_t c = 0; c < r->hs_ncand; c++)
+            {
+                h_chain_of.push_back(r->chain);
+                h_offs.push_back(base + r->offs[(size_t)c + 1]);
+            }
+            const lvbgpu_edit *e = reinterpret_cast<const lvbgpu_edit *>(r->all_edits.data());
+            h_edits.insert(h_edits.end(), e, e + r->all_edits.size());
+        }
+        h_lens.resize(h_chain_of.size());
+        hs_prep_s += since(t0);
+        t0 = Clock::now();
+        int rs = lvbgpu_chains_score_edits(ctx, (int32_t)h_chain_of.size(), h_chain_of.data(), h_offs.data(), h_edits.data(), h_lens.data());
+        if (rs != LVBGPU_OK)
+            return rs;
+        hs_score_s += since(t0);
+        t0 = Clock::now();
+        hot_job.lens = h_lens.data();
+        hot_job.first = h_first.data();
+        rp = lvbgpu_parallel_for(ctx, (int32_t)hot.size(), [](int32_t i, void *a) {
+            HotJob *j = (HotJob *)a;
+            (*j->hot)[(size_t)i]->hs_consume(j->lens + j->first[(size_t)i]); }, &hot_job);
+        if (rp != LVBGPU_OK)
+            return rp;
+        h_commit_chain.clear();
+        h_commit_offs.assign(1, 0);
+        h_commit_edits.clear();
+        for (ChainRun *r : hot)
+        {
+            if (r->rc != LVBGPU_OK)
+                return r->rc;
+            if (r->hs_acc < 0)
+                continue;
+            const lvbgpu_edit *e = reinterpret_cast<const lvbgpu_edit *>(r->all_edits.data());
+            h_commit_chain.push_back(r->chain);
+            h_commit_edits.insert(h_commit_edits.end(), e + r->offs[(size_t)r->hs_acc], e + r->offs[(size_t)r->hs_acc + 1]);
+            h_commit_offs.push_back((int32_t)h_commit_edits.size());
+        }
+        if (!h_commit_chain.empty())
+        {
+            const int rcm = lvbgpu_chains_commit_edits(ctx, (int32_t)h_commit_chain.size(), h_commit_chain.data(), h_commit_offs.data(),
+                                                       h_commit_edits.data());
+            if (rcm != LVBGPU_OK)
+                return rcm;
+            for (ChainRun *r : hot)
+            {
+                r->hs_follow();
+                if (r->rc != LVBGPU_OK)
+                    return r->rc;
+            }
+        }
+        hs_commit_s += since(t0);
+        hs_parts++;
+        return LVBGPU_OK;
+    };
 
     // plan the chains and enqueue their step (nothing if every chain is done)
     auto submit_step = [&]() -> int {
-        if (levels > 0 && runs[0].wants_host_step(levels))
-        {
-            auto td = Clock::now();
-            const bool ok = runs[0].host_step(levels);
-            dev_seconds += since(td);
-            t_score += since(td);
-            f.active = false;
-            host_stepped = ok;
-            return ok ? LVBGPU_OK : (runs[0].rc != LVBGPU_OK ? runs[0].rc : LVBGPU_E_STATE);
-        }
+        hot.clear();
+        host_stepped = false;
+        if (levels > 0)
+            for (ChainRun &r : runs)
+                if (r.wants_host_step(levels))
+                    hot.push_back(&r);
         f.draws.clear();
         f.rules.clear();
         f.who.clear();
@@ -782,6 +900,8 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         {
             lvbgpu_chain_draw d{};
             lvbgpu_chain_rule rule{};
+            if (r.hot)
+                continue; // (served by the host part)
             if (r.plan(d, rule))
             {
                 f.draws.push_back(d);
@@ -813,16 +933,26 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
                 return rr;
         }
         t_plan += since(tp);
-        if (f.draws.empty())
-            return LVBGPU_OK;
-        f.lens.resize(f.total);
-        f.picks.resize(f.draws.size());
-        auto td = Clock::now();
-        const int r = lvbgpu_chains_step_submit(ctx, 0, (int32_t)f.draws.size(), f.draws.data(), f.rules.data());
-        dev_seconds += since(td);
-        t_score += since(td);
-        t_submit += since(td);
-        f.active = r == LVBGPU_OK;
+        int r = LVBGPU_OK;
+        if (!f.draws.empty())
+        {
+            f.lens.resize(f.total);
+            f.picks.resize(f.draws.size());
+            auto td = Clock::now();
+            r = lvbgpu_chains_step_submit(ctx, 0, (int32_t)f.draws.size(), f.draws.data(), f.rules.data());
+            dev_seconds += since(td);
+            t_score += since(td);
+            t_submit += since(td);
+            f.active = r == LVBGPU_OK;
+        }
+        if (r == LVBGPU_OK && !hot.empty()) // (while the device draws and walks the others' candidates)
+        {
+            auto td = Clock::now();
+            r = host_part();
+            dev_seconds += since(td);
+            t_score += since(td);
+            host_stepped = r == LVBGPU_OK;
+        }
         return r;
     };
     // the trees of the chains that accepted in the step before follow their moves now, while the device works
@@ -896,13 +1026,11 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     {
         if (!lockstep && !f.active && !host_stepped)
             break;
-        if (host_stepped) // (the step is complete already)
-        {
-            host_stepped = false;
-            account();
-        }
+        if (f.active)
+            rc = finish_step(); // (accounts for the step)
         else
-            rc = finish_step();
+            account(); // the host part was the whole step
+        host_stepped = false;
         if (rc != LVBGPU_OK)
             break;
         steps++;
@@ -958,6 +1086,22 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
                         "consume + bookkeeping %.1f  trees following %.1f  total %.1f\n",
                 R, (long long)steps, 1e6 * t_plan / steps, 1e6 * t_reroot / steps, 1e6 * t_score / steps, 1e6 * t_submit / steps,
                 1e6 * t_consume / steps, 1e6 * t_after / steps, 1e6 * secs / steps);
+    if (getenv("LVBHOST_PROFILE") && hs_parts)
+    {
+        int64_t chain_steps = 0, cands = 0;
+        double draw_s = 0, consume_s = 0;
+        for (const ChainRun &r : runs)
+        {
+            chain_steps += r.hs_steps;
+            cands += r.hs_cands;
+            draw_s += r.hs_draw_s;
+            consume_s += r.hs_consume_s;
+        }
+        fprintf(stderr, "[anneal_chains] host-drawn parts: %lld (%.1f chains, %.1f candidates per chain); per part (us): re-roots + draw + gather %.1f  "
+                        "score %.1f  consume + commit %.1f   (summed over the chains' threads: draw %.1f, consume %.1f)\n",
+                (long long)hs_parts, (double)chain_steps / hs_parts, (double)cands / std::max<int64_t>(1, chain_steps), 1e6 * hs_prep_s / hs_parts,
+                1e6 * hs_score_s / hs_parts, 1e6 * hs_commit_s / hs_parts, 1e6 * draw_s / hs_parts, 1e6 * consume_s / hs_parts);
+    }
     for (ChainRun &r : runs)
     {
         const int64_t keep_global = r.res->global_best_length;

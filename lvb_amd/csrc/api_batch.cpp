@@ -37,6 +37,8 @@ struct BuildJob
     const int32_t *roots = nullptr;
     const int32_t *left = nullptr, *right = nullptr; // full mode: [B][2n-3]
     bool full = false;
+    const int32_t *chain_of = nullptr; // a chain per candidate (lvbgpu_chains_score_edits: every chain's state is parked)
+    int32_t par_min = 0;               // candidates from which the pool builds (0: the default)
 };
 
 // whole-tree programs of trees [b0, b1)
@@ -83,7 +85,7 @@ void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const 
     const int32_t *edit_offsets = job.edit_offsets;
     const lvbgpu_edit *edits = job.edits;
     const int32_t *roots = job.roots;
-    if (w.topo_version != ctx->topo_version)
+    if (!job.chain_of && w.topo_version != ctx->topo_version)
     {
         w.topo = ctx->topo;
         w.topo_version = ctx->topo_version;
@@ -104,6 +106,24 @@ void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const 
             w.why = "edit_offsets not monotone";
             return;
         }
+        int32_t chain = ctx->chain;
+        if (job.chain_of) // the candidate's own chain: this worker's private copy of that chain's topology
+        {
+            chain = job.chain_of[b];
+            if (chain < 0 || chain >= ctx->nchains || !ctx->parked[(size_t)chain].have_tree)
+            {
+                w.rc = chain < 0 || chain >= ctx->nchains ? LVBGPU_E_ARG : LVBGPU_E_STATE;
+                w.why = "candidate " + std::to_string(b) + ": chain out of range, or it has no resident tree";
+                return;
+            }
+            const ChainSlot &cs = ctx->parked[(size_t)chain];
+            if (w.topo_version != cs.topo_version)
+            {
+                w.topo = cs.topo;
+                w.topo_version = cs.topo_version;
+                w.pb.resize(w.topo.nb);
+            }
+        }
         const size_t tok0 = w.prog.toks.size(), dst0 = w.prog.dsts.size();
         w.prog.max_stack = 0;
         if (!w.pb.build_candidate(w.topo, reinterpret_cast<const Edit *>(edits) + e0, e1 - e0, roots ? roots[b] : -1,
@@ -118,7 +138,7 @@ void build_slice(lvbgpu_ctx *ctx, BuildWorker &w, int32_t b0, int32_t b1, const 
         cd.ntok = (uint32_t)(w.prog.toks.size() - tok0);
         cd.dst_off = (uint32_t)dst0;
         cd.ncomb = (uint32_t)(w.prog.dsts.size() - dst0);
-        cd.flags = CAND_RESIDENT_BASE | ((uint32_t)ctx->chain << CAND_CHAIN_SHIFT);
+        cd.flags = CAND_RESIDENT_BASE | ((uint32_t)chain << CAND_CHAIN_SHIFT);
         for (size_t i = tok0; i < w.prog.toks.size(); i++)
             cd.nfresh += (w.prog.toks[i] & TOK_FRESH) ? 1u : 0u;
         w.cands.push_back(cd);
@@ -139,7 +159,7 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
         const int v = e ? atoi(e) : PARALLEL_BUILD_MIN;
         return (int32_t)(v < 2 ? 2 : v);
     }();
-    const int32_t par_min = job.full ? 16 : par_min_edits;
+    const int32_t par_min = job.par_min > 0 ? job.par_min : (job.full ? 16 : par_min_edits);
     if (B >= par_min)
     {
         if (!ctx->pool)
@@ -335,6 +355,7 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     bt->full_mode = job.full;
     bt->topo_version = ctx->topo_version;
     bt->chain = ctx->chain;
+    bt->spans_chains = job.chain_of != nullptr;
     bt->stats.candidates = B;
     bt->stats.combines = (int64_t)ndst;
     bt->stats.rows_read = (int64_t)ntok;
@@ -567,6 +588,94 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
                     ctx->set_aside.push_back(b);
                     b = nullptr;
                 }
+        }
+        else
+            (void)hipStreamSynchronize(ctx->stream);
+    }
+    return rc;
+}
+
+namespace lvbgpu_detail
+{
+void park_chain(lvbgpu_ctx *ctx);
+void unpark_chain(lvbgpu_ctx *ctx, int32_t c);
+} // namespace lvbgpu_detail
+
+// fn(i, arg) for i in [0, n) on the context's host threads (the pool that builds programs), the caller among them;
+// returns when all are done.  For host loops that prepare many chains' candidates between two library calls.
+extern "C" int lvbgpu_parallel_for(lvbgpu_ctx *ctx, int32_t n, lvbgpu_task_fn fn, void *arg)
+{
+    if (!ctx || n < 0 || !fn)
+        return LVBGPU_E_ARG;
+    if (n > 1 && !ctx->pool)
+    {
+        const int t = host_threads();
+        if (t > 1)
+            ctx->pool = new (std::nothrow) Pool(t);
+    }
+    const int T = ctx->pool ? std::max(1, std::min(ctx->pool->size(), (int)n)) : 1;
+    if (T == 1)
+    {
+        for (int32_t i = 0; i < n; i++)
+            fn(i, arg);
+        return LVBGPU_OK;
+    }
+    ctx->pool->run(T, [&](int t) {
+        for (int32_t i = (int32_t)((int64_t)n * t / T), e = (int32_t)((int64_t)n * (t + 1) / T); i < e; i++)
+            fn(i, arg);
+    });
+    return LVBGPU_OK;
+}
+
+// Host-made candidates of SEVERAL chains in one walk: candidate b is a set of rewrites of chain chain_of[b]'s resident
+// tree (any set that gives a tree: one move, or the cumulative rewrites of a run of moves).  What lvbgpu_select_chain +
+// lvbgpu_score_batch does chain by chain, with one launch for all of them; the programs are built on the pool's threads
+// from 32 candidates on.  Candidates of one chain should be adjacent (a builder thread keeps one chain's topology at a time).
+extern "C" int lvbgpu_chains_score_edits(lvbgpu_ctx *ctx, int32_t B, const int32_t *chain_of, const int32_t *edit_offsets,
+                                         const lvbgpu_edit *edits, int64_t *lengths_out)
+{
+    if (!ctx || !lengths_out || B < 1 || !chain_of || !edit_offsets || (!edits && edit_offsets[B] > 0))
+        return LVBGPU_E_ARG;
+    {
+        const int rf = settle(ctx); // the host side of a chain commit still on its way
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    struct Parked
+    {
+        lvbgpu_ctx *c;
+        int32_t sel;
+        explicit Parked(lvbgpu_ctx *x) : c(x), sel(x->chain) { park_chain(x); }
+        ~Parked() { unpark_chain(c, sel); }
+    } guard(ctx);
+    lvbgpu_batch *&b = ctx->step_batch[0];
+    if (!b)
+    {
+        b = new (std::nothrow) lvbgpu_batch();
+        if (!b)
+            return LVBGPU_E_NOMEM;
+        b->recycled = true;
+    }
+    BuildJob job;
+    job.edit_offsets = edit_offsets;
+    job.edits = edits;
+    job.chain_of = chain_of;
+    job.par_min = 32;
+    for (BuildWorker &w : ctx->workers)
+        w.topo_version = ~0ull; // (versions are unique across chains, but a worker's copy may be of a chain re-uploaded since)
+    int rc = build_into(ctx, b, B, job);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_launch(ctx, b);
+    if (rc == LVBGPU_OK)
+        rc = lvbgpu_batch_lengths(ctx, b, lengths_out);
+    if (rc != LVBGPU_OK)
+    {
+        if (ctx->wait_gave_up)
+        {
+            ctx->wait_gave_up = false;
+            ctx->set_aside.push_back(b);
+            b = nullptr;
         }
         else
             (void)hipStreamSynchronize(ctx->stream);

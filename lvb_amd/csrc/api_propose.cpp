@@ -1160,47 +1160,26 @@ extern "C" int lvbgpu_chains_step_edits(lvbgpu_ctx *ctx, int32_t i, lvbgpu_edit 
 // new-root path): what lvbgpu_select_chain + lvbgpu_commit(edits, new_root, NULL) does chain by chain - R chains
 // re-rooting every 1000 proposals each were a third of a step's device time that way.  The generator's tables follow
 // on the device.  Asynchronous: a re-root does not change the length.
-extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_root *reqs)
+namespace lvbgpu_detail
 {
-    if (!ctx || k < 1 || k > MAX_CHAINS || !reqs)
-        return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    AllParked guard(ctx);
-    {
-        const int rf = resolve_follow(ctx); // the programs below are built from the chains' topologies as they are NOW
-        if (rf != LVBGPU_OK)
-            return rf;
-    }
-    uint64_t seen = 0;
-    std::vector<std::vector<Edit>> edits((size_t)k);
+// Rewrites of several chains' resident trees (distinct chains; a new root leaf per chain or -1) walked in ONE commit walk,
+// the generator's tables following on the device: the common part of lvbgpu_chains_reroot and
+// lvbgpu_chains_commit_edits.  The caller holds AllParked and has resolved the pending follow.
+int commit_rewrites(lvbgpu_ctx *ctx, int32_t k, const int32_t *chains, std::vector<std::vector<Edit>> &edits, const int32_t *new_roots,
+                    uint64_t seen, const char *what, bool rebuild_tables)
+{
     Packed pk;
     Program prog;
     for (int32_t j = 0; j < k; j++)
     {
-        const lvbgpu_chain_root &rq = reqs[j];
-        if (rq.chain < 0 || rq.chain >= ctx->nchains || ((seen >> rq.chain) & 1u))
-            return ctx->fail(LVBGPU_E_ARG, "re-root " + std::to_string(j) + ": chain out of range or listed twice");
-        seen |= 1ull << rq.chain;
-        ChainSlot &cs = ctx->parked[(size_t)rq.chain];
-        if (!cs.have_tree)
-            return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-        const Topology &t = cs.topo;
-        if (rq.new_root < 0 || rq.new_root >= t.n || rq.new_root == t.root)
-            return ctx->fail(LVBGPU_E_TOPOLOGY, "re-root " + std::to_string(j) + ": the new root must be another leaf");
-        // every node on the way up takes (its old parent, its old sister); the old root becomes an ordinary leaf
+        ChainSlot &cs = ctx->parked[(size_t)chains[j]];
         std::vector<Edit> &ed = edits[(size_t)j];
-        for (int32_t c = rq.new_root; c != t.root; c = t.parent[c])
-        {
-            const int32_t p = t.parent[c];
-            ed.push_back({c, p, t.left[p] == c ? t.right[p] : t.left[p]});
-        }
-        ed.push_back({t.root, UNSET, UNSET});
         const size_t tok0 = prog.toks.size(), dst0 = prog.dsts.size();
         std::string why;
         prog.max_stack = 0;
-        if (!ctx->pb.build_candidate(cs.topo, ed.data(), (int32_t)ed.size(), rq.new_root, prog, &why))
-            return ctx->fail(LVBGPU_E_TOPOLOGY, "re-root " + std::to_string(j) + ": " + why);
-        pk.add(prog, tok0, dst0, 0, (uint32_t)rq.chain << CAND_CHAIN_SHIFT);
+        if (!ctx->pb.build_candidate(cs.topo, ed.data(), (int32_t)ed.size(), new_roots[j], prog, &why))
+            return ctx->fail(LVBGPU_E_TOPOLOGY, std::string(what) + " " + std::to_string(j) + ": " + why);
+        pk.add(prog, tok0, dst0, 0, (uint32_t)chains[j] << CAND_CHAIN_SHIFT);
         pk.max_stack = std::max(pk.max_stack, prog.max_stack);
     }
     int rc = check_depth(ctx, pk.max_stack);
@@ -1228,15 +1207,17 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     size_t off = 0;
     for (int32_t j = 0; j < k; j++)
     {
-        ext[j] = {reqs[j].chain, reqs[j].new_root, (int32_t)off, (int32_t)edits[(size_t)j].size()};
+        ext[j] = {chains[j], new_roots[j] >= 0 ? new_roots[j] : ctx->parked[(size_t)chains[j]].topo.root, (int32_t)off, (int32_t)edits[(size_t)j].size()};
         memcpy(all + off, edits[(size_t)j].data(), edits[(size_t)j].size() * sizeof(lvbgpu_edit_dev));
         off += edits[(size_t)j].size();
     }
     static_assert(sizeof(Edit) == sizeof(lvbgpu_edit_dev), "edit layout");
     // the tables follow on the device when they describe the trees as they are now
-    bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
+    // (rebuild_tables false: the caller draws on the host for now - the tables go stale and are made again, on the host,
+    // when a device draw next needs them)
+    bool tables_on_device = rebuild_tables && (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
     for (int32_t j = 0; j < k && tables_on_device; j++)
-        tables_on_device = ctx->parked[(size_t)reqs[j].chain].d_topo_version == ctx->parked[(size_t)reqs[j].chain].topo_version;
+        tables_on_device = ctx->parked[(size_t)chains[j]].d_topo_version == ctx->parked[(size_t)chains[j]].topo_version;
     if (tables_on_device)
     {
         RebuildArgs ra{};
@@ -1287,9 +1268,9 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     // the host's topologies follow
     for (int32_t j = 0; j < k; j++)
     {
-        ChainSlot &cs = ctx->parked[(size_t)reqs[j].chain];
+        ChainSlot &cs = ctx->parked[(size_t)chains[j]];
         std::string why;
-        if (!ctx->pb.apply_edits(cs.topo, edits[(size_t)j].data(), (int32_t)edits[(size_t)j].size(), reqs[j].new_root, &why))
+        if (!ctx->pb.apply_edits(cs.topo, edits[(size_t)j].data(), (int32_t)edits[(size_t)j].size(), new_roots[j], &why))
         {
             cs.have_tree = false;
             return ctx->fail(LVBGPU_E_TOPOLOGY, why);
@@ -1301,6 +1282,82 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     }
     forget_named_candidates(ctx, seen);
     return LVBGPU_OK;
+}
+} // namespace lvbgpu_detail
+
+extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_chain_root *reqs)
+{
+    if (!ctx || k < 1 || k > MAX_CHAINS || !reqs)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    AllParked guard(ctx);
+    {
+        const int rf = resolve_follow(ctx); // the programs below are built from the chains' topologies as they are NOW
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
+    uint64_t seen = 0;
+    std::vector<std::vector<Edit>> edits((size_t)k);
+    int32_t chains[MAX_CHAINS], new_roots[MAX_CHAINS];
+    for (int32_t j = 0; j < k; j++)
+    {
+        const lvbgpu_chain_root &rq = reqs[j];
+        if (rq.chain < 0 || rq.chain >= ctx->nchains || ((seen >> rq.chain) & 1u))
+            return ctx->fail(LVBGPU_E_ARG, "re-root " + std::to_string(j) + ": chain out of range or listed twice");
+        seen |= 1ull << rq.chain;
+        ChainSlot &cs = ctx->parked[(size_t)rq.chain];
+        if (!cs.have_tree)
+            return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+        const Topology &t = cs.topo;
+        if (rq.new_root < 0 || rq.new_root >= t.n || rq.new_root == t.root)
+            return ctx->fail(LVBGPU_E_TOPOLOGY, "re-root " + std::to_string(j) + ": the new root must be another leaf");
+        // every node on the way up takes (its old parent, its old sister); the old root becomes an ordinary leaf
+        std::vector<Edit> &ed = edits[(size_t)j];
+        for (int32_t c = rq.new_root; c != t.root; c = t.parent[c])
+        {
+            const int32_t p = t.parent[c];
+            ed.push_back({c, p, t.left[p] == c ? t.right[p] : t.left[p]});
+        }
+        ed.push_back({t.root, UNSET, UNSET});
+        chains[j] = rq.chain;
+        new_roots[j] = rq.new_root;
+    }
+    return commit_rewrites(ctx, k, chains, edits, new_roots, seen, "re-root", true);
+}
+
+// Accept host-made candidates of several chains at once: chain chains[j]'s resident tree takes the rewrites
+// edits[edit_offsets[j] .. edit_offsets[j + 1]) - any set of child-pair rewrites that gives a tree, e.g. the cumulative
+// rewrites of a run of accepted moves - in ONE commit walk for all of them; what lvbgpu_select_chain + lvbgpu_commit(.., NULL)
+// does chain by chain.  Asynchronous: the caller scored the candidates and knows the lengths.
+extern "C" int lvbgpu_chains_commit_edits(lvbgpu_ctx *ctx, int32_t k, const int32_t *chains, const int32_t *edit_offsets,
+                                          const lvbgpu_edit *edits_in)
+{
+    if (!ctx || k < 1 || k > MAX_CHAINS || !chains || !edit_offsets || !edits_in)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    AllParked guard(ctx);
+    {
+        const int rf = resolve_follow(ctx);
+        if (rf != LVBGPU_OK)
+            return rf;
+    }
+    uint64_t seen = 0;
+    std::vector<std::vector<Edit>> edits((size_t)k);
+    int32_t new_roots[MAX_CHAINS];
+    for (int32_t j = 0; j < k; j++)
+    {
+        if (chains[j] < 0 || chains[j] >= ctx->nchains || ((seen >> chains[j]) & 1u))
+            return ctx->fail(LVBGPU_E_ARG, "commit " + std::to_string(j) + ": chain out of range or listed twice");
+        seen |= 1ull << chains[j];
+        if (!ctx->parked[(size_t)chains[j]].have_tree)
+            return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
+        if (edit_offsets[j + 1] <= edit_offsets[j])
+            return ctx->fail(LVBGPU_E_ARG, "commit " + std::to_string(j) + ": no rewrites (or edit_offsets not monotone)");
+        const Edit *e = reinterpret_cast<const Edit *>(edits_in) + edit_offsets[j];
+        edits[(size_t)j].assign(e, e + (edit_offsets[j + 1] - edit_offsets[j]));
+        new_roots[j] = -1;
+    }
+    return commit_rewrites(ctx, k, chains, edits, new_roots, seen, "commit", false);
 }
 
 extern "C" int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits)

@@ -634,6 +634,63 @@ int lvbgpu_chains_step_edits(lvbgpu_ctx *c, int32_t i, lvbgpu_edit *e, int32_t c
     return lvbgpu_chains_picked_edits(c, STEP.map[i], e, cap, n);
 }
 
+int lvbgpu_parallel_for(lvbgpu_ctx *c, int32_t n, lvbgpu_task_fn fn, void *arg)
+{
+    if (!c || n < 0 || !fn)
+        return LVBGPU_E_ARG;
+    for (int32_t i = 0; i < n; i++)
+        fn(i, arg);
+    return LVBGPU_OK;
+}
+
+/* host-made candidates of several chains: scored against each candidate's own chain, one accepted per listed chain */
+int lvbgpu_chains_score_edits(lvbgpu_ctx *c, int32_t B, const int32_t *chain_of, const int32_t *off, const lvbgpu_edit *edits,
+                              int64_t *lengths_out)
+{
+    adopt(c);
+    if (G.owner != c || B < 1 || !chain_of || !off || !lengths_out)
+        return LVBGPU_E_ARG;
+    store_selected(c);
+    const long keep_root = c->root;
+    int rc = LVBGPU_OK;
+    for (int32_t b = 0; b < B && rc == LVBGPU_OK; b++)
+    {
+        if (chain_of[b] < 0 || chain_of[b] >= G.R || !G.ch[chain_of[b]].have_tree)
+        {
+            rc = chain_of[b] < 0 || chain_of[b] >= G.R ? LVBGPU_E_ARG : LVBGPU_E_STATE;
+            break;
+        }
+        dbl_chain *h = &G.ch[chain_of[b]];
+        long root = h->root;
+        c->root = h->root;
+        lvbo_treecopy(c->cand, h->cur, c->nb, c->nwords);
+        lengths_out[b] = apply_and_score(c, c->cand, off[b + 1] - off[b], edits + off[b], &root);
+    }
+    c->root = keep_root;
+    load_selected(c);
+    return rc;
+}
+
+int lvbgpu_chains_commit_edits(lvbgpu_ctx *c, int32_t k, const int32_t *chains, const int32_t *off, const lvbgpu_edit *edits)
+{
+    adopt(c);
+    if (G.owner != c || k < 1 || k > G.R || !chains || !off || !edits)
+        return LVBGPU_E_ARG;
+    store_selected(c);
+    int rc = LVBGPU_OK;
+    for (int32_t j = 0; j < k && rc == LVBGPU_OK; j++)
+    {
+        if (chains[j] < 0 || chains[j] >= G.R || off[j + 1] <= off[j])
+        {
+            rc = LVBGPU_E_ARG;
+            break;
+        }
+        rc = commit_on_chain(c, &G.ch[chains[j]], off[j + 1] - off[j], edits + off[j], -1, -1);
+    }
+    load_selected(c);
+    return rc;
+}
+
 int lvbgpu_chains_reroot(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_root *r)
 {
     adopt(c);

@@ -160,3 +160,24 @@ def test_runs_of_acceptances_in_one_step_leave_the_trajectory_alone(double, algo
     assert one[0]["consumed"] == 2500 and one[0]["accepted"] > 50 and one[0]["reroots"] >= 2
     dev, _, _ = run_chains(double, rows, min_len, n, [11], 2500, algorithm, run_levels=0)
     assert dev[0]["consumed"] == 2500                                            # the device-drawn law: another valid run
+
+
+def test_runs_among_other_chains_are_the_runs_of_the_chain_alone(double):
+    """With run_levels > 0 the hot chains of a step share ONE scoring walk (lvbgpu_chains_score_edits) and ONE commit
+    walk (lvbgpu_chains_commit_edits) while the others go through the device step: a chain's trajectory is still its
+    own - the same with five chains beside it as alone, and the same for every run length."""
+    from lvb_amd import host
+    lib = double[0]
+    n, m = 24, 600
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 91), lib)
+    seeds = [3, 4, 5, 6, 7]
+    keys = tuple(k for k in KEYS if k not in ("device_steps", "scored"))
+    many, many_final, log = run_chains(double, rows, min_len, n, seeds, 1500, 0, run_levels=3)
+    for pick in (1, 4):
+        for levels in (1, 3):
+            one, one_final, _ = run_chains(double, rows, min_len, n, [seeds[pick]], 1500, 0, run_levels=levels)
+            assert {k: one[0][k] for k in keys} == {k: many[pick][k] for k in keys}, (pick, levels)
+            assert all(np.array_equal(a, b) for a, b in zip(one_final[0][:2], many_final[pick][:2]))
+            assert one_final[0][2:] == many_final[pick][2:]
+    assert all(r["consumed"] == 1500 for r in many)
+    assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)

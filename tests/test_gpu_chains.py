@@ -219,6 +219,77 @@ def test_runs_of_acceptances_in_one_step_leave_the_trajectory_alone(mods, algori
     fresh.close()
 
 
+def test_host_made_candidates_of_several_chains_in_one_walk(mods):
+    """lvbgpu_chains_score_edits / lvbgpu_chains_commit_edits against lvbgpu_select_chain + lvbgpu_score_batch /
+    lvbgpu_commit chain by chain: single moves and cumulative rewrites of runs of moves, chains in any mix, the
+    generator's tables following on the device (the next device draw equals the one a fresh upload gives)."""
+    api, host = mods
+    n, m, R = 40, 2600, 5
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 17))
+    both = [api.FitchContext(text_rows=rows) for _ in range(2)]
+    trees = [host.HostTree(n, seed=300 + c) for c in range(R)]
+    for ctx in both:
+        ctx.set_chains(R)
+        for c, t in enumerate(trees):
+            ctx.select_chain(c)
+            t.upload(ctx)
+    one_by_one, together = both
+    rng = np.random.default_rng(3)
+    for round_ in range(6):
+        chains, cands = [], []
+        for c in rng.permutation(R)[: int(rng.integers(1, R + 1))]:
+            c = int(c)
+            for _ in range(int(rng.integers(1, 40))):
+                # a run of 1 .. 3 moves, given as its cumulative rewrites of the chain's tree
+                copy = host.HostTree(left=trees[c].arrays()[1], right=trees[c].arrays()[2], root=trees[c].root, seed=int(rng.integers(1, 1 << 30)))
+                for _ in range(int(rng.integers(1, 4))):
+                    copy.apply(copy.propose(int(rng.integers(0, 3))))
+                _, l0, r0 = trees[c].arrays()
+                _, l1, r1 = copy.arrays()
+                e = api.edits_between(l0, r0, l1, r1)
+                copy.close()
+                if len(e) == 0:                                       # (the run undid itself)
+                    continue
+                cands.append(e)
+                chains.append(c)
+        order = np.argsort(np.array(chains), kind="stable")          # one chain's candidates adjacent
+        chains = [chains[i] for i in order]
+        cands = [cands[i] for i in order]
+        got = together.chains_score_edits(chains, cands)
+        want = np.zeros(len(cands), dtype=np.int64)
+        for c in set(chains):
+            idx = [i for i, x in enumerate(chains) if x == c]
+            one_by_one.select_chain(c)
+            want[idx] = one_by_one.score_batch([cands[i] for i in idx])
+        assert np.array_equal(got, want), round_
+        # accept the best candidate of every chain that has one
+        pick = {}
+        for i, c in enumerate(chains):
+            if c not in pick or got[i] < got[pick[c]]:
+                pick[c] = i
+        cs = sorted(pick)
+        together.chains_commit_edits(cs, [cands[pick[c]] for c in cs])
+        for c in cs:
+            one_by_one.select_chain(c)
+            assert one_by_one.commit(cands[pick[c]]) == got[pick[c]]
+            trees[c].apply(cands[pick[c]])
+            together.select_chain(c)
+            assert together.current_length() == got[pick[c]]
+            _, l, r, root = together.topology()
+            _, hl, hr = trees[c].arrays()
+            assert np.array_equal(l, hl) and np.array_equal(r, hr) and root == trees[c].root
+        # the device's own draws from the committed trees agree on both contexts (tables rebuilt on the device / by the host)
+        draws = [(c, 33, -1, 70 + round_) for c in range(R)]
+        a, b = together.chains_propose_score(draws), one_by_one.chains_propose_score(draws)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(api.LvbGpuError):
+        together.chains_commit_edits([0, 0], [cands[0], cands[0]])                    # a chain listed twice
+    with pytest.raises(api.LvbGpuError):
+        together.chains_score_edits([R], [cands[0]])                                 # no such chain
+    for ctx in both:
+        ctx.close()
+
+
 def test_rerooting_several_chains_at_once_equals_rerooting_them_one_by_one(mods):
     """lvbgpu_chains_reroot: one commit walk for all, tables rebuilt on the device; same state as a commit of the
     re-root rewrites chain by chain, and the neighbourhoods drawn afterwards are the same."""
