@@ -815,6 +815,7 @@ def rank_main(args) -> None:
         else:
             res, log = host.anneal_chains(actx, atrees, [params_for(c) for c in range(R)])
         anneal_log = list(log)
+        single_log = []
         keep = log[:: max(1, len(log) // 12)] + log[-1:]
         secs = max(r["seconds"] for r in res)
         tot = lambda k: sum(r[k] for r in res)
@@ -843,13 +844,14 @@ def rank_main(args) -> None:
             p1 = params_for(0)
             p1.seed = args.seed * 7919 + 1000 * rank + 1
             p1.run_levels = args.single_chain_levels   # a lone chain: runs of acceptances in one step while it is hot
-            one, _ = host.anneal_chains(actx, [fresh], [p1])
+            one, single_log = host.anneal_chains(actx, [fresh], [p1])
             fresh.close()
             out["anneal"]["single_chain"] = {
                 "seconds": round(one[0]["seconds"], 3), "best_length": one[0]["best_length"], "scored": one[0]["scored"],
                 "consumed": one[0]["consumed"], "device_steps": one[0]["device_steps"],
                 "scored_per_s": round(one[0]["scored"] / one[0]["seconds"]), "frozen": one[0]["frozen"],
                 "run_levels": args.single_chain_levels,
+                "best_length_vs_wallclock": [[round(t, 3), b] for t, b in (single_log[:: max(1, len(single_log) // 8)] + single_log[-1:])],
                 "what": "one chain alone in its context; run_levels > 0: while it accepts most of what it sees its candidates are "
                         "cumulative (host-drawn, up to that many accepted moves per scoring walk: lvbhost_anneal_params::run_levels)"}
         for t in atrees:
@@ -865,6 +867,10 @@ def rank_main(args) -> None:
 
     if extras and not args.no_cpu_baseline and args.dist == "tree" and "anneal" in out:
         out["anneal"]["reference_cpu"] = cpu_reference_anneal(rows, min(2.5 * args.cpu_seconds, 30.0), args.seed, anneal_log)
+        ref = out["anneal"]["reference_cpu"]
+        if ref and "length" in ref and single_log:   # ... and when the chain that ran alone passed that length
+            hit = next((t for t, b in single_log if b <= ref["length"]), None)
+            ref["gpu_single_chain_seconds_to_same_length"] = None if hit is None else round(hit, 4)
 
     if extras and not args.no_cpu_baseline and args.dist == "tree" and "mixed_walk" in out:
         out["mixed_walk"]["cpu_baseline"] = cpu_reference_on_tree(rows, kind, args.cpu_seconds, mixed_arrays, mixed_len,
