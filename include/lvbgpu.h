@@ -300,9 +300,13 @@ int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds);
 /* test hook: keeps the context's stream busy for about `ms` milliseconds (1 .. 2000) with a kernel that only watches
  * the clock, so that what is enqueued behind it cannot complete before then */
 int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms);
-/* test hook: scoring walks this context launched two candidates per wave so far (LVBGPU_PAIR=n when the context was
- * created: batches of at least n candidates; fitch_walk_pair) */
-int lvbgpu_debug_paired_walks(lvbgpu_ctx *ctx, int64_t *launches);
+/* test hook: counters of what results cannot show (they are the same either way): scoring walks launched two
+ * candidates per wave (LVBGPU_PAIR=n when the context was created; fitch_walk_pair);
+ * lvbgpu_chains_commit_edits calls that walked the SCORED programs of the last lvbgpu_chains_score_edits call
+ * instead of building the accepted candidates' programs again */
+#define LVBGPU_COUNT_PAIRED_WALKS 0
+#define LVBGPU_COUNT_COMMITS_REUSING_PROGRAMS 1
+int lvbgpu_debug_count(lvbgpu_ctx *ctx, int32_t what, int64_t *count);
 
 /* per-kernel timing for the roofline line: while enabled (every > 0), every `every`-th scoring walk the
  * library launches (batch launches, lvbgpu_score_batch, lvbgpu_propose_score*, lvbgpu_score_moves) is

@@ -102,7 +102,7 @@ SIGNATURES = {
     "lvbgpu_stream": (C.c_void_p, [C.c_void_p]),
     "lvbgpu_set_wait_limit": (C.c_int, [C.c_void_p, C.c_double]),
     "lvbgpu_debug_stall": (C.c_int, [C.c_void_p, C.c_int32]),
-    "lvbgpu_debug_paired_walks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "lvbgpu_debug_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "lvbgpu_comm_available": (C.c_int, []),
     "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lvbgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -222,11 +222,18 @@ class FitchContext:
     def last_error(self) -> str:
         return (self.lib.lvbgpu_last_error(self.h) or b"").decode()
 
+    def debug_count(self, what: int) -> int:
+        out = C.c_int64(0)
+        self._chk(self.lib.lvbgpu_debug_count(self.h, int(what), C.byref(out)))
+        return int(out.value)
+
     def paired_walks(self) -> int:
         """Scoring walks launched two candidates per wave so far (LVBGPU_PAIR)."""
-        out = C.c_int64(0)
-        self._chk(self.lib.lvbgpu_debug_paired_walks(self.h, C.byref(out)))
-        return int(out.value)
+        return self.debug_count(0)
+
+    def commits_reusing_programs(self) -> int:
+        """chains_commit_edits calls that walked the scored programs of the last chains_score_edits call."""
+        return self.debug_count(1)
 
     def set_wait_limit(self, seconds: float) -> None:
         self._chk(self.lib.lvbgpu_set_wait_limit(self.h, float(seconds)))

@@ -356,6 +356,7 @@ int build_into(lvbgpu_ctx *ctx, lvbgpu_batch *bt, int32_t B, const BuildJob &job
     bt->topo_version = ctx->topo_version;
     bt->chain = ctx->chain;
     bt->spans_chains = job.chain_of != nullptr;
+    bt->build_gen++;
     bt->stats.candidates = B;
     bt->stats.combines = (int64_t)ndst;
     bt->stats.rows_read = (int64_t)ntok;
@@ -599,6 +600,14 @@ namespace lvbgpu_detail
 {
 void park_chain(lvbgpu_ctx *ctx);
 void unpark_chain(lvbgpu_ctx *ctx, int32_t c);
+uint64_t edits_hash(const lvbgpu_edit *e, int32_t n)
+{
+    uint64_t h = 0xCBF29CE484222325ull; // FNV-1a over the rewrites as given
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(e);
+    for (size_t i = 0; i < (size_t)n * sizeof(lvbgpu_edit); i++)
+        h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
 } // namespace lvbgpu_detail
 
 // fn(i, arg) for i in [0, n) on the context's host threads (the pool that builds programs), the caller among them;
@@ -664,6 +673,8 @@ extern "C" int lvbgpu_chains_score_edits(lvbgpu_ctx *ctx, int32_t B, const int32
     job.par_min = 32;
     for (BuildWorker &w : ctx->workers)
         w.topo_version = ~0ull; // (versions are unique across chains, but a worker's copy may be of a chain re-uploaded since)
+    ctx->scored.clear();
+    ctx->scored_batch = nullptr;
     int rc = build_into(ctx, b, B, job);
     if (rc == LVBGPU_OK)
         rc = lvbgpu_batch_launch(ctx, b);
@@ -679,6 +690,20 @@ extern "C" int lvbgpu_chains_score_edits(lvbgpu_ctx *ctx, int32_t B, const int32
         }
         else
             (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    // what was scored, for the commit that follows (programs read in place from pinned memory are not kept: the next
+    // build overwrites them while a commit walk might still read)
+    if (!b->in_place && b->slot_of.empty())
+    {
+        ctx->scored.resize((size_t)B);
+        for (int32_t i = 0; i < B; i++)
+        {
+            const int32_t n = edit_offsets[i + 1] - edit_offsets[i];
+            ctx->scored[(size_t)i] = {chain_of[i], n, ctx->parked[(size_t)chain_of[i]].topo_version, edits_hash(edits + edit_offsets[i], n)};
+        }
+        ctx->scored_batch = b;
+        ctx->scored_gen = b->build_gen;
     }
     return rc;
 }

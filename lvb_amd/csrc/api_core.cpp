@@ -928,12 +928,17 @@ extern "C" int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds)
 
 // test hook for the wait limit: keeps the context's stream busy for about `ms` milliseconds (bounded: <= 2000) with a
 // kernel that does nothing but watch the clock, so that a step enqueued behind it cannot complete before then
-// test hook: how many scoring walks this context has launched two candidates per wave (LVBGPU_PAIR)
-extern "C" int lvbgpu_debug_paired_walks(lvbgpu_ctx *ctx, int64_t *launches)
+// test hook: counters of things a test cannot see from results (results are the same either way)
+extern "C" int lvbgpu_debug_count(lvbgpu_ctx *ctx, int32_t what, int64_t *count)
 {
-    if (!ctx || !launches)
+    if (!ctx || !count)
         return LVBGPU_E_ARG;
-    *launches = ctx->paired_walks;
+    switch (what)
+    {
+    case LVBGPU_COUNT_PAIRED_WALKS: *count = ctx->paired_walks; break;
+    case LVBGPU_COUNT_COMMITS_REUSING_PROGRAMS: *count = ctx->commits_reusing_programs; break;
+    default: return LVBGPU_E_ARG;
+    }
     return LVBGPU_OK;
 }
 

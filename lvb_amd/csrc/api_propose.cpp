@@ -1357,7 +1357,73 @@ extern "C" int lvbgpu_chains_commit_edits(lvbgpu_ctx *ctx, int32_t k, const int3
         edits[(size_t)j].assign(e, e + (edit_offsets[j + 1] - edit_offsets[j]));
         new_roots[j] = -1;
     }
-    return commit_rewrites(ctx, k, chains, edits, new_roots, seen, "commit", false);
+    // Every one of them a candidate of the last lvbgpu_chains_score_edits call, its chain's tree unchanged since?  Then
+    // their programs lie in that batch: one commit walk over them, picked by position (as lvbgpu_chains_commit does with
+    // device-built batches) - nothing is built and nothing uploaded.  (k commit programs built one after the other were
+    // most of a host-drawn step of many chains.)
+    uint32_t where[MAX_CHAINS];
+    lvbgpu_batch *sb = ctx->scored_batch;
+    bool reuse = sb && sb == ctx->step_batch[0] && sb->build_gen == ctx->scored_gen && !sb->in_place;
+    for (int32_t j = 0; j < k && reuse; j++)
+    {
+        const int32_t n = edit_offsets[j + 1] - edit_offsets[j];
+        const uint64_t h = edits_hash(edits_in + edit_offsets[j], n);
+        const uint64_t v = ctx->parked[(size_t)chains[j]].topo_version;
+        bool found = false;
+        for (size_t i = 0; i < ctx->scored.size() && !found; i++)
+        {
+            const lvbgpu_ctx::ScoredEdit &se = ctx->scored[i];
+            if (se.chain == chains[j] && se.n_edits == n && se.hash == h && se.version == v)
+            {
+                where[j] = (uint32_t)i;
+                found = true;
+            }
+        }
+        reuse = found;
+    }
+    if (!reuse)
+        return commit_rewrites(ctx, k, chains, edits, new_roots, seen, "commit", false);
+    {
+        const size_t old_done = ctx->d_done.cap;
+        HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
+        if (ctx->d_done.cap != old_done) // once per context
+        {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
+    if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
+    {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
+        ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
+    }
+    HIPCHK(ctx, ctx->d_len.reserve(8));
+    WalkArgs a = resident_args(ctx, sb->d_prog.p, sb->off_toks, sb->off_dsts, ctx->d_len.p, (uint32_t)k, (int32_t)sb->stats.max_stack);
+    a.use_pick = 1;
+    memcpy(a.pick_idx, where, (size_t)k * 4);
+    for (int32_t j = 0; j < k; j++)
+        a.pick_chain[j] = (uint8_t)chains[j];
+    a.s_all_out = (unsigned long long *)ctx->d_scalars;
+    a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
+    a.tmp_stride = (uint32_t)(ctx->nb + 1);
+    a.done_count = (uint32_t *)ctx->d_done.p;
+    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+    for (int32_t j = 0; j < k; j++) // the host's topologies follow; the generator's tables go stale
+    {
+        ChainSlot &cs = ctx->parked[(size_t)chains[j]];
+        std::string why;
+        if (!ctx->pb.apply_edits(cs.topo, edits[(size_t)j].data(), (int32_t)edits[(size_t)j].size(), -1, &why))
+        {
+            cs.have_tree = false;
+            return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+        }
+        cs.topo_version = ++ctx->version_counter;
+        cs.cur_length_stale = true;
+    }
+    forget_named_candidates(ctx, seen);
+    ctx->commits_reusing_programs++;
+    return LVBGPU_OK;
 }
 
 extern "C" int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits)

@@ -299,6 +299,17 @@ struct lvbgpu_ctx
     uint32_t step_seq = 0;
     bool direct_steps = true; // env LVBGPU_DIRECT_STEPS=0 turns them off (A/B measurements)
     bool lpt_order = true;    // env LVBGPU_LPT=0: keep big batches in the caller's order on the device
+    // the candidates of the last lvbgpu_chains_score_edits call: lvbgpu_chains_commit_edits walks an accepted one's SCORED
+    // program (it lies in the batch) instead of building it again
+    struct ScoredEdit
+    {
+        int32_t chain, n_edits;
+        uint64_t version, hash;
+    };
+    std::vector<ScoredEdit> scored;
+    lvbgpu_batch *scored_batch = nullptr;
+    uint64_t scored_gen = 0;
+    int64_t commits_reusing_programs = 0;
     int64_t paired_walks = 0; // scoring walks launched two candidates per wave (lvbgpu_debug_paired_walks)
     int pair_min = 0;         // env LVBGPU_PAIR=n: batches of n candidates and more are walked two candidates per wave (0: never)
     DevBuf d_tmp_changes;     // fused commits: per-combine accumulators, zero between launches
@@ -388,6 +399,7 @@ struct lvbgpu_batch
     uint32_t npick_chains = 0;
     uint8_t pick_chain[MAX_CHAINS] = {};
     bool spans_chains = false; // device-built batch over several chains: every program names its own chain
+    uint64_t build_gen = 0;    // counts the builds into this batch (lvbgpu_chains_commit_edits re-uses scored programs)
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)
     int32_t chain = 0;         // ... and which chain's tree that is
     std::vector<int32_t> slot_of; // big batches: candidate b sits at position slot_of[b] (longest program first)
@@ -459,6 +471,7 @@ int walk_timing_drain(lvbgpu_ctx *ctx);
 // api_propose.cpp: finish the host side of the last lvbgpu_chains_commit (Follow).  resolve_follow: every chain parked
 // (inside a multi-chain call); settle: from anywhere - every entry point that reads a chain's host topology calls it
 int resolve_follow(lvbgpu_ctx *ctx);
+uint64_t edits_hash(const lvbgpu_edit *e, int32_t n);
 int settle(lvbgpu_ctx *ctx);
 } // namespace lvbgpu_detail
 

@@ -224,7 +224,7 @@ def test_host_made_candidates_of_several_chains_in_one_walk(mods):
     lvbgpu_commit chain by chain: single moves and cumulative rewrites of runs of moves, chains in any mix, the
     generator's tables following on the device (the next device draw equals the one a fresh upload gives)."""
     api, host = mods
-    n, m, R = 40, 2600, 5
+    n, m, R = 40, 26000, 5                                         # 13 tiles: most rounds are too large for a direct step
     rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 17))
     both = [api.FitchContext(text_rows=rows) for _ in range(2)]
     trees = [host.HostTree(n, seed=300 + c) for c in range(R)]
@@ -235,6 +235,7 @@ def test_host_made_candidates_of_several_chains_in_one_walk(mods):
             t.upload(ctx)
     one_by_one, together = both
     rng = np.random.default_rng(3)
+    reused = 0
     for round_ in range(6):
         chains, cands = [], []
         for c in rng.permutation(R)[: int(rng.integers(1, R + 1))]:
@@ -268,7 +269,11 @@ def test_host_made_candidates_of_several_chains_in_one_walk(mods):
             if c not in pick or got[i] < got[pick[c]]:
                 pick[c] = i
         cs = sorted(pick)
+        before = together.commits_reusing_programs()
         together.chains_commit_edits(cs, [cands[pick[c]] for c in cs])
+        # (scored a moment ago, trees unchanged: the commit walks the scored programs - unless the batch was small enough
+        # to be read in place from pinned memory, which the next build overwrites)
+        reused += together.commits_reusing_programs() - before
         for c in cs:
             one_by_one.select_chain(c)
             assert one_by_one.commit(cands[pick[c]]) == got[pick[c]]
@@ -282,6 +287,14 @@ def test_host_made_candidates_of_several_chains_in_one_walk(mods):
         draws = [(c, 33, -1, 70 + round_) for c in range(R)]
         a, b = together.chains_propose_score(draws), one_by_one.chains_propose_score(draws)
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert reused >= 3
+    # a commit of rewrites that were NOT scored builds its programs (same result)
+    e = trees[0].propose(1)
+    together.chains_commit_edits([0], [e])
+    one_by_one.select_chain(0)
+    want = one_by_one.commit(e)
+    together.select_chain(0)
+    assert together.current_length() == want
     with pytest.raises(api.LvbGpuError):
         together.chains_commit_edits([0, 0], [cands[0], cands[0]])                    # a chain listed twice
     with pytest.raises(api.LvbGpuError):
