@@ -21,6 +21,7 @@ extern "C" void lvbgpu_batch_free(lvbgpu_batch *b)
     b->d_len.release();
     b->h_len.release();
     b->h_stage.release();
+    b->h_wflag.release();
     delete b;
 }
 
@@ -436,6 +437,28 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
             memcpy(a.pick_chain, b->pick_chain, sizeof a.pick_chain);
         }
     }
+    b->own_watch = false;
+    if (!b->direct && !b->watch_flag && b->recycled && !b->full_mode)
+    {
+        static const bool allow_watcher = [] {
+            const char *e = getenv("LVBGPU_WATCHER");
+            return !(e && e[0] == '0');
+        }();
+        if (allow_watcher && a.ngroups <= WATCH_MAX_GROUPS && b->B <= 8192)
+        {
+            if (!b->h_wflag.p)
+            {
+                HIPCHK(ctx, b->h_wflag.reserve(WATCH_WAVES * 4));
+                memset(b->h_wflag.p, 0, WATCH_WAVES * 4);
+            }
+            b->own_seq = ++b->own_seq == 0xFFFFFFFFu ? 1u : b->own_seq; // (0xFFFFFFFF is the watcher's "gave up")
+            a.host_len = (unsigned long long *)b->h_len.p;
+            a.host_flag = (uint32_t *)b->h_wflag.p;
+            a.step_seq = b->own_seq;
+            a.watcher = 1;
+            b->own_watch = true;
+        }
+    }
     if (b->npairs && !b->direct)
     {
         a.pairs = (const uint32_t *)b->d_pairs.p;
@@ -495,6 +518,31 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
     {
         HIPCHK(ctx, wait_for_direct_step(ctx));
         b->len_zeroed = true; // by the walk's last wave
+    }
+    else if (b->own_watch)
+    {
+        // the walk's watcher waves store the lengths into h_len and set their words: nothing but memory is polled
+        const uint32_t *flag = (const uint32_t *)b->h_wflag.p;
+        const WaitClock clock(ctx->wait_limit_s);
+        uint32_t seen = b->own_seq, w = 0;
+        for (uint32_t spins = 1; w < WATCH_WAVES; spins++)
+        {
+            seen = __atomic_load_n(flag + w, __ATOMIC_ACQUIRE);
+            if (seen == b->own_seq)
+            {
+                w++;
+                continue;
+            }
+            if (seen == 0xFFFFFFFFu)
+                break;
+            if ((spins & 4095u) == 0 && clock.expired())
+            {
+                ctx->wait_gave_up = true;
+                return ctx->fail_wait("lvbgpu_batch_lengths: the walk's watcher waves", clock.waited());
+            }
+        }
+        if (seen != b->own_seq)
+            return ctx->fail(LVBGPU_E_STATE, "the walk's watcher did not hand the lengths over (flag " + std::to_string(seen) + ")");
     }
     else
     {

@@ -393,6 +393,11 @@ struct lvbgpu_batch
     // to watch_seq (pinned; null: no watcher, the caller copies the lengths back)
     uint32_t *watch_flag = nullptr;
     uint32_t watch_seq = 0;
+    // host-built step batches (recycled, too large for a direct step): watcher waves of their own, so that the lengths need
+    // no read-back copy and no stream synchronisation behind the walk
+    PinBuf h_wflag;
+    uint32_t own_seq = 0;
+    bool own_watch = false;
     // ... and, for a step decided on the device, apply these rules and leave the picks (kernels.hpp WalkArgs::rules)
     const DecideRule *rules = nullptr;
     uint32_t *d_pick = nullptr, *host_pick = nullptr, *watch_done = nullptr;
