@@ -178,6 +178,7 @@ typedef struct
      * scorer does. */
     double seconds_busy;
     int64_t scored_busy;
+    int64_t host_steps;         /* of device_steps: host-drawn steps with cumulative candidates (run_levels > 0) */
 } lvbhost_anneal_result;
 
 void lvbhost_anneal_defaults(lvbhost_anneal_params *p);

@@ -586,6 +586,7 @@ struct ChainRun
         const int L = hs_L, K = hs_K;
         const uint64_t i0 = hs_i0;
         res->device_steps++;
+        res->host_steps++;
         res->scored += hs_ncand;
         consumed_now = accepted_now = 0;
         int acc = -1; // the candidate the step ends on (its rewrites are the step's commit)

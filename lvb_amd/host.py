@@ -33,7 +33,8 @@ class AnnealResult(C.Structure):
                 ("accepted", C.c_int64), ("topologies", C.c_int64), ("device_steps", C.c_int64), ("reroots", C.c_int64),
                 ("dirty_nodes", C.c_int64), ("temperatures", C.c_int64), ("t_final", C.c_double),
                 ("seconds", C.c_double), ("seconds_device", C.c_double), ("n_log", C.c_int32),
-                ("frozen", C.c_int32), ("seconds_done", C.c_double), ("seconds_busy", C.c_double), ("scored_busy", C.c_int64)]
+                ("frozen", C.c_int32), ("seconds_done", C.c_double), ("seconds_busy", C.c_double), ("scored_busy", C.c_int64),
+                ("host_steps", C.c_int64)]
 
 
 class RefSearchParams(C.Structure):

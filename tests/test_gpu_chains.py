@@ -212,6 +212,9 @@ def test_runs_of_acceptances_in_one_step_leave_the_trajectory_alone(mods, algori
         assert {k: runs[0][k] for k in keys} == {k: one[0][k] for k in keys}, levels
         assert all(np.array_equal(a, b) for a, b in zip(runs_final[0][:2], one_final[0][:2])) and runs_final[0][2:] == one_final[0][2:]
         assert runs[0]["device_steps"] < one[0]["device_steps"]
+        # both kinds of step happened: host-drawn ones while the chain was hot, device-drawn ones before (the starting
+        # temperature) and after (cooled off), so the generator's tables were made again from the host's tree on the way
+        assert 0 < runs[0]["host_steps"] < runs[0]["device_steps"]
     assert one[0]["consumed"] == 6000 and one[0]["accepted"] > 100 and one[0]["reroots"] >= 5
     fresh = api.FitchContext(text_rows=rows)
     l, r, root, _ = one_final[0]
