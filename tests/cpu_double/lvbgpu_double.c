@@ -634,12 +634,52 @@ int lvbgpu_chains_step_edits(lvbgpu_ctx *c, int32_t i, lvbgpu_edit *e, int32_t c
     return lvbgpu_chains_picked_edits(c, STEP.map[i], e, cap, n);
 }
 
+/* on threads, as the library does it (a few short-lived ones here): what the host hands to lvbgpu_parallel_for must be
+ * free of races between the tasks - the ThreadSanitizer tier runs the annealing loop against this */
+#include <pthread.h>
+typedef struct
+{
+    lvbgpu_task_fn fn;
+    void *arg;
+    int32_t first, step, n;
+} dbl_par;
+static void *dbl_par_run(void *p)
+{
+    dbl_par *j = (dbl_par *)p;
+    for (int32_t i = j->first; i < j->n; i += j->step)
+        j->fn(i, j->arg);
+    return NULL;
+}
 int lvbgpu_parallel_for(lvbgpu_ctx *c, int32_t n, lvbgpu_task_fn fn, void *arg)
 {
     if (!c || n < 0 || !fn)
         return LVBGPU_E_ARG;
-    for (int32_t i = 0; i < n; i++)
-        fn(i, arg);
+    enum { T = 3 };
+    if (n < 2)
+    {
+        for (int32_t i = 0; i < n; i++)
+            fn(i, arg);
+        return LVBGPU_OK;
+    }
+    pthread_t th[T];
+    dbl_par job[T];
+    int started[T] = {0};
+    for (int t = 0; t < T; t++)
+    {
+        job[t].fn = fn;
+        job[t].arg = arg;
+        job[t].first = t;
+        job[t].step = T;
+        job[t].n = n;
+        if (t > 0)
+            started[t] = pthread_create(&th[t], NULL, dbl_par_run, &job[t]) == 0;
+    }
+    dbl_par_run(&job[0]);
+    for (int t = 1; t < T; t++)
+        if (started[t])
+            pthread_join(th[t], NULL);
+        else
+            dbl_par_run(&job[t]);
     return LVBGPU_OK;
 }
 

@@ -42,7 +42,7 @@ int main()
             return 2;
     const int64_t min_len = lvbhost_min_tree_length(n, m, ptr.data());
 
-    auto run = [&](int G, std::vector<lvbhost_anneal_result> &res) {
+    auto run = [&](int G, std::vector<lvbhost_anneal_result> &res, int run_levels = 0) {
         std::vector<lvbgpu_ctx *> ctxs;
         for (int g = 0; g < G; g++)
             ctxs.push_back(lvbgpu_double_new(n, nwords, enc.data()));
@@ -59,6 +59,7 @@ int main()
             pars[(size_t)c].min_len_tree = min_len;
             pars[(size_t)c].max_proposals = 120;
             pars[(size_t)c].log_cap = 32;
+            pars[(size_t)c].run_levels = run_levels;
         }
         std::vector<int32_t> first;
         for (int g = 0; g <= G; g++)
@@ -87,6 +88,28 @@ int main()
             printf("chain %d differs\n", c);
             return 4;
         }
+    // runs of acceptances: the hot chains' candidates are drawn and consumed on several threads (lvbgpu_parallel_for):
+    // no race between the chains' tasks, and a chain ends where it ends with one move per step
+    std::vector<lvbhost_anneal_result> runs1, runs3;
+    if (run(1, runs1, 1) != 0 || run(1, runs3, 3) != 0)
+        return 5;
+    int64_t host_steps = 0;
+    for (int c = 0; c < R; c++)
+    {
+        host_steps += runs3[(size_t)c].host_steps;
+        if (runs1[(size_t)c].best_length != runs3[(size_t)c].best_length || runs1[(size_t)c].final_length != runs3[(size_t)c].final_length ||
+            runs1[(size_t)c].consumed != runs3[(size_t)c].consumed || runs1[(size_t)c].accepted != runs3[(size_t)c].accepted ||
+            runs1[(size_t)c].topologies != runs3[(size_t)c].topologies)
+        {
+            printf("chain %d differs between run lengths\n", c);
+            return 6;
+        }
+    }
+    if (host_steps == 0)
+    {
+        printf("no host-drawn step happened\n");
+        return 7;
+    }
     printf("ok\n");
     return 0;
 }
