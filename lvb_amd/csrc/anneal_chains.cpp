@@ -871,12 +871,12 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
                                                        h_commit_edits.data());
             if (rcm != LVBGPU_OK)
                 return rcm;
+            rp = lvbgpu_parallel_for(ctx, (int32_t)hot.size(), [](int32_t i, void *a) { (*((HotJob *)a)->hot)[(size_t)i]->hs_follow(); }, &hot_job);
+            if (rp != LVBGPU_OK)
+                return rp;
             for (ChainRun *r : hot)
-            {
-                r->hs_follow();
                 if (r->rc != LVBGPU_OK)
                     return r->rc;
-            }
         }
         hs_commit_s += since(t0);
         hs_parts++;

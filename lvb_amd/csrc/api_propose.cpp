@@ -1409,17 +1409,42 @@ extern "C" int lvbgpu_chains_commit_edits(lvbgpu_ctx *ctx, int32_t k, const int3
     a.tmp_stride = (uint32_t)(ctx->nb + 1);
     a.done_count = (uint32_t *)ctx->d_done.p;
     HIPCHK(ctx, launch_walk(a, true, ctx->stream));
-    for (int32_t j = 0; j < k; j++) // the host's topologies follow; the generator's tables go stale
+    // the host's topologies follow (every chain on its own: on the pool's threads from a few chains on); the
+    // generator's tables go stale
     {
-        ChainSlot &cs = ctx->parked[(size_t)chains[j]];
-        std::string why;
-        if (!ctx->pb.apply_edits(cs.topo, edits[(size_t)j].data(), (int32_t)edits[(size_t)j].size(), -1, &why))
+        std::vector<std::string> whys((size_t)k);
+        std::vector<uint8_t> ok((size_t)k, 0);
+        auto apply_one = [&](int32_t j, ProgramBuilder &pb) {
+            ChainSlot &cs = ctx->parked[(size_t)chains[j]];
+            ok[(size_t)j] = pb.apply_edits(cs.topo, edits[(size_t)j].data(), (int32_t)edits[(size_t)j].size(), -1, &whys[(size_t)j]) ? 1 : 0;
+        };
+        const int T = (ctx->pool && k >= 8) ? std::min(ctx->pool->size(), (int)k / 2) : 1;
+        if (T > 1)
         {
-            cs.have_tree = false;
-            return ctx->fail(LVBGPU_E_TOPOLOGY, why);
+            if ((int)ctx->workers.size() < T)
+                ctx->workers.resize((size_t)T);
+            ctx->pool->run(T, [&](int t) {
+                BuildWorker &w = ctx->workers[(size_t)t];
+                w.pb.resize(ctx->nb);
+                w.topo_version = ~0ull; // (its builder's scratch is used, its topology copy is not)
+                for (int32_t j = (int32_t)((int64_t)k * t / T), e = (int32_t)((int64_t)k * (t + 1) / T); j < e; j++)
+                    apply_one(j, w.pb);
+            });
         }
-        cs.topo_version = ++ctx->version_counter;
-        cs.cur_length_stale = true;
+        else
+            for (int32_t j = 0; j < k; j++)
+                apply_one(j, ctx->pb);
+        for (int32_t j = 0; j < k; j++)
+        {
+            ChainSlot &cs = ctx->parked[(size_t)chains[j]];
+            if (!ok[(size_t)j])
+            {
+                cs.have_tree = false;
+                return ctx->fail(LVBGPU_E_TOPOLOGY, whys[(size_t)j]);
+            }
+            cs.topo_version = ++ctx->version_counter;
+            cs.cur_length_stale = true;
+        }
     }
     forget_named_candidates(ctx, seen);
     ctx->commits_reusing_programs++;
