@@ -28,7 +28,7 @@ for case in cases:
     print(case['infile'], case['seed'], case['algorithm'], 'ok', n)
 # the multi-chain annealing loop (anneal_chains.cpp) on the double's chains: 5 chains, every move schedule
 from tests import synth
-for alg in (0, 1, 2):
+for alg, levels in ((0, 0), (1, 0), (2, 0), (0, 3), (1, 3), (2, 4)):   # levels > 0: runs of acceptances (host-drawn hot phase)
     rows5, ml5 = host.prepare_alignment(synth.treelike_rows(20, 500, 33), lib)
     enc5 = binding.encode_rows(rows5)
     ctx5 = C.c_void_p(lib.lvbgpu_double_new(enc5.shape[0], enc5.shape[1], np.ascontiguousarray(enc5)))
@@ -36,13 +36,14 @@ for alg in (0, 1, 2):
     pars5 = []
     for c in range(5):
         q = host.anneal_defaults(lib); q.seed, q.algorithm, q.batch, q.t0, q.min_len_tree = 90 + c, alg, 48, 0.0, ml5
-        q.max_proposals, q.log_cap = 2500, 32
+        q.max_proposals, q.log_cap, q.run_levels = 2500, 32, levels
         pars5.append(q)
     res5, log5 = host.anneal_chains(ctx5, trees5, pars5, lib=lib)
     assert all(r['consumed'] == 2500 for r in res5), res5
     for t5 in trees5: t5.close()
     lib.lvbgpu_double_free(ctx5)
-    print('anneal_chains', alg, [r['best_length'] for r in res5], 'ok')
+    assert levels == 0 or sum(r['host_steps'] for r in res5) > 0
+    print('anneal_chains', alg, levels, [r['best_length'] for r in res5], 'ok')
 # program builder fuzz through the sanitized library
 t = host.HostTree(40, seed=3, lib=lib)
 for k in range(3000):
