@@ -511,7 +511,8 @@ struct ChainRun
             room = std::min(room, std::max<int64_t>(1, p.max_proposals - iter));
         // alternatives per level: so many that a level goes without an acceptance one time in twenty
         int K = (int)std::ceil(std::log(0.05) / std::log(1.0 - std::min(0.95, std::max(0.05, rate_p))));
-        K = std::max(2, std::min(K, 8));
+        static const int k_max = [] { const char *e = getenv("LVBHOST_RUN_K_MAX"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+        K = std::max(std::min(2, k_max), std::min(K, k_max));
         int L = std::max(1, std::min(levels, 8));
         while (L > 1 && (int64_t)(L - 1) + K > room)
             L--;
