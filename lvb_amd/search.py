@@ -24,10 +24,13 @@ from . import api, host
 
 def run_chains(path: str, seed: int = 1, chains: int = 16, algorithm: int = 1, batch: int = 4096, device: int = 0,
                out: str | None = "outtree", max_seconds: float = 0.0, cooling: int = 0, verbose: bool = True,
-               fmt: str = "phylip") -> dict:
+               fmt: str = "phylip", run_levels: int | None = None) -> dict:
     """`chains` independent restarts stepped together on ONE GPU (lvbhost_anneal_chains): every device step draws,
     scores and commits for all of them.  The trees written are the distinct topologies of the best length over all
-    chains."""
+    chains.  run_levels: runs of accepted moves per scoring walk while a chain is hot (lvbhost_anneal_params::run_levels);
+    None: 3 for one or two chains - where it pays - else off."""
+    if run_levels is None:
+        run_levels = 3 if chains <= 2 else 0
     t0 = time.perf_counter()
     names, rows = host.read_alignment(path, fmt)
     n, m_read = len(rows), len(rows[0])
@@ -42,6 +45,7 @@ def run_chains(path: str, seed: int = 1, chains: int = 16, algorithm: int = 1, b
         p.seed = seed * 1000 + c + 1
         p.algorithm, p.cooling_schedule, p.batch = algorithm, cooling, batch
         p.min_len_tree, p.max_seconds, p.t0, p.log_cap = min_len, max_seconds, 0.0, 4096
+        p.run_levels = run_levels
         params.append(p)
     per_chain, log = host.anneal_chains(ctx, trees, params)
     best = min(r["best_length"] for r in per_chain)
@@ -212,6 +216,9 @@ def main(argv=None) -> int:
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--host-proposals", action="store_true", help="draw neighbours on the host instead of the GPU")
     ap.add_argument("--chains", type=int, default=1, help="independent restarts stepped together on this GPU (1 .. 64)")
+    ap.add_argument("--run-levels", type=int, default=None,
+                    help="with --chains: runs of up to this many accepted moves per scoring walk while a chain is hot "
+                         "(default: 3 for one or two chains, else off)")
     ap.add_argument("--exact", action="store_true", help="reproduce the reference program's run for this seed")
     ap.add_argument("-N", dest="max_trees", type=int, default=0)
     a = ap.parse_args(argv)
@@ -227,9 +234,9 @@ def main(argv=None) -> int:
         if ranks.world > 1:
             run_restarts(ranks, a.infile, a.seed, a.out, **kw)
             ranks.close()
-        elif a.chains > 1:
+        elif a.chains > 1 or a.run_levels is not None:
             run_chains(a.infile, a.seed, a.chains, algorithm=a.algorithm, batch=a.batch, device=a.device, out=a.out,
-                       max_seconds=a.max_seconds, cooling=0 if a.cooling == "g" else 1, fmt=a.fmt)
+                       max_seconds=a.max_seconds, cooling=0 if a.cooling == "g" else 1, fmt=a.fmt, run_levels=a.run_levels)
         else:
             run(a.infile, a.seed, device=a.device, out=a.out, **kw)
     except (api.LvbGpuError, ValueError, OSError) as exc:

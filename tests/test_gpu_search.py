@@ -34,14 +34,18 @@ def test_search_reaches_reference_optimum(tmp_path, phy, score, topologies, on_d
     assert len(lines) == res["topologies"] and all(l.startswith("(") and l.endswith(");") for l in lines)
 
 
-@pytest.mark.parametrize("phy,score", [("test_treelength_6_thread_2.phy", 1628), ("test_treelength_7_thread_2.phy", 1006)])
-def test_chains_on_one_gpu_reach_the_reference_optimum(tmp_path, phy, score):
+@pytest.mark.parametrize("phy,score,chains,levels", [("test_treelength_6_thread_2.phy", 1628, 6, None),
+                                                     ("test_treelength_7_thread_2.phy", 1006, 6, None),
+                                                     ("test_treelength_7_thread_2.phy", 1006, 2, None),   # runs of 3 (the default for two chains)
+                                                     ("test_treelength_6_thread_2.phy", 1628, 6, 3)])     # runs among six chains
+def test_chains_on_one_gpu_reach_the_reference_optimum(tmp_path, phy, score, chains, levels):
     """`--chains R`: R restarts stepped together; the best over the chains is the reference's known optimum and the
-    output holds each distinct best topology once."""
+    output holds each distinct best topology once - device-drawn steps, and with runs of accepted moves per scoring walk
+    (`--run-levels`, host-drawn while a chain is hot)."""
     from lvb_amd import search
     out = tmp_path / "outtree"
-    res = search.run_chains(str(GOLD / "ref_tests" / phy), seed=77, chains=6, batch=64, out=str(out), max_seconds=60,
-                            verbose=False)
+    res = search.run_chains(str(GOLD / "ref_tests" / phy), seed=77, chains=chains, batch=64, out=str(out), max_seconds=60,
+                            verbose=False, run_levels=levels)
     assert res["best_length"] == score and min(res["best_lengths"]) == score, res["best_lengths"]
     lines = out.read_text().splitlines()
     assert len(lines) == res["topologies"] >= 1 and len(set(lines)) == len(lines)
