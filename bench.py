@@ -839,7 +839,8 @@ def rank_main(args) -> None:
                         "commit walk per device step for all of them; starting temperatures included",
             }
             # one chain alone, for comparison: the same loop with R = 1
-            # (seeded as in rounds 1 and 2 - from --seed, not --anneal-seed - so that this is the same chain as in their lines)
+            # (seeded as in rounds 1 and 2 - from --seed, not --anneal-seed; with --single-chain-levels 0 it is the same chain
+            # as in their lines, with runs of accepted moves - the default - the hot phase draws by the host's law)
             fresh = host.HostTree(args.taxa, seed=ranks.restart_seed(args.seed) * 100)
             p1 = params_for(0)
             p1.seed = args.seed * 7919 + 1000 * rank + 1
