@@ -48,7 +48,7 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].split("(")[0]
-                if KERNEL in name:
+                if KERNEL in name or "fitch_walk_pair<" in name:   # (the paired walk: A/B profiles taken with LVBGPU_PAIR)
                     by_variant[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     variant = max(by_variant, key=lambda v: sum(len(x) for x in by_variant[v].values()), default=None)
     counters = by_variant[variant] if variant else {}
