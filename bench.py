@@ -89,9 +89,6 @@ def parse_args(argv=None):
                          "StartingTemperature.c; DESIGN.md 7c); the default base gives 32 chains without such a straggler, as round "
                          "2's did (tools/anneal_seed_scan.py), so that `scored_per_s` - measured until ALL chains have frozen - says "
                          "something about the scorer.  `scored_per_s_busy` does so for any seed")
-    ap.add_argument("--anneal-groups", type=int, default=1,
-                    help="the chains are dealt to this many groups that anneal side by side, each with a context and a host "
-                         "thread of its own (lvbhost_anneal_chain_groups); 1 = all chains lock-stepped in one context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 / 16 384 and uniform-alignment legs")
     ap.add_argument("--single-chain-levels", type=int, default=3,
@@ -806,14 +803,9 @@ def rank_main(args) -> None:
             p.log_cap = 4096
             return p
         R = max(1, args.anneal_chains)
-        G = max(1, min(args.anneal_groups, R))
-        actxs = [api.FitchContext(text_rows=rows, device=ranks.device) for _ in range(G)]
-        actx = actxs[0]
+        actx = api.FitchContext(text_rows=rows, device=ranks.device)
         atrees = [host.HostTree(args.taxa, seed=ranks.restart_seed(args.anneal_seed) * 100 + c) for c in range(R)]
-        if G > 1:
-            res, log = host.anneal_chain_groups(actxs, atrees, [params_for(c) for c in range(R)])
-        else:
-            res, log = host.anneal_chains(actx, atrees, [params_for(c) for c in range(R)])
+        res, log = host.anneal_chains(actx, atrees, [params_for(c) for c in range(R)])
         anneal_log = list(log)
         single_log = []
         keep = log[:: max(1, len(log) // 12)] + log[-1:]
@@ -821,7 +813,7 @@ def rank_main(args) -> None:
         tot = lambda k: sum(r[k] for r in res)
         if rank == 0:
             out["anneal"] = {
-                "chains": R, "groups": G, "seconds": round(secs, 3),
+                "chains": R, "seconds": round(secs, 3),
                 "best_length": min(r["best_length"] for r in res), "best_lengths": [r["best_length"] for r in res],
                 "start_lengths": [r["start_length"] for r in res],
                 "scored": tot("scored"), "consumed": tot("consumed"), "accepted": tot("accepted"),
@@ -834,9 +826,8 @@ def rank_main(args) -> None:
                 "device_fraction": round(res[0]["seconds_device"] / secs, 3), "batch": args.anneal_batch,
                 "temperatures": [r["temperatures"] for r in res], "frozen": sum(r["frozen"] for r in res),
                 "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
-                "what": f"{R} independent chains (own seeds and start trees) in {G} group(s) side by side (a context and a host "
-                        "thread per group); a group's chains are stepped together: one generator launch, one walk and one "
-                        "commit walk per device step for all of them; starting temperatures included",
+                "what": f"{R} independent chains (own seeds and start trees) stepped together in one context: one generator "
+                        "launch, one walk and one commit walk per device step for all of them; starting temperatures included",
             }
             # one chain alone, for comparison: the same loop with R = 1
             # (seeded as in rounds 1 and 2 - from --seed, not --anneal-seed; with --single-chain-levels 0 it is the same chain
@@ -857,8 +848,7 @@ def rank_main(args) -> None:
                         "cumulative (host-drawn, up to that many accepted moves per scoring walk: lvbhost_anneal_params::run_levels)"}
         for t in atrees:
             t.close()
-        for c in actxs:
-            c.close()
+        actx.close()
     # LVB's own CPU path last: 32 reference processes at once leave the host's CPU quota throttled for a while, which
     # the legs above (host threads beside the GPU) would feel
     if extras and not args.no_cpu_baseline and args.dist == "tree":

@@ -198,16 +198,6 @@ int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbh
  * log (wall time, best length over all chains).  1 <= R <= 64. */
 int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, const lvbhost_anneal_params *params,
                           lvbhost_anneal_result *results, double *log_seconds, int64_t *log_best, int32_t *n_log);
-/* The same with the chains dealt to G groups that run SIDE BY SIDE: group g is lvbhost_anneal_chains on its own
- * context ctxs[g] (all created from the same alignment on the same device; distinct - a context is not thread-safe)
- * with chains first[g] .. first[g+1]-1 of trees / params / results (first[0] = 0, first[G] = number of chains), on a
- * host thread of its own.  The groups' device work overlaps (own streams) and so does their host work; a chain's
- * trajectory is the same in any grouping.  params[0] supplies max_seconds, max_device_steps and log_cap for all groups
- * (sync_every must be 0); the log holds the improvements of the best length over ALL chains against the common
- * clock, results[c].seconds the whole run's wall time. */
-int lvbhost_anneal_chain_groups(int32_t G, lvbgpu_ctx *const *ctxs, const int32_t *first, lvbhost_tree *const *trees,
-                                const lvbhost_anneal_params *params, lvbhost_anneal_result *results, double *log_seconds,
-                                int64_t *log_best, int32_t *n_log);
 /* make `tree` resident in ctx (full evaluation) */
 int lvbhost_tree_upload(lvbgpu_ctx *ctx, const lvbhost_tree *tree, int64_t *length_out);
 

@@ -14,7 +14,8 @@
 // acceptance rate; never across a cooling step or a re-root tick) and by which rule it accepts (current length,
 // temperature, a seed for the step's Metropolis draws), consume() books the lengths in order up to the accepted candidate
 // the step reports, after_commit() finishes that proposal.  A chain's decisions depend on its own
-// state and random stream only, so its trajectory is the same whatever R is (tests/test_gpu_chains.py).
+// state and random stream only, so - for a given run_levels: hot chains draw by the host's law when it is > 0 - its
+// trajectory is the same whatever R is (tests/test_gpu_chains.py).
 #include "../../include/lvbhost.h"
 
 #include <algorithm>
@@ -739,7 +740,7 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     // (Stepping the chains as two groups taking turns - the host working on one group's lengths while the device draws and
     // scores the other's - was measured in rounds 2 and 3 and LOSES on MI355X (R = 32: 1.345 -> 1.578 s): a step is mostly
     // fixed device latency and two half-sized groups pay it twice on one in-order stream.  Groups side by side on streams
-    // of their own: lvbhost_anneal_chain_groups.)
+    // and host threads of their own lost as well (1.42 s with one group, 1.86 s with eight); round 4 removed them.)
     struct Flight
     {
         std::vector<lvbgpu_chain_draw> draws;
@@ -1127,89 +1128,4 @@ extern "C" int lvbhost_anneal_chains(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *c
                                      lvbhost_anneal_result *results, double *log_seconds, int64_t *log_best, int32_t *n_log)
 {
     return anneal_chains_run(ctx, R, trees, params, results, log_seconds, log_best, n_log, Clock::now());
-}
-
-// G groups of chains side by side on one GPU.  A lock-stepped group pays a step's latency chain (generator, walk, the
-// host's decisions, commit walk, table rebuild) once per step for all its chains, but while the host decides the
-// device idles and while the device works the host does: with every chain in one group a 32-chain step is 105 us in
-// the hot phase of which the device computes 60 and the host 65.  Here every group has a context of its own - own
-// streams, so the groups' kernels run beside one another on the device - and a host thread of its own, so their
-// launches and bookkeeping overlap too; the alignment is resident once per context (12.5 MB at 500 x 50k: nothing).
-// A chain's trajectory depends on its own parameters only, so it is the same in any grouping
-// (tests/test_anneal_chains_cpu.py, tests/test_gpu_chains.py).
-extern "C" int lvbhost_anneal_chain_groups(int32_t G, lvbgpu_ctx *const *ctxs, const int32_t *first, lvbhost_tree *const *trees,
-                                           const lvbhost_anneal_params *params, lvbhost_anneal_result *results,
-                                           double *log_seconds, int64_t *log_best, int32_t *n_log)
-{
-    if (G < 1 || G > 64 || !ctxs || !first || !trees || !params || !results || first[0] != 0)
-        return LVBGPU_E_ARG;
-    for (int32_t g = 0; g < G; g++)
-        if (!ctxs[g] || first[g + 1] <= first[g] || first[g + 1] - first[g] > 64)
-            return LVBGPU_E_ARG;
-    for (int32_t g = 0; g < G; g++)
-        for (int32_t h = 0; h < g; h++)
-            if (ctxs[g] == ctxs[h])
-                return LVBGPU_E_ARG; // a context is not thread-safe: one per group
-    if (params[0].sync_every > 0)
-        return LVBGPU_E_ARG; // the lockstep collective belongs to one context: use lvbhost_anneal_chains
-    const int32_t total = first[G];
-    const int32_t cap = std::max(params[0].log_cap, 0);
-    // what concerns the whole run travels in params[0]: every group's first chain carries a copy
-    std::vector<lvbhost_anneal_params> pars(params, params + total);
-    for (int32_t g = 1; g < G; g++)
-    {
-        lvbhost_anneal_params &p = pars[(size_t)first[g]];
-        p.max_seconds = params[0].max_seconds;
-        p.max_device_steps = params[0].max_device_steps;
-        p.sync_every = 0;
-        p.log_cap = cap;
-    }
-    std::vector<std::vector<double>> secs((size_t)G, std::vector<double>((size_t)std::max(cap, 1)));
-    std::vector<std::vector<int64_t>> best((size_t)G, std::vector<int64_t>((size_t)std::max(cap, 1)));
-    std::vector<int32_t> nlog((size_t)G, 0);
-    std::vector<int> rcs((size_t)G, LVBGPU_OK);
-    const auto wall0 = Clock::now();
-    auto run_group = [&](int32_t g) {
-        rcs[(size_t)g] = anneal_chains_run(ctxs[g], first[g + 1] - first[g], trees + first[g], pars.data() + first[g],
-                                           results + first[g], secs[(size_t)g].data(), best[(size_t)g].data(), &nlog[(size_t)g], wall0);
-    };
-    std::vector<std::thread> threads;
-    for (int32_t g = 1; g < G; g++)
-        threads.emplace_back(run_group, g);
-    run_group(0);
-    for (std::thread &t : threads)
-        t.join();
-    for (int32_t g = 0; g < G; g++)
-        if (rcs[(size_t)g] != LVBGPU_OK)
-            return rcs[(size_t)g];
-    // one log: the groups' improvements in time order, the best over all groups so far
-    std::vector<std::pair<double, int64_t>> ev;
-    for (int32_t g = 0; g < G; g++)
-        for (int32_t i = 0; i < nlog[(size_t)g]; i++)
-            ev.push_back({secs[(size_t)g][(size_t)i], best[(size_t)g][(size_t)i]});
-    std::stable_sort(ev.begin(), ev.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-    int32_t out = 0;
-    int64_t global = INT64_MAX;
-    for (const auto &e : ev)
-        if (e.second < global)
-        {
-            global = e.second;
-            if (log_seconds && log_best && out < cap)
-            {
-                log_seconds[out] = e.first;
-                log_best[out] = e.second;
-                out++;
-            }
-        }
-    double longest = 0.0;
-    for (int32_t c = 0; c < total; c++)
-        longest = std::max(longest, results[c].seconds);
-    for (int32_t c = 0; c < total; c++)
-    {
-        results[c].global_best_length = global == INT64_MAX ? results[c].best_length : global;
-        results[c].seconds = longest; // the run's wall time (every group measured from the common origin)
-    }
-    if (n_log)
-        *n_log = out;
-    return LVBGPU_OK;
 }

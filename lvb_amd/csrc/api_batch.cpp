@@ -427,15 +427,6 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
         a.host_flag = b->watch_flag;
         a.step_seq = b->watch_seq;
         a.watcher = 1; // (launch_walk turns it off again for launches it does not fit)
-        if (b->rules) // the watcher waves also decide (lvbgpu_chains_step_submit made sure this launch fits the watcher)
-        {
-            a.rules = b->rules;
-            a.d_pick_out = b->d_pick;
-            a.host_pick = b->host_pick;
-            a.watch_done = b->watch_done;
-            a.npick_chains = b->npick_chains;
-            memcpy(a.pick_chain, b->pick_chain, sizeof a.pick_chain);
-        }
     }
     b->own_watch = false;
     if (!b->direct && !b->watch_flag && b->recycled && !b->full_mode)
@@ -745,10 +736,12 @@ extern "C" int lvbgpu_chains_score_edits(lvbgpu_ctx *ctx, int32_t B, const int32
     if (!b->in_place && b->slot_of.empty())
     {
         ctx->scored.resize((size_t)B);
+        ctx->scored_edits.assign(edits, edits + edit_offsets[B]); // (the commit compares the rewrites themselves on a hash hit)
         for (int32_t i = 0; i < B; i++)
         {
             const int32_t n = edit_offsets[i + 1] - edit_offsets[i];
-            ctx->scored[(size_t)i] = {chain_of[i], n, ctx->parked[(size_t)chain_of[i]].topo_version, edits_hash(edits + edit_offsets[i], n)};
+            ctx->scored[(size_t)i] = {chain_of[i], n, edit_offsets[i], ctx->parked[(size_t)chain_of[i]].topo_version,
+                                      edits_hash(edits + edit_offsets[i], n)};
         }
         ctx->scored_batch = b;
         ctx->scored_gen = b->build_gen;

@@ -299,6 +299,9 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
             (void)hipEventDestroy(ps.done_ev);
         if (ps.walk_ev)
             (void)hipEventDestroy(ps.walk_ev);
+        if (ps.gen_ev)
+            (void)hipEventDestroy(ps.gen_ev);
+        ps.d_keys.release();
         ps.h_flag.release();
     }
     ctx->h_pinfo.release();

@@ -196,9 +196,6 @@ const char *move_defect(const Topology &t, const lvbgpu_move &m)
 // tree); lengths_out holds the segments one after the other.  `moves` (host-named moves): k == 1 only.
 // Two halves: submit (everything up to the lengths' read-back is enqueued; returns at once) and collect (waits for
 // that batch alone and hands the lengths over).  Two batches may be in flight, in slots 0 and 1.
-int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const uint32_t *where, const int32_t *chains, uint64_t chain_mask,
-                   const uint32_t *d_pick, int *slot_out, uint32_t *seq_out, bool *tables_on_device_out);
-
 int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws, const lvbgpu_move *moves,
                    const lvbgpu_chain_rule *rules = nullptr)
 {
@@ -355,15 +352,10 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     const uint32_t groups_now = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
     ps.watched = allow_watcher && groups_now <= WATCH_MAX_GROUPS &&
                  (!ctx->pslot[1 - slot].in_flight || (uint64_t)B * groups_now < WATCH_PIPELINED_MAX_ITEMS);
-    // A STEP: the rule by which every chain accepts rides with the batch.  Where this launch fits the watcher (always, for
-    // a lone batch of these shapes) and the chains' tables follow on the device, the device decides: the generator resets
-    // the chains' picks, the walk's watcher waves apply the rules, and commit walk, table rebuild and the moves' way to
-    // the host are enqueued right behind the walk (below) - else the host decides at the collect with the same function.
+    // A STEP: the rule by which every chain accepts rides with the batch; the library decides at the collect
+    // (lvb_amd/csrc/decide.h) and commits every chain's first taken candidate there.
     ps.step = rules != nullptr;
-    ps.step_decided = false;
     ps.host_rules.clear();
-    uint32_t seg_where[MAX_CHAINS];
-    int32_t seg_chain[MAX_CHAINS];
     if (rules)
     {
         uint32_t st = 0;
@@ -371,34 +363,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         {
             ps.host_rules.push_back(DecideRule{(long long)rules[i].cur_length, rules[i].temperature, rules[i].min_len_tree,
                                                (unsigned long long)rules[i].accept_seed, st, (uint32_t)draws[i].count});
-            seg_where[i] = st;
-            seg_chain[i] = draws[i].chain;
             st += (uint32_t)draws[i].count;
-        }
-        // LVBGPU_DEVICE_DECIDE=1 (read per step).  The default is the HOST's decision at the collect: measured on MI355X
-        // / ROCm 7.2 the device's is slower - one chain 45.8 us per step with the host deciding, 54.7 us with the device
-        // (same trajectories): what the step saves in host round trips it pays twice over in launch and event calls of
-        // one submit (24 us instead of 10) and in two cross-stream hand-overs (walk -> rebuild on the side stream ->
-        // next generator) on its critical path.  profiles/experiments/r03_anneal_step.md
-        const char *dd = getenv("LVBGPU_DEVICE_DECIDE");
-        const bool allow_device = dd && dd[0] == '1';
-        bool on_device = allow_device && ps.watched && (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
-        for (int32_t i = 0; i < k && on_device; i++)
-            on_device = ctx->parked[(size_t)draws[i].chain].d_topo_version == ctx->parked[(size_t)draws[i].chain].topo_version;
-        if (on_device)
-        {
-            HIPCHK(ctx, ps.h_rules.reserve((size_t)MAX_CHAINS * sizeof(DecideRule)));
-            HIPCHK(ctx, ps.h_pickout.reserve((size_t)MAX_CHAINS * 4));
-            const size_t old = ps.d_pick.cap;
-            HIPCHK(ctx, ps.d_pick.reserve((size_t)(MAX_CHAINS + 1) * 4));
-            if (ps.d_pick.cap != old) // once per slot: the watcher waves' finished-count starts at zero
-            {
-                HIPCHK(ctx, hipMemsetAsync(ps.d_pick.p, 0, ps.d_pick.cap, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            }
-            for (int32_t i = 0; i < k; i++)
-                ((DecideRule *)ps.h_rules.p)[draws[i].chain] = ps.host_rules[(size_t)i];
-            ps.step_decided = true;
         }
     }
     GenArgs ga{};
@@ -415,7 +380,6 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     ga.cands = (CandDesc *)bt->d_prog.p;
     ga.info = (ProposalInfo *)ps.d_pinfo.p;
     ga.len_out = (unsigned long long *)bt->d_len.p;
-    ga.pick_out = ps.step_decided ? (uint32_t *)ps.d_pick.p : nullptr;
     // two candidates per wave (fitch_walk_pair): big launches only - a small one is a chain of latencies, not of loads -
     // and only where every segment's keys fit the sorting workgroup's LDS and preorder numbers fit 16 bits
     bool pair_up = ctx->pair_min > 0 && B >= ctx->pair_min && ctx->gen_idx_bytes == 2;
@@ -501,47 +465,19 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     {
         if (!ps.h_flag.p)
         {
-            HIPCHK(ctx, ps.h_flag.reserve((WATCH_WAVES + 1) * 4)); // one word per watcher wave + one behind the picks of a step
-            memset(ps.h_flag.p, 0, (WATCH_WAVES + 1) * 4);
+            HIPCHK(ctx, ps.h_flag.reserve(WATCH_WAVES * 4)); // one word per watcher wave
+            memset(ps.h_flag.p, 0, WATCH_WAVES * 4);
         }
         bt->watch_flag = (uint32_t *)ps.h_flag.p;
         bt->watch_seq = ++ps.seq == 0xFFFFFFFFu ? (ps.seq = 1) : ps.seq; // 0xFFFFFFFF is the watcher's "gave up"
     }
     else
         bt->watch_flag = nullptr;
-    bt->rules = nullptr;
-    if (ps.step_decided)
-    {
-        bt->rules = (const DecideRule *)ps.h_rules.p;
-        bt->d_pick = (uint32_t *)ps.d_pick.p;
-        bt->watch_done = (uint32_t *)ps.d_pick.p + MAX_CHAINS;
-        bt->host_pick = (uint32_t *)ps.h_pickout.p;
-        bt->npick_chains = (uint32_t)k;
-        for (int32_t i = 0; i < k; i++)
-            bt->pick_chain[i] = (uint8_t)draws[i].chain;
-    }
     rc = lvbgpu_batch_launch(ctx, bt);
     if (rc != LVBGPU_OK)
     {
         ps.segs.clear();
         return rc;
-    }
-    if (ps.step_decided)
-    {
-        // right behind the walk, with no host round trip in between: what the accepted candidates need (every kernel
-        // adds its chain's pick itself and does nothing for a chain that accepted nothing)
-        // (gather and table rebuild run on the side stream: they read the picks, so this once they have to wait for the
-        // walk that decides them)
-        HIPCHK(ctx, hipEventRecord(ps.walk_ev, ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->side_stream, ps.walk_ev, 0));
-        rc = enqueue_accept(ctx, ps, k, seg_where, seg_chain, seen, (const uint32_t *)ps.d_pick.p, &ps.step_pick_slot, &ps.step_seq,
-                            &ps.step_tables_on_device);
-        if (rc != LVBGPU_OK)
-        {
-            ps.segs.clear();
-            return rc;
-        }
-        ctx->pick_use_ord[ps.step_pick_slot] = ctx->submits + 1; // its readers run behind THIS batch's walk (take_pick_slot)
     }
     if (!ps.watched)
     {
@@ -761,6 +697,10 @@ int resolve_follow(lvbgpu_ctx *ctx)
                     ctx->parked[(size_t)f.chains[j]].have_tree = false;
             return ctx->fail_wait("lvbgpu_chains_commit: the picked moves' gather", clock.waited());
         }
+    // what lvbgpu_chains_picked_edits hands out is a COPY: the pinned slot may be taken again (by the next commits and
+    // re-roots) long before the caller asks for the moves
+    ctx->pick_records.assign(h + o_out, h + o_out + (size_t)f.k * out_stride);
+    ctx->pick_records_stride = out_stride;
     for (int32_t j = 0; j < f.k; j++)
     {
         if (!f.has[j])
@@ -850,12 +790,9 @@ namespace lvbgpu_detail
 {
 // What accepted candidates of the batch in `ps` need on the device, enqueued (nothing is waited for): their descriptors
 // and rewrites on the way into a pinned slot (gather), the generator's tables of their chains rebuilt (side stream), and
-// their own device-built programs walked in commit form (main stream).  where[j] is the batch position of pick j - or,
-// with d_pick != null (the picks are being decided on the device, lvbgpu_chains_step_submit), the position of the FIRST
-// candidate of chain chains[j], to which every kernel adds d_pick[chain] itself (doing nothing for a chain that
-// accepted nothing).
+// their own device-built programs walked in commit form (main stream).  where[j] is the batch position of pick j.
 int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const uint32_t *where, const int32_t *chains, uint64_t chain_mask,
-                   const uint32_t *d_pick, int *slot_out, uint32_t *seq_out, bool *tables_on_device_out)
+                   int *slot_out, uint32_t *seq_out, bool *tables_on_device_out)
 {
     lvbgpu_batch *bt = ps.batch;
     // a pinned slot: [flag][picks][k x (descriptor + rewrites)]
@@ -881,9 +818,6 @@ int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const u
     //    as a launch of its own
     GatherArgs gat{};
     memcpy(gat.pick_idx, where, (size_t)k * 4);
-    gat.d_pick = d_pick;
-    for (int32_t j = 0; j < k; j++)
-        gat.pick_chain[j] = (uint8_t)chains[j];
     gat.k = (uint32_t)k;
     gat.info = (const ProposalInfo *)ps.d_pinfo.p;
     gat.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
@@ -915,9 +849,6 @@ int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const u
         ra.K = ctx->gen_kmax;
         ra.leaf_order_len = (uint32_t)ctx->n;
         memcpy(ra.pick_idx, where, (size_t)k * 4);
-        ra.d_pick = d_pick;
-        for (int32_t j = 0; j < k; j++)
-            ra.pick_chain[j] = (uint8_t)chains[j];
         ra.cands = (const CandDesc *)bt->d_prog.p;
         ra.info = (const ProposalInfo *)ps.d_pinfo.p;
         ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
@@ -942,11 +873,8 @@ int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const u
     }
     HIPCHK(ctx, ctx->d_len.reserve(8));
     WalkArgs a = resident_args(ctx, bt->d_prog.p, bt->off_toks, bt->off_dsts, ctx->d_len.p, (uint32_t)k, 1);
-    a.use_pick = d_pick ? 2 : 1;
+    a.use_pick = 1;
     memcpy(a.pick_idx, where, (size_t)k * 4);
-    a.d_pick = d_pick;
-    for (int32_t j = 0; j < k; j++)
-        a.pick_chain[j] = (uint8_t)chains[j];
     a.s_all_out = (unsigned long long *)ctx->d_scalars;
     a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
     a.tmp_stride = (uint32_t)(ctx->nb + 1);
@@ -1013,7 +941,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     uint32_t seq = 0;
     bool tables_on_device = false;
     {
-        const int ra = enqueue_accept(ctx, ps, k, where.data(), pchains.data(), seen, nullptr, &slot, &seq, &tables_on_device);
+        const int ra = enqueue_accept(ctx, ps, k, where.data(), pchains.data(), seen, &slot, &seq, &tables_on_device);
         if (ra != LVBGPU_OK)
             return ra;
     }
@@ -1034,7 +962,6 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
             cs.d_topo_version = cs.topo_version; // rebuilt in place by the launch above
     }
     forget_named_candidates(ctx, seen);
-    ctx->last_pick_slot = slot;
     ctx->last_pick_count = k;
     for (int32_t j = 0; j < k; j++)
         ctx->last_pick_has[j] = true;
@@ -1064,87 +991,24 @@ extern "C" int lvbgpu_chains_step_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t
     const int32_t k = (int32_t)ps.host_rules.size();
     ps.step = false;
     if (rc != LVBGPU_OK)
-    {
-        if (ps.step_decided) // commits may have been walked for picks nobody has seen: these trees cannot be trusted any more
-        {
-            AllParked guard(ctx);
-            for (const lvbgpu_ctx::PSeg &sg : ps.segs)
-                ctx->parked[(size_t)sg.chain].have_tree = false;
-        }
-        return rc;
-    }
+        return rc; // (nothing was committed: the chains' trees stand as they were)
     ctx->step_map.assign((size_t)k, -1);
-    ctx->last_step_slot = slot;
-    if (!ps.step_decided)
-    {
-        // the host decides, by the same function, and commits as lvbgpu_chains_commit does
-        std::vector<lvbgpu_chain_pick> picks;
-        for (int32_t i = 0; i < k; i++)
-        {
-            const DecideRule &r = ps.host_rules[(size_t)i];
-            picks_out[i] = -1;
-            for (uint32_t j = 0; j < r.count; j++)
-                if (lvb_take(lengths_out[r.start + j] == INT64_MAX ? (long long)LVB_OVERFLOW_LENGTH : (long long)lengths_out[r.start + j], &r, j))
-                {
-                    picks_out[i] = (int32_t)j;
-                    ctx->step_map[(size_t)i] = (int32_t)picks.size();
-                    picks.push_back({ps.segs[(size_t)i].chain, (int32_t)j});
-                    break;
-                }
-        }
-        return picks.empty() ? LVBGPU_OK : lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
-    }
-    // the device has decided: the picks come behind the lengths, under a flag word of their own
-    {
-        const uint32_t *flag = (const uint32_t *)ps.h_flag.p + WATCH_WAVES;
-        const WaitClock clock(ctx->wait_limit_s);
-        for (uint32_t spins = 1; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != ps.seq; spins++)
-            if ((spins & 1023u) == 0 && clock.expired())
-            {
-                AllParked guard(ctx);
-                for (const lvbgpu_ctx::PSeg &sg : ps.segs)
-                    ctx->parked[(size_t)sg.chain].have_tree = false;
-                return ctx->fail_wait("lvbgpu_chains_step_collect: the step's picks", clock.waited());
-            }
-    }
-    AllParked guard(ctx);
-    {
-        const int rf = resolve_follow(ctx); // the step before this one: long arrived (its pinned slot is not this step's)
-        if (rf != LVBGPU_OK)
-            return rf;
-    }
-    const uint32_t *hp = (const uint32_t *)ps.h_pickout.p;
-    uint64_t moved = 0;
-    lvbgpu_ctx::Follow &f = ctx->follow;
-    f.pending = false;
-    f.slot = ps.step_pick_slot;
-    f.k = k;
-    f.seq = ps.step_seq;
+    // the library decides, by the one function (decide.h), and commits as lvbgpu_chains_commit does
+    std::vector<lvbgpu_chain_pick> picks;
     for (int32_t i = 0; i < k; i++)
     {
-        const uint32_t pk = __atomic_load_n(hp + i, __ATOMIC_RELAXED);
-        const int32_t chain = ps.segs[(size_t)i].chain;
-        f.chains[i] = chain;
-        f.has[i] = pk != PICK_NONE;
-        ctx->last_pick_has[i] = f.has[i];
-        picks_out[i] = f.has[i] ? (int32_t)pk : -1;
-        if (!f.has[i])
-            continue;
-        if (pk >= (uint32_t)ps.segs[(size_t)i].count)
-            return ctx->fail(LVBGPU_E_STATE, "the device picked candidate " + std::to_string(pk) + " of a draw of " + std::to_string(ps.segs[(size_t)i].count));
-        ctx->step_map[(size_t)i] = i;
-        f.pending = true;
-        moved |= 1ull << chain;
-        ChainSlot &cs = ctx->parked[(size_t)chain];
-        cs.topo_version = ++ctx->version_counter;
-        cs.cur_length_stale = true;
-        if (ps.step_tables_on_device)
-            cs.d_topo_version = cs.topo_version; // rebuilt in place behind the walk
+        const DecideRule &r = ps.host_rules[(size_t)i];
+        picks_out[i] = -1;
+        for (uint32_t j = 0; j < r.count; j++)
+            if (lvb_take(lengths_out[r.start + j] == INT64_MAX ? (long long)LVB_OVERFLOW_LENGTH : (long long)lengths_out[r.start + j], &r, j))
+            {
+                picks_out[i] = (int32_t)j;
+                ctx->step_map[(size_t)i] = (int32_t)picks.size();
+                picks.push_back({ps.segs[(size_t)i].chain, (int32_t)j});
+                break;
+            }
     }
-    forget_named_candidates(ctx, moved);
-    ctx->last_pick_slot = ps.step_pick_slot;
-    ctx->last_pick_count = k;
-    return LVBGPU_OK;
+    return picks.empty() ? LVBGPU_OK : lvbgpu_chains_commit(ctx, (int32_t)picks.size(), picks.data());
 }
 
 extern "C" int lvbgpu_chains_step_edits(lvbgpu_ctx *ctx, int32_t i, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits)
@@ -1373,7 +1237,9 @@ extern "C" int lvbgpu_chains_commit_edits(lvbgpu_ctx *ctx, int32_t k, const int3
         for (size_t i = 0; i < ctx->scored.size() && !found; i++)
         {
             const lvbgpu_ctx::ScoredEdit &se = ctx->scored[i];
-            if (se.chain == chains[j] && se.n_edits == n && se.hash == h && se.version == v)
+            // (found by the hash, told apart by the rewrites themselves - as the treestack does with its trees)
+            if (se.chain == chains[j] && se.n_edits == n && se.hash == h && se.version == v &&
+                memcmp(ctx->scored_edits.data() + se.edit_off, edits_in + edit_offsets[j], (size_t)n * sizeof(lvbgpu_edit)) == 0)
             {
                 where[j] = (uint32_t)i;
                 found = true;
@@ -1402,8 +1268,6 @@ extern "C" int lvbgpu_chains_commit_edits(lvbgpu_ctx *ctx, int32_t k, const int3
     WalkArgs a = resident_args(ctx, sb->d_prog.p, sb->off_toks, sb->off_dsts, ctx->d_len.p, (uint32_t)k, (int32_t)sb->stats.max_stack);
     a.use_pick = 1;
     memcpy(a.pick_idx, where, (size_t)k * 4);
-    for (int32_t j = 0; j < k; j++)
-        a.pick_chain[j] = (uint8_t)chains[j];
     a.s_all_out = (unsigned long long *)ctx->d_scalars;
     a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
     a.tmp_stride = (uint32_t)(ctx->nb + 1);
@@ -1464,8 +1328,9 @@ extern "C" int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edi
     }
     if (!ctx->last_pick_has[j])
         return ctx->fail(LVBGPU_E_ARG, "that chain accepted nothing in the last step");
-    const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
-    const char *rec = (const char *)ctx->h_pick[ctx->last_pick_slot].p + 64 + align16((size_t)MAX_CHAINS * 4) + (size_t)j * out_stride;
+    if ((size_t)(j + 1) * ctx->pick_records_stride > ctx->pick_records.size())
+        return ctx->fail(LVBGPU_E_STATE, "the picked moves never arrived from the device");
+    const char *rec = ctx->pick_records.data() + (size_t)j * ctx->pick_records_stride; // (resolve_follow's copy)
     const ProposalInfo pi = *(const ProposalInfo *)rec;
     if (pi.n_edits > cap)
         return ctx->fail(LVBGPU_E_ARG, "edit buffer too small");

@@ -232,15 +232,8 @@ struct lvbgpu_ctx
         bool watched = false;         // this batch's lengths come through the watcher, not a copy
         bool in_flight = false;
         // a STEP (lvbgpu_chains_step_submit): the accept decision rides with the batch
-        bool step = false;            // rules were given
-        bool step_decided = false;    // ... and the device decides (else the host does, at the collect, with the same rule)
+        bool step = false;            // rules were given: the library decides at the collect and commits the picks
         std::vector<DecideRule> host_rules; // by draw index
-        PinBuf h_rules;               // DecideRule[MAX_CHAINS] by chain: what the watcher waves read
-        DevBuf d_pick;                // uint32[MAX_CHAINS] by chain + the watcher waves' finished-count
-        PinBuf h_pickout;             // uint32[MAX_CHAINS] by draw index: the picks as the host reads them
-        int step_pick_slot = 0;       // pinned slot the accepted moves' records go to
-        uint32_t step_seq = 0;
-        bool step_tables_on_device = false;
     };
     static constexpr int PROP_SLOTS = 2;
     PropSlot pslot[PROP_SLOTS];
@@ -273,9 +266,10 @@ struct lvbgpu_ctx
     bool pick_used[PICK_SLOTS] = {false, false, false, false};
     int pick_slot = 0;
     uint32_t pick_seq = 0;
-    int last_pick_slot = 0, last_pick_count = 0; // what lvbgpu_chains_picked_edits reads
-    bool last_pick_has[MAX_CHAINS] = {};         // ... and which of those records exist
-    int last_step_slot = 0;                      // the slot of the last lvbgpu_chains_step_collect
+    int last_pick_count = 0;                     // picks of the last lvbgpu_chains_commit
+    bool last_pick_has[MAX_CHAINS] = {};         // ... and which of their records exist
+    std::vector<char> pick_records;              // ... copied out of the pinned slot when they arrived (lvbgpu_chains_picked_edits)
+    uint32_t pick_records_stride = 0;
     std::vector<int32_t> step_map;               // ... its draws -> record index of lvbgpu_chains_picked_edits (-1: nothing accepted)
     DevBuf d_done; // per picked candidate: finished-wave count of a multi-chain commit (zero between launches)
     // The host side of the last lvbgpu_chains_commit, not done yet: the picked moves' descriptors and rewrites are on
@@ -290,7 +284,7 @@ struct lvbgpu_ctx
         int32_t k = 0;
         uint32_t seq = 0;
         int32_t chains[MAX_CHAINS];
-        bool has[MAX_CHAINS]; // record j exists (a step decided on the device writes none for a chain that accepted nothing)
+        bool has[MAX_CHAINS]; // record j exists
     } follow;
     PinBuf h_pin;
     // direct steps: small batches whose programs the walk reads straight from h_pin and whose lengths its last
@@ -303,10 +297,11 @@ struct lvbgpu_ctx
     // program (it lies in the batch) instead of building it again
     struct ScoredEdit
     {
-        int32_t chain, n_edits;
+        int32_t chain, n_edits, edit_off; // its rewrites: scored_edits[edit_off .. edit_off + n_edits)
         uint64_t version, hash;
     };
     std::vector<ScoredEdit> scored;
+    std::vector<lvbgpu_edit> scored_edits;
     lvbgpu_batch *scored_batch = nullptr;
     uint64_t scored_gen = 0;
     int64_t commits_reusing_programs = 0;
@@ -398,11 +393,6 @@ struct lvbgpu_batch
     PinBuf h_wflag;
     uint32_t own_seq = 0;
     bool own_watch = false;
-    // ... and, for a step decided on the device, apply these rules and leave the picks (kernels.hpp WalkArgs::rules)
-    const DecideRule *rules = nullptr;
-    uint32_t *d_pick = nullptr, *host_pick = nullptr, *watch_done = nullptr;
-    uint32_t npick_chains = 0;
-    uint8_t pick_chain[MAX_CHAINS] = {};
     bool spans_chains = false; // device-built batch over several chains: every program names its own chain
     uint64_t build_gen = 0;    // counts the builds into this batch (lvbgpu_chains_commit_edits re-uses scored programs)
     uint64_t topo_version = 0; // resident tree the programs were built against (edits are relative to it)

@@ -135,8 +135,8 @@ struct OffVec
 };
 
 // The watcher waves of a launch (WalkArgs::watcher; eight extra blocks at the end of the grid, wave `wid` of WATCH_WAVES):
-// wait until every length slot of this wave's chunks has its ngroups arrivals, hand the lengths to the host - and, for
-// a step decided on the device, apply the chains' rules (WalkArgs::rules).  Shared by fitch_walk and fitch_walk_pair.
+// wait until every length slot of this wave's chunks has its ngroups arrivals and hand the lengths to the host.  Shared
+// by fitch_walk and fitch_walk_pair.
 __device__ __forceinline__ void watcher_block(const WalkArgs &a, const uint32_t wid, const uint32_t lane)
 {
     // all 32 waves of the eight extra blocks watch: wave w takes the 64-candidate chunks w, w + 32, ... (one
@@ -150,16 +150,6 @@ __device__ __forceinline__ void watcher_block(const WalkArgs &a, const uint32_t 
         const uint32_t i = base + lane;
         if (i < a.B)
         {
-            // the accept decision (kernels.hpp WalkArgs::rules): the candidate's chain says which rule (fetched now,
-            // over the host link, while the walking waves are still at it), the rule where the chain's candidates
-            // start; the chain's pick is the smallest taken index
-            uint32_t ch = 0;
-            DecideRule rule{};
-            if (a.rules)
-            {
-                ch = a.cands[i].flags >> CAND_CHAIN_SHIFT;
-                rule = a.rules[ch];
-            }
             unsigned long long v;
             uint32_t budget = 1u << 24; // ~ seconds: every walking wave finishes on its own, this is a backstop
             while ((((v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & count_mask) >>
@@ -168,36 +158,13 @@ __device__ __forceinline__ void watcher_block(const WalkArgs &a, const uint32_t 
                 __builtin_amdgcn_s_sleep(8);
             gave_up |= budget == 0u;
             __hip_atomic_store(a.host_len + i, v & ~count_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (a.rules && budget != 0u && lvb_take((long long)(v & ~count_mask), &rule, i - rule.start))
-                atomicMin(a.d_pick_out + ch, i - rule.start);
         }
     }
-    atomics_acknowledged(); // the wave's stores and picks (all lanes) before its flag
+    atomics_acknowledged(); // the wave's stores (all lanes) before its flag
     // every watcher wave has a flag word of its own (the host waits for all 32): no counter for them to meet at
     if (lane == 0)
         __hip_atomic_store(a.host_flag + wid, __builtin_amdgcn_ballot_w64(gave_up) != 0ull ? 0xFFFFFFFFu : a.step_seq,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (a.rules)
-    {
-        // the picks go to the host once EVERY watcher wave has had its say: the last one to tick (all the others'
-        // atomics were acknowledged before their ticks were sent) copies them and sets the flag behind the waves'
-        uint32_t last = 0;
-        if (lane == 0)
-            last = atomicAdd(a.watch_done, 1u) == WATCHERS - 1u ? 1u : 0u;
-        if (__builtin_amdgcn_readfirstlane(last))
-        {
-            if (lane < a.npick_chains)
-                __hip_atomic_store(a.host_pick + lane,
-                                   __hip_atomic_load(a.d_pick_out + a.pick_chain[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            atomics_acknowledged();
-            if (lane == 0)
-            {
-                __hip_atomic_store(a.watch_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.host_flag + WATCHERS, a.step_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
 }
 
 // WIDE: row offsets kept as 64-bit byte counts in two vectors (tree blocks of 64 GiB and more).  The
@@ -258,14 +225,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
     uint32_t which = cand;
     if constexpr (COMMIT)
     {
-        if (a.use_pick == 2u) // decided on the device: this chain's pick, or nothing to do for any wave of this candidate
-        {
-            const uint32_t pk = a.d_pick[a.pick_chain[cand]];
-            if (pk == PICK_NONE)
-                return;
-            which = a.pick_idx[cand] + pk;
-        }
-        else if (a.use_pick)
+        if (a.use_pick)
             which = a.pick_idx[cand];
     }
     const CandDesc cd = a.cands[which];

@@ -25,32 +25,12 @@ struct GatherArgs
     uint32_t *flag;                // pinned: = seq once all k records are on the host
     uint32_t seq;
     uint32_t *arrived;             // device word, zero between launches
-    // picks decided on the device: pick j = pick_idx[j] + d_pick[pick_chain[j]]; a chain that accepted nothing writes no
-    // record (the host knows from the picks it was handed) but still counts as arrived
-    const uint32_t *d_pick;
-    uint8_t pick_chain[MAX_CHAINS];
 };
 
 // pick j by one wave (lane = 0..63): word by word, as system-scope stores (written through to the host)
 __device__ __forceinline__ void gather_one_pick(const GatherArgs &a, uint32_t j, uint32_t lane)
 {
-    uint32_t g = a.pick_idx[j];
-    bool nothing = false;
-    if (a.d_pick)
-    {
-        const uint32_t pk = a.d_pick[a.pick_chain[j]];
-        nothing = pk == PICK_NONE;
-        g += nothing ? 0u : pk;
-    }
-    if (nothing)
-    {
-        if (lane == 0 && atomicAdd(a.arrived, 1u) == a.k - 1u)
-        {
-            __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
-    }
+    const uint32_t g = a.pick_idx[j];
     const ProposalInfo pi = a.info[g];
     uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + (size_t)j * a.out_stride);
     constexpr uint32_t PI_WORDS = sizeof(ProposalInfo) / 4u;

@@ -116,23 +116,9 @@ struct WalkArgs
     // waves settles that candidate.  A single commit is j = 0, tmp_stride irrelevant.  The picks travel IN the kernel
     // arguments: from pinned host memory every commit wave (and the table rebuild, and the gather) began with a read
     // over the host link.
-    // use_pick == 2: the picks are not known to the host yet - the scoring walk's watcher waves decide them (below) and
-    // leave them in d_pick[chain]; launch candidate j belongs to chain pick_chain[j], whose candidates start at
-    // pick_idx[j], and walks cands[pick_idx[j] + d_pick[chain]] - or nothing at all if that chain accepted nothing
     uint32_t use_pick;
     uint32_t pick_idx[MAX_CHAINS];
-    uint8_t pick_chain[MAX_CHAINS];
-    const uint32_t *d_pick;
     uint32_t tmp_stride;
-    // the accept decision on the device (watcher launches, rules != null): every watcher wave, once a candidate's length
-    // is complete, applies the chain's rule (pinned host memory, indexed by chain) and lowers d_pick[chain] to the
-    // candidate's index if it is taken; the LAST watcher wave to finish copies the npick_chains picks listed in
-    // pick_chain[] to host_pick[] and sets host_flag[WATCH_WAVES]
-    const DecideRule *rules;
-    uint32_t *d_pick_out;
-    uint32_t *host_pick;
-    uint32_t npick_chains;
-    uint32_t *watch_done; // device word, zero between launches
     uint32_t flip; // walk each XCD's share of the items from its far end (filled by launch_walk)
     // two candidates per wave (fitch_walk_pair; scoring launches): pairs[2 p], pairs[2 p + 1] = the candidates of pair p
     // (the second PICK_NONE: walked alone); an item is then (tile group, pair) and nitems = npairs * ngroups
@@ -214,7 +200,6 @@ struct GenArgs
     CandDesc *cands;
     ProposalInfo *info;
     unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
-    uint32_t *pick_out;          // [MAX_CHAINS] picks of a step decided on the device: the generator resets its chains' (null: none)
     uint32_t *keys;              // [B] sort keys for pairing the candidates (pair_kernel; null: none; needs 16-bit tables)
     const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
     unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
@@ -256,10 +241,6 @@ struct RebuildArgs
     int32_t n, nb, K;
     uint32_t leaf_order_len;
     uint32_t pick_idx[MAX_CHAINS]; // batch positions of the picked candidates (in the kernel arguments, see WalkArgs)
-    // d_pick != null: picks decided on the device - pick j is pick_idx[j] (its chain's first candidate) + d_pick[pick_chain[j]],
-    // nothing to do if that is PICK_NONE
-    const uint32_t *d_pick;
-    uint8_t pick_chain[MAX_CHAINS];
     const CandDesc *cands;   // their descriptors (flags carry the chain)
     const ProposalInfo *info;
     const lvbgpu_edit_dev *edits;

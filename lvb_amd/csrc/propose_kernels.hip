@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <stdint.h>
 
 #include "kernels.hpp"
@@ -646,8 +647,6 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
         g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 5u] = t_enter;
         g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 6u] = __builtin_readcyclecounter();
     }
-    if (g.pick_out && blk_local == 0u && threadIdx.x == 0u)
-        g.pick_out[sg.chain] = PICK_NONE; // this step's accept decision starts from "nothing accepted" (WalkArgs::rules)
     for (uint32_t bl = blk_local * GEN_WAVES + wave; bl < sg.count; bl += seg_blocks * GEN_WAVES)
         generate_one(t, g, sg, bl, lane);
 }
@@ -672,14 +671,7 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
         return;
     }
     const uint32_t j = blockIdx.x - ga.k;
-    uint32_t cand = g.ext ? 0u : g.pick_idx[j];
-    if (!g.ext && g.d_pick)
-    {
-        const uint32_t pk = g.d_pick[g.pick_chain[j]];
-        if (pk == PICK_NONE)
-            return; // this chain accepted nothing: its tables stand (uniform for the workgroup: no barrier is skipped by some)
-        cand += pk;
-    }
+    const uint32_t cand = g.ext ? 0u : g.pick_idx[j];
     const uint32_t chain = g.ext ? (uint32_t)g.ext[j].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
     IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
     const int32_t n = g.n, nb = g.nb, K = g.K;
@@ -793,17 +785,18 @@ hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t s
     const size_t lds = (((size_t)4 * g.nb + 4 + 1) & ~(size_t)1) * sizeof(int32_t) + (size_t)g.nb * sizeof(uint2);
     if (lds > MAX_LDS_BYTES)
         return hipErrorInvalidValue; // the caller keeps the host path for trees this large
-    static bool raised_on[64];
+    // (the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raised once per device, whichever host
+    // thread gets there first - contexts may be driven from several threads)
+    static std::once_flag raised_on[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !raised_on[dev])
-    {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<uint16_t>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<int32_t>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-        raised_on[dev] = true;
-    }
+    if (dev >= 0 && dev < 64)
+        std::call_once(raised_on[dev], [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<uint16_t>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<int32_t>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        });
     if (g.idx_bytes == 2)
         hipLaunchKernelGGL(rebuild_tables_kernel<uint16_t>, dim3(k + ga.k), dim3(REBUILD_THREADS), lds, stream, g, ga);
     else
@@ -954,14 +947,13 @@ hipError_t launch_pair_sort(const PairArgs &args, hipStream_t stream)
     }
     g.cap = longest;
     const size_t lds = ((size_t)4 * longest + most_buckets + 1 + 64 + 2) * 4;
-    static bool raised_on[64];
+    static std::once_flag raised_on[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !raised_on[dev])
-    {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-        raised_on[dev] = true;
-    }
+    if (dev >= 0 && dev < 64)
+        std::call_once(raised_on[dev], [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        });
     if (lds > MAX_LDS_BYTES)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(pair_kernel, dim3(nblk), dim3(PAIR_THREADS), lds, stream, g);
@@ -975,22 +967,20 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
     // the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raise it once for each device a
     // context of this process launches on (the walk does the same per context, raise_lds_limit)
     static hipError_t raised_on[64];
-    static bool asked_on[64];
+    static std::once_flag asked_on[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     hipError_t raised = hipErrorInvalidDevice;
     if (dev >= 0 && dev < 64)
     {
-        if (!asked_on[dev])
-        {
+        std::call_once(asked_on[dev], [dev] {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<uint16_t, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<int32_t, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
             raised_on[dev] = e;
-            asked_on[dev] = true;
-        }
+        });
         raised = raised_on[dev];
     }
     const size_t lds_max = raised == hipSuccess ? (size_t)MAX_LDS_BYTES : (size_t)64 * 1024;

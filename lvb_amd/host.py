@@ -92,9 +92,6 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p]),
     "lvbhost_anneal_chains": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(AnnealParams),
                                         C.POINTER(AnnealResult), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
-    "lvbhost_anneal_chain_groups": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
-                                              C.POINTER(AnnealParams), C.POINTER(AnnealResult), C.c_void_p, C.c_void_p,
-                                              C.POINTER(C.c_int32)]),
     "lvbhost_starting_temperature": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(AnnealParams),
                                                C.POINTER(C.c_double)]),
     "lvbhost_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
@@ -410,38 +407,6 @@ def anneal_chains(ctx, trees: list[HostTree], params: list[AnnealParams], lib=No
         ctx._chk(rc)
     elif rc != 0:
         raise api.LvbGpuError(rc, "lvbhost_anneal_chains")
-    out = [{k: getattr(res[c], k) for k, _ in AnnealResult._fields_} for c in range(R)]
-    return out, [(float(secs[i]), int(best[i])) for i in range(nlog.value)]
-
-
-def deal_groups(R: int, G: int) -> list[int]:
-    """first[] of lvbhost_anneal_chain_groups: R chains dealt to G groups as evenly as they go, in order."""
-    G = max(1, min(G, R))
-    return [R * g // G for g in range(G + 1)]
-
-
-def anneal_chain_groups(ctxs, trees: list[HostTree], params: list[AnnealParams], first: list[int] | None = None, lib=None):
-    """The chains dealt to len(ctxs) groups that anneal SIDE BY SIDE (one context and one host thread per group,
-    lvbhost_anneal_chain_groups) -> ([result dict per chain], [(seconds, best over all chains), ...]).  One context:
-    the same as anneal_chains."""
-    lib = lib or load_library()
-    G, R = len(ctxs), len(trees)
-    first = first or deal_groups(R, G)
-    assert len(first) == G + 1 and first[0] == 0 and first[-1] == R
-    cap = max(int(params[0].log_cap), 0)
-    secs = np.zeros(max(cap, 1), dtype=np.float64)
-    best = np.zeros(max(cap, 1), dtype=np.int64)
-    chandles = (C.c_void_p * G)(*[getattr(c, "h", c) for c in ctxs])
-    handles = (C.c_void_p * R)(*[t.h for t in trees])
-    firsts = (C.c_int32 * (G + 1))(*first)
-    pars = (AnnealParams * R)(*params)
-    res = (AnnealResult * R)()
-    nlog = C.c_int32()
-    rc = lib.lvbhost_anneal_chain_groups(G, chandles, firsts, handles, pars, res, secs.ctypes.data, best.ctypes.data,
-                                         C.byref(nlog))
-    if rc != 0:
-        msgs = [c.last_error() for c in ctxs if hasattr(c, "last_error")]
-        raise api.LvbGpuError(rc, "lvbhost_anneal_chain_groups: " + "; ".join(m for m in msgs if m))
     out = [{k: getattr(res[c], k) for k, _ in AnnealResult._fields_} for c in range(R)]
     return out, [(float(secs[i]), int(best[i])) for i in range(nlog.value)]
 

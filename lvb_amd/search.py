@@ -222,6 +222,8 @@ def main(argv=None) -> int:
     ap.add_argument("--exact", action="store_true", help="reproduce the reference program's run for this seed")
     ap.add_argument("-N", dest="max_trees", type=int, default=0)
     a = ap.parse_args(argv)
+    if (a.chains > 1 or a.run_levels is not None) and (a.exact or a.host_proposals or a.max_trees):
+        ap.error("--chains / --run-levels run the multi-chain loop, which has no --exact, --host-proposals or -N")
     try:
         if a.exact:
             run_exact(a.infile, a.seed, a.algorithm, 0 if a.cooling == "g" else 1, a.device, a.out,

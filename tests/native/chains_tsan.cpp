@@ -1,8 +1,8 @@
-// tests/native/groups_tsan.cpp - lvbhost_anneal_chain_groups under ThreadSanitizer (CPU test tier).
-// Three groups of chains, each on a host thread of its own with a context of its own; the scorer is the TEST DOUBLE
-// (tests/cpu_double/lvbgpu_double.c: the oracle behind the lvbgpu_* calls the host makes - test tier only, never part
-// of the product).  What must hold: no data race between the groups' threads, and every chain ends where the same
-// chain ends when all chains run in ONE group on the calling thread.
+// tests/native/chains_tsan.cpp - lvbhost_anneal_chains with runs of acceptances under ThreadSanitizer (CPU test tier).
+// The hot chains' candidates are drawn, consumed and followed on several host threads (lvbgpu_parallel_for); the scorer
+// is the TEST DOUBLE (tests/cpu_double/lvbgpu_double.c: the oracle behind the lvbgpu_* calls the host makes - test tier
+// only, never part of the product).  What must hold: no data race between the chains' tasks, and every chain ends where
+// it ends with one move per step.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -42,10 +42,8 @@ int main()
             return 2;
     const int64_t min_len = lvbhost_min_tree_length(n, m, ptr.data());
 
-    auto run = [&](int G, std::vector<lvbhost_anneal_result> &res, int run_levels = 0) {
-        std::vector<lvbgpu_ctx *> ctxs;
-        for (int g = 0; g < G; g++)
-            ctxs.push_back(lvbgpu_double_new(n, nwords, enc.data()));
+    auto run = [&](std::vector<lvbhost_anneal_result> &res, int run_levels) {
+        lvbgpu_ctx *ctx = lvbgpu_double_new(n, nwords, enc.data());
         std::vector<lvbhost_tree *> trees;
         std::vector<lvbhost_anneal_params> pars((size_t)R);
         for (int c = 0; c < R; c++)
@@ -61,37 +59,20 @@ int main()
             pars[(size_t)c].log_cap = 32;
             pars[(size_t)c].run_levels = run_levels;
         }
-        std::vector<int32_t> first;
-        for (int g = 0; g <= G; g++)
-            first.push_back(R * g / G);
         std::vector<double> secs(32);
         std::vector<int64_t> best(32);
         int32_t nlog = 0;
         res.assign((size_t)R, lvbhost_anneal_result{});
-        const int rc = G == 1 ? lvbhost_anneal_chains(ctxs[0], R, trees.data(), pars.data(), res.data(), secs.data(), best.data(), &nlog)
-                              : lvbhost_anneal_chain_groups(G, ctxs.data(), first.data(), trees.data(), pars.data(), res.data(),
-                                                            secs.data(), best.data(), &nlog);
+        const int rc = lvbhost_anneal_chains(ctx, R, trees.data(), pars.data(), res.data(), secs.data(), best.data(), &nlog);
         for (auto *t : trees)
             lvbhost_tree_free(t);
-        for (auto *c : ctxs)
-            lvbgpu_double_free(c);
+        lvbgpu_double_free(ctx);
         return rc;
     };
-    std::vector<lvbhost_anneal_result> one, three;
-    if (run(1, one) != 0 || run(3, three) != 0)
-        return 3;
-    for (int c = 0; c < R; c++)
-        if (one[(size_t)c].best_length != three[(size_t)c].best_length || one[(size_t)c].final_length != three[(size_t)c].final_length ||
-            one[(size_t)c].consumed != three[(size_t)c].consumed || one[(size_t)c].accepted != three[(size_t)c].accepted ||
-            one[(size_t)c].device_steps != three[(size_t)c].device_steps || one[(size_t)c].topologies != three[(size_t)c].topologies)
-        {
-            printf("chain %d differs\n", c);
-            return 4;
-        }
     // runs of acceptances: the hot chains' candidates are drawn and consumed on several threads (lvbgpu_parallel_for):
     // no race between the chains' tasks, and a chain ends where it ends with one move per step
     std::vector<lvbhost_anneal_result> runs1, runs3;
-    if (run(1, runs1, 1) != 0 || run(1, runs3, 3) != 0)
+    if (run(runs1, 1) != 0 || run(runs3, 3) != 0)
         return 5;
     int64_t host_steps = 0;
     for (int c = 0; c < R; c++)

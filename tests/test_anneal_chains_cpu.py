@@ -80,49 +80,6 @@ def test_a_chains_trajectory_does_not_depend_on_the_chains_beside_it(double, alg
     assert log[-1][1] == min(r["best_length"] for r in many)
 
 
-def test_groups_side_by_side_give_every_chain_the_trajectory_it_has_alone(double):
-    """lvbhost_anneal_chain_groups: the chains dealt to groups with a context and a host thread each.  Every chain's
-    counters, final tree and kept trees are what ONE lock-stepped group gives it; the merged log only improves and ends
-    at the best length over all chains."""
-    from lvb_amd import host
-    lib, new_ctx, free_ctx = double
-    n, m = 20, 500
-    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 44), lib)
-    seeds = [11, 12, 13, 14, 15, 16, 17]
-    together, together_final, _ = run_chains(double, rows, min_len, n, seeds, 1200, 1)
-
-    def grouped(first):
-        G = len(first) - 1
-        ctxs = [new_ctx(rows) for _ in range(G)]
-        trees = [host.HostTree(n, seed=1000 + s, lib=lib) for s in seeds]
-        params = []
-        for s in seeds:
-            p = host.anneal_defaults(lib)
-            p.seed, p.algorithm, p.batch, p.t0, p.min_len_tree, p.max_proposals, p.log_cap = 7000 + s, 1, 64, 0.0, min_len, 1200, 64
-            params.append(p)
-        try:
-            res, log = host.anneal_chain_groups(ctxs, trees, params, first, lib=lib)
-            final = [(t.arrays()[1].copy(), t.arrays()[2].copy(), t.root, t.best_count()) for t in trees]
-        finally:
-            for t in trees:
-                t.close()
-            for c in ctxs:
-                free_ctx(c)
-        return res, final, log
-
-    for first in ([0, 3, 7], [0, 1, 2, 4, 7], [0, 7]):
-        res, final, log = grouped(first)
-        for c in range(len(seeds)):
-            assert {k: res[c][k] for k in KEYS} == {k: together[c][k] for k in KEYS}, (first, c)
-            assert np.array_equal(final[c][0], together_final[c][0]) and np.array_equal(final[c][1], together_final[c][1])
-            assert final[c][2:] == together_final[c][2:]
-        assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)
-        assert [t for t, _ in log] == sorted(t for t, _ in log)
-        assert log[-1][1] == min(r["best_length"] for r in res)
-        assert len({r["seconds"] for r in res}) == 1             # the run's wall time, the same for every chain
-        assert all(r["global_best_length"] == log[-1][1] for r in res)
-
-
 def test_chains_run_to_the_freezing_criterion_and_stop(double):
     """No proposal cap: every chain anneals until the reference's criterion freezes it (Solve.c:409-443), the run ends
     when the last one has, and a frozen chain's counters stand still while the others go on."""

@@ -640,37 +640,6 @@ def test_proposal_edits_are_refused_once_a_chain_commit_has_moved_the_tree(mods)
     ctx.close()
 
 
-def test_groups_side_by_side_on_the_gpu(mods):
-    """lvbhost_anneal_chain_groups on the HIP scorer: three contexts, three host threads, every chain's run equal to
-    what one lock-stepped group gives it (tests/test_anneal_chains_cpu.py holds the same on the CPU double)."""
-    api, host = mods
-    n, m = 40, 1500
-    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 91))
-    seeds = [3, 4, 5, 6, 7, 8, 9]
-    together, together_final, _ = _run_chains(api, host, rows, min_len, n, seeds, 2500, 1)
-    ctxs = [api.FitchContext(text_rows=rows) for _ in range(3)]
-    trees = [host.HostTree(n, seed=1000 + s) for s in seeds]
-    params = []
-    for s in seeds:
-        p = host.anneal_defaults()
-        p.seed, p.algorithm, p.batch, p.t0, p.min_len_tree, p.max_proposals, p.log_cap = 7000 + s, 1, 256, 0.0, min_len, 2500, 64
-        params.append(p)
-    res, log = host.anneal_chain_groups(ctxs, trees, params)
-    keys = ("start_length", "best_length", "final_length", "consumed", "accepted", "temperatures", "device_steps", "scored",
-            "reroots", "topologies", "t_final")
-    for c, t in enumerate(trees):
-        assert {k: res[c][k] for k in keys} == {k: together[c][k] for k in keys}, c
-        _, l, r = t.arrays()
-        assert np.array_equal(l, together_final[c][0]) and np.array_equal(r, together_final[c][1])
-        assert (t.root, t.best_count()) == together_final[c][2:]
-    assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)
-    assert log[-1][1] == min(r["best_length"] for r in res)
-    for t in trees:
-        t.close()
-    for c in ctxs:
-        c.close()
-
-
 def test_cfg2_chains_step_equals_single_chain_steps(mods):
     """BASELINE configs[1] (64 x 10 000, NNI, 1024 candidates) through the multi-chain step - R chains x 1024 candidates in
     one generator launch and one walk, which is how bench.py fills the chip at this shape - gives every chain exactly the
@@ -718,15 +687,12 @@ def _take(length, cur, t, minlen, seed, j):
     return u < p, abs(u - p)
 
 
-@pytest.mark.parametrize("device_decide", [True, False])
-def test_a_step_decides_and_commits_like_the_host_would(mods, device_decide, monkeypatch):
+def test_a_step_decides_and_commits_like_the_host_would(mods):
     """lvbgpu_chains_step_*: the accept decision rides with the batch.  Lengths are the plain step's; every chain's pick is
     the FIRST candidate decide.h's rule takes (checked against a restatement of the rule here); the accepted moves are
     committed - resident lengths, per-node changes, node sets, topologies and the next neighbourhoods equal a reference
-    context that committed the same picks through lvbgpu_chains_commit; the moves' rewrites are the candidates' own.  Both
-    ways: decided by the walk's watcher waves on the device, and by the library on the host (LVBGPU_DEVICE_DECIDE=0)."""
+    context that committed the same picks through lvbgpu_chains_commit; the moves' rewrites are the candidates' own."""
     api, host = mods
-    monkeypatch.setenv("LVBGPU_DEVICE_DECIDE", "1" if device_decide else "0")
     n, m, R = 60, 5000, 5
     rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 41))
     ctx, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)

@@ -21,11 +21,12 @@ def test_parallel_program_build_is_race_free_and_equals_serial(tmp_path):
     assert run.returncode == 0 and run.stdout.strip() == "ok", (run.returncode, run.stdout[-500:], run.stderr[-3000:])
 
 
-def test_chain_groups_on_threads_are_race_free_and_equal_one_group(tmp_path):
-    """lvbhost_anneal_chain_groups (a host thread and a context per group) under ThreadSanitizer, on the scorer's test
-    double: no race between the groups, and every chain ends where it ends in one lock-stepped group."""
+def test_runs_of_acceptances_on_threads_are_race_free(tmp_path):
+    """lvbhost_anneal_chains with runs of accepted moves (the hot chains' candidates drawn, consumed and followed on the
+    context's host threads) under ThreadSanitizer, on the scorer's test double: no race between the chains' tasks, and
+    every chain ends where it ends with one move per step."""
     from lvb_amd import build as product_build
-    exe = tmp_path / "groups_tsan"
+    exe = tmp_path / "chains_tsan"
     srcs = [str(ROOT / "lvb_amd" / "csrc" / s) for s in product_build.HOST_SOURCES]
     objs = []
     for c in (ROOT / "tests" / "cpu_double" / "lvbgpu_double.c", ROOT / "oracle" / "fitch_oracle.c"):
@@ -36,7 +37,7 @@ def test_chain_groups_on_threads_are_race_free_and_equal_one_group(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         objs.append(str(o))
     build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", f"-I{ROOT / 'include'}",
-                            str(ROOT / "tests" / "native" / "groups_tsan.cpp"), *srcs, *objs, "-o", str(exe)], capture_output=True, text=True)
+                            str(ROOT / "tests" / "native" / "chains_tsan.cpp"), *srcs, *objs, "-o", str(exe)], capture_output=True, text=True)
     if build.returncode != 0 and "tsan" in build.stderr.lower():
         pytest.skip("ThreadSanitizer runtime not installed")
     assert build.returncode == 0, build.stderr[-3000:]

@@ -1,5 +1,5 @@
-"""anneal_chains at 500 x 50k for a few (R, G): where does a step's time go (LVBHOST_PROFILE=1 prints each group's
-breakdown).  Arguments: R or R:G pairs (G groups side by side, lvbhost_anneal_chain_groups), e.g.  1 32 32:4 32:8"""
+"""anneal_chains at 500 x 50k for a few R: where does a step's time go (LVBHOST_PROFILE=1 prints the breakdown).
+Arguments: numbers of chains, e.g.  1 32"""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -11,8 +11,8 @@ from tests.synth import treelike_rows
 n, m = 500, 50000
 rows, min_len = host.prepare_alignment(treelike_rows(n, m, 3))
 for spec in [a for a in sys.argv[1:] if not a.startswith("--")] or ["1", "16"]:
-    R, G = (int(x) for x in spec.split(":")) if ":" in spec else (int(spec), 1)
-    ctxs = [api.FitchContext(text_rows=rows) for _ in range(G)]
+    R = int(spec)
+    ctx = api.FitchContext(text_rows=rows)
     trees = [host.HostTree(n, seed=(9 * 1000 + 1) * 100 + c) for c in range(R)]   # bench.py's default --anneal-seed 9: no straggler among 32
     ps = []
     for c in range(R):
@@ -24,14 +24,13 @@ for spec in [a for a in sys.argv[1:] if not a.startswith("--")] or ["1", "16"]:
             p.reroot_interval = 0   # upper bound of what cheaper re-roots could give (the trajectories change)
         ps.append(p)
     t0 = time.perf_counter()
-    res, log = host.anneal_chain_groups(ctxs, trees, ps) if G > 1 else host.anneal_chains(ctxs[0], trees, ps)
+    res, log = host.anneal_chains(ctx, trees, ps)
     dt = time.perf_counter() - t0
     # when the best length first got below a few marks (the reference program stands at ~3.9 M after 20 s)
     marks = {L: next((round(t, 3) for t, b in log if b <= L), None) for L in (5000000, 3900000, 3000000, 2600000)}
-    print(f"R={R} G={G}: {dt:.3f} s, scored/s {sum(r['scored'] for r in res)/dt:.0f}, consumed/s {sum(r['consumed'] for r in res)/dt:.0f}, "
+    print(f"R={R}: {dt:.3f} s, scored/s {sum(r['scored'] for r in res)/dt:.0f}, consumed/s {sum(r['consumed'] for r in res)/dt:.0f}, "
           f"steps {max(r['device_steps'] for r in res)}, best {min(r['best_length'] for r in res)}, frozen {sum(r['frozen'] for r in res)}, "
           f"seconds to length {marks}", flush=True)
     for t in trees:
         t.close()
-    for c in ctxs:
-        c.close()
+    ctx.close()
