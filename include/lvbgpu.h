@@ -303,9 +303,12 @@ int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms);
 /* test hook: counters of what results cannot show (they are the same either way): scoring walks launched two
  * candidates per wave (LVBGPU_PAIR=n when the context was created; fitch_walk_pair);
  * lvbgpu_chains_commit_edits calls that walked the SCORED programs of the last lvbgpu_chains_score_edits call
- * instead of building the accepted candidates' programs again */
+ * instead of building the accepted candidates' programs again; post launches (commit walk + table rebuilds of the
+ * chains' accepted moves and re-roots in one launch), and those of them in which the next batch's generator rode along */
 #define LVBGPU_COUNT_PAIRED_WALKS 0
 #define LVBGPU_COUNT_COMMITS_REUSING_PROGRAMS 1
+#define LVBGPU_COUNT_POST_LAUNCHES 2
+#define LVBGPU_COUNT_POST_LAUNCHES_WITH_GENERATOR 3
 int lvbgpu_debug_count(lvbgpu_ctx *ctx, int32_t what, int64_t *count);
 
 /* per-kernel timing for the roofline line: while enabled (every > 0), every `every`-th scoring walk the

@@ -235,6 +235,11 @@ class FitchContext:
         """chains_commit_edits calls that walked the scored programs of the last chains_score_edits call."""
         return self.debug_count(1)
 
+    def post_launches(self) -> tuple[int, int]:
+        """(post launches so far - the chains' commits and re-roots, all pending ones in one launch -, those of them that
+        carried the next batch's generator)."""
+        return self.debug_count(2), self.debug_count(3)
+
     def set_wait_limit(self, seconds: float) -> None:
         self._chk(self.lib.lvbgpu_set_wait_limit(self.h, float(seconds)))
 

@@ -750,6 +750,10 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         std::vector<int32_t> picks;
         size_t total = 0;
         bool active = false;
+        // the two batch slots take turns: the step being submitted draws into one while the chains' accepted candidates of
+        // the step before still lie in the other - their commit walk rides in the SAME launch as this step's generator
+        // (the library's post launch), which it could not if the generator overwrote their programs
+        int32_t slot = 0;
     } f;
     std::vector<lvbgpu_chain_root> roots;
     int64_t steps = 0, busy_scored = 0;
@@ -942,7 +946,8 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             f.lens.resize(f.total);
             f.picks.resize(f.draws.size());
             auto td = Clock::now();
-            r = lvbgpu_chains_step_submit(ctx, 0, (int32_t)f.draws.size(), f.draws.data(), f.rules.data());
+            f.slot ^= 1;
+            r = lvbgpu_chains_step_submit(ctx, f.slot, (int32_t)f.draws.size(), f.draws.data(), f.rules.data());
             dev_seconds += since(td);
             t_score += since(td);
             t_submit += since(td);
@@ -999,7 +1004,7 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             return LVBGPU_OK;
         f.active = false;
         auto td = Clock::now();
-        int r = lvbgpu_chains_step_collect(ctx, 0, f.lens.data(), f.picks.data());
+        int r = lvbgpu_chains_step_collect(ctx, f.slot, f.lens.data(), f.picks.data());
         dev_seconds += since(td);
         t_score += since(td);
         if (r != LVBGPU_OK)

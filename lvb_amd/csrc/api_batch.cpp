@@ -381,7 +381,7 @@ extern "C" int lvbgpu_batch_build(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
     *out = nullptr;
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     lvbgpu_batch *bt = new (std::nothrow) lvbgpu_batch();
     if (!bt)
         return LVBGPU_E_NOMEM;
@@ -408,7 +408,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
     // that no longer mean what its programs assume (whole-topology batches read leaf rows only and stay valid)
     if (!b->full_mode && !b->spans_chains && (b->chain >= ctx->nchains || b->topo_version != ctx->version_of(b->chain)))
         return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since this batch was built");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     if (!b->len_zeroed) // the whole buffer: a direct step's last wave re-zeroes only the B slots it used
         HIPCHK(ctx, hipMemsetAsync(b->d_len.p, 0, b->recycled ? b->d_len.cap : (size_t)b->B * 8, ctx->stream));
     b->len_zeroed = false;
@@ -504,7 +504,7 @@ extern "C" int lvbgpu_batch_lengths(lvbgpu_ctx *ctx, lvbgpu_batch *b, int64_t *l
         return LVBGPU_E_ARG;
     if (!b->launched)
         return ctx->fail(LVBGPU_E_STATE, "this batch was never launched: call lvbgpu_batch_launch first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     if (b->direct)
     {
         HIPCHK(ctx, wait_for_direct_step(ctx));
@@ -582,7 +582,7 @@ extern "C" int lvbgpu_score_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t *edi
     }
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     // recycled batches owned by the context: a search calls this every step, so no allocation here.  A big batch
     // is cut into STEP_PIPELINE pieces: while the device walks one piece the host threads build the next, so the
     // device time of all but the last piece hides behind program building (the larger part of such a step).
@@ -689,7 +689,7 @@ extern "C" int lvbgpu_chains_score_edits(lvbgpu_ctx *ctx, int32_t B, const int32
         if (rf != LVBGPU_OK)
             return rf;
     }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     struct Parked
     {
         lvbgpu_ctx *c;
@@ -754,7 +754,7 @@ extern "C" int lvbgpu_score_full_batch(lvbgpu_ctx *ctx, int32_t B, const int32_t
 {
     if (!ctx || B < 1 || !left || !right || !lengths_out)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     if (!ctx->full_batch)
     {
         ctx->full_batch = new (std::nothrow) lvbgpu_batch();

@@ -7,7 +7,7 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
 {
     if (!ctx || !tree_v || !length_out)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     RefNode *tree = (RefNode *)tree_v;
     const int32_t nb = ctx->nb, n = (int32_t)ctx->n;
     const uint32_t W = (uint32_t)ctx->nwords, Wp = ctx->stride_words;
@@ -120,6 +120,7 @@ extern "C" int lvbgpu_getplen_compat(lvbgpu_ctx *ctx, void *tree_v, long root, i
     a.len_out = (unsigned long long *)ctx->d_cout.p;
     a.changes_out = (unsigned long long *)((char *)ctx->d_cout.p + oo_ch);
     a.root_slot = n_out;
+    a.n_first = UINT32_MAX; // one program block
     a.in_stride4 = Wp / 2;                // the staging arenas are row-major
     a.in_tile_bytes = 1024;
     a.block_bytes = (uint64_t)n_in * Wp * 8u;

@@ -65,6 +65,7 @@ WalkArgs resident_args(lvbgpu_ctx *ctx, const void *prog, size_t off_toks, size_
     a.nitems = B * a.ngroups;
     a.stack_depth = (uint32_t)std::max(max_stack, 1);
     a.root_slot = ctx->rows_total(); // + the candidate's chain
+    a.n_first = UINT32_MAX;          // one program block
     return a;
 }
 
@@ -102,9 +103,7 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
             ctx->wait_limit_s = atof(wl);
     // (row offsets are 64-bit in the kernels: the tree block is limited by HBM, not by index width)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
     ctx->nchains = 1;
@@ -276,8 +275,6 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->comm)
         (void)lvbgpu_comm_destroy(ctx);
-    if (ctx->side_stream)
-        (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream)
@@ -299,8 +296,6 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
             (void)hipEventDestroy(ps.done_ev);
         if (ps.walk_ev)
             (void)hipEventDestroy(ps.walk_ev);
-        if (ps.gen_ev)
-            (void)hipEventDestroy(ps.gen_ev);
         ps.d_keys.release();
         ps.h_flag.release();
     }
@@ -353,10 +348,6 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1)
         (void)hipEventDestroy(ctx->ev1);
-    if (ctx->side_ev)
-        (void)hipEventDestroy(ctx->side_ev);
-    if (ctx->side_stream)
-        (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream)
@@ -574,9 +565,7 @@ extern "C" int lvbgpu_set_chains(lvbgpu_ctx *ctx, int32_t nchains)
         if (rf != LVBGPU_OK)
             return rf;
     }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->side_stream));
-    ctx->side_pending = false;
+    ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     if ((uint64_t)(ctx->n + (long)nchains * (ctx->n - 3)) >= (uint64_t)MAX_ROWS)
@@ -666,7 +655,7 @@ extern "C" int lvbgpu_set_tree(lvbgpu_ctx *ctx, const int32_t *left, const int32
         if (rf != LVBGPU_OK)
             return rf;
     }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     std::string why;
     Topology t;
     if (!t.assign((int32_t)ctx->n, left, right, root, &why))
@@ -693,7 +682,7 @@ extern "C" int lvbgpu_current_length(lvbgpu_ctx *ctx, int64_t *length_out)
         return LVBGPU_E_ARG;
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     const int rc = read_current_length(ctx);
     if (rc != LVBGPU_OK)
         return rc;
@@ -729,7 +718,7 @@ extern "C" int lvbgpu_get_changes(lvbgpu_ctx *ctx, int64_t *changes)
         return LVBGPU_E_ARG;
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     memset(changes, 0, (size_t)ctx->n * 8); // leaves hold nothing
     HIPCHK(ctx, hipMemcpyAsync(changes + ctx->n, ctx->d_changes + ctx->row_of((int32_t)ctx->n), (size_t)ctx->chain_rows() * 8,
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -743,7 +732,7 @@ extern "C" int lvbgpu_get_sets(lvbgpu_ctx *ctx, int32_t node, uint64_t *out)
         return LVBGPU_E_ARG;
     if (node >= ctx->n && !ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     // resident rows are bit planes; hand back the reference's nibble layout
     HIPCHK(ctx, ctx->d_export.reserve((size_t)ctx->stride_words * 8));
     HIPCHK(ctx, launch_export_row((const uint4 *)ctx->d_rows, ctx->row_of(node), ctx->rows_total(), ctx->ntiles,
@@ -767,7 +756,7 @@ extern "C" int lvbgpu_commit(lvbgpu_ctx *ctx, int32_t n_edits, const lvbgpu_edit
     }
     if (!ctx->have_tree)
         return ctx->fail(LVBGPU_E_STATE, "no resident tree: call lvbgpu_set_tree first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     std::string why;
     Program prog;
     if (!ctx->pb.build_candidate(ctx->topo, reinterpret_cast<const Edit *>(edits), n_edits, root, prog, &why))
@@ -796,7 +785,7 @@ extern "C" int lvbgpu_timer_start(lvbgpu_ctx *ctx)
 {
     if (!ctx)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return LVBGPU_OK;
 }
@@ -805,7 +794,7 @@ extern "C" int lvbgpu_timer_stop(lvbgpu_ctx *ctx, float *elapsed_ms)
 {
     if (!ctx || !elapsed_ms)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
@@ -834,7 +823,7 @@ extern "C" int lvbgpu_walk_timing(lvbgpu_ctx *ctx, int enable)
 {
     if (!ctx || enable < 0)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     if (enable)
     {
         for (hipEvent_t &ev : ctx->wt_ev)
@@ -857,7 +846,7 @@ extern "C" int lvbgpu_walk_timing_read(lvbgpu_ctx *ctx, double *total_ms, int64_
 {
     if (!ctx || !total_ms || !launches)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     const int rc = walk_timing_drain(ctx);
     if (rc != LVBGPU_OK)
         return rc;
@@ -870,7 +859,7 @@ extern "C" int lvbgpu_probe_l2(lvbgpu_ctx *ctx, int32_t B, int32_t rows_per_wave
 {
     if (!ctx || !gb_per_s || B < 1 || rows_per_wave < 8 || reps < 1 || (uint64_t)B * ctx->ntiles >= (1ull << 31))
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     HIPCHK(ctx, ctx->d_probe_sink.reserve(64));
     const uint32_t ngroups = choose_groups((uint32_t)B, ctx->ntiles, ctx->target_waves);
     double best = 0.0;
@@ -912,9 +901,8 @@ extern "C" int lvbgpu_synchronize(lvbgpu_ctx *ctx)
         if (rf != LVBGPU_OK)
             return rf;
     }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->side_stream)); // table rebuilds of the last commit / re-root
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     return LVBGPU_OK;
 }
@@ -940,6 +928,8 @@ extern "C" int lvbgpu_debug_count(lvbgpu_ctx *ctx, int32_t what, int64_t *count)
     {
     case LVBGPU_COUNT_PAIRED_WALKS: *count = ctx->paired_walks; break;
     case LVBGPU_COUNT_COMMITS_REUSING_PROGRAMS: *count = ctx->commits_reusing_programs; break;
+    case LVBGPU_COUNT_POST_LAUNCHES: *count = ctx->post_launches; break;
+    case LVBGPU_COUNT_POST_LAUNCHES_WITH_GENERATOR: *count = ctx->post_launches_with_generator; break;
     default: return LVBGPU_E_ARG;
     }
     return LVBGPU_OK;
@@ -949,7 +939,7 @@ extern "C" int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms)
 {
     if (!ctx || ms < 1 || ms > 2000)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     HIPCHK(ctx, launch_stall(ctx->stream, (uint32_t)ms));
     return LVBGPU_OK;
 }

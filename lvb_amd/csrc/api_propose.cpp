@@ -246,16 +246,6 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     if ((uint64_t)total * stride_t >= (1ull << 32) || (uint64_t)total * ctx->ntiles >= (1ull << 31))
         return ctx->fail(LVBGPU_E_ARG, "batch too large");
     const int32_t B = (int32_t)total;
-    // Tables being rebuilt on the side stream (an accepted move or a re-root just before this call): before an upload
-    // below could be overtaken by them, and before the generator reads them.  (Round 3 tried the generator BEHIND the
-    // rebuild on the side stream, beside the commit walk, with only the scoring walk waiting for both: 2-5 us per step
-    // SLOWER - a second cross-stream hand-over costs more than the 10-17 us of generator it hides;
-    // profiles/experiments/r03_anneal_step.md)
-    if (ctx->side_pending)
-    {
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev, 0));
-        ctx->side_pending = false;
-    }
     int rc = prepare_tables(ctx, chains.data(), k);
     if (rc != LVBGPU_OK)
         return rc;
@@ -269,8 +259,6 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         HIPCHK(ctx, hipEventCreateWithFlags(&ps.done_ev, hipEventDisableTiming));
     if (!ps.walk_ev)
         HIPCHK(ctx, hipEventCreateWithFlags(&ps.walk_ev, hipEventDisableTiming));
-    if (!ps.gen_ev)
-        HIPCHK(ctx, hipEventCreateWithFlags(&ps.gen_ev, hipEventDisableTiming));
     lvbgpu_batch *bt = ps.batch;
     const size_t o_t = align16((size_t)B * sizeof(CandDesc));
     const size_t o_d = o_t + align16((size_t)B * stride_t * 4);
@@ -369,6 +357,8 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     GenArgs ga{};
     ga.tables = ctx->d_topo4.p;
     ga.idx_bytes = ctx->gen_idx_bytes;
+    ga.table_stride = ctx->gen_table_stride;
+    ga.K = ctx->gen_kmax;
     ga.n = (int32_t)ctx->n;
     ga.nb = ctx->nb;
     ga.leaf_order_len = (uint32_t)ctx->n;
@@ -412,16 +402,14 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         GenSeg &sg = ga.seg[i];
         sg.start = start;
         sg.count = (uint32_t)d.count;
-        sg.kind_all = d.kind;
+        sg.kind_all = (int8_t)d.kind;
         sg.mix_a = d.mix_a;
         sg.mix_b = d.mix_b;
         sg.seed_lo = (uint32_t)d.seed;
         sg.seed_hi = (uint32_t)(d.seed >> 32);
-        sg.table_off = (uint32_t)d.chain * ctx->gen_table_stride;
-        sg.table_bytes = cs.gen_table_bytes;
         sg.root = cs.topo.root;
-        sg.chain = (uint16_t)d.chain;
-        sg.K = (uint16_t)cs.gen_K;
+        sg.chain = (uint8_t)d.chain;
+        ga.table_bytes = std::max(ga.table_bytes, cs.gen_table_bytes); // (the same for every tree of these taxa)
         ps.segs.push_back({d.chain, (int32_t)start, d.count, cs.topo_version});
         start += (uint32_t)d.count;
     }
@@ -429,7 +417,29 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     // stream of its own: measured at B = 4096 the walk then takes 100 us instead of 88 - the generator's workgroups
     // hold LDS and wave slots - and the step gains nothing over queueing behind it; with that stream at the lowest
     // priority a step takes 161 us.  profiles/experiments/r02_walk_and_step.md)
-    HIPCHK(ctx, launch_propose(ga, ctx->stream));
+    // What the chains' last commits and re-roots left pending goes out NOW, and the generator with it: one post launch
+    // (commit walk + table rebuilds + this generator, whose segments wait for their chains' rebuilds) instead of up to
+    // five launches on two streams.  Not when the accepted candidates' programs lie in this very slot's buffers, which the
+    // generator is about to overwrite, or when the moves are named by the host (their list is read beside the tables).
+    if (ctx->pend.any())
+    {
+        const bool same_buffers = ctx->pend.k_pick > 0 && ctx->pend.src_slot == slot;
+        if (!same_buffers && !moves && post_can_generate(ga))
+            rc = flush_pending(ctx, &ga);
+        else
+        {
+            rc = flush_pending(ctx, nullptr);
+            if (rc == LVBGPU_OK)
+                HIPCHK(ctx, launch_propose(ga, ctx->stream));
+        }
+        if (rc != LVBGPU_OK)
+        {
+            ps.segs.clear();
+            return rc;
+        }
+    }
+    else
+        HIPCHK(ctx, launch_propose(ga, ctx->stream));
     if (pair_up)
     {
         PairArgs pa{};
@@ -651,7 +661,7 @@ extern "C" int lvbgpu_debug_generator_stamps(lvbgpu_ctx *ctx, unsigned long long
 {
     if (!ctx || !out2048 || !ctx->d_gen_prof.p)
         return LVBGPU_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(out2048, ctx->d_gen_prof.p, 256 * 8 * 8, hipMemcpyDeviceToHost));
     return LVBGPU_OK;
@@ -683,6 +693,12 @@ int resolve_follow(lvbgpu_ctx *ctx)
     lvbgpu_ctx::Follow &f = ctx->follow;
     if (!f.pending)
         return LVBGPU_OK;
+    if (ctx->pend.k_pick) // the records are sent by the post launch, which has not been given to the device yet
+    {
+        const int rp = flush_pending(ctx, nullptr);
+        if (rp != LVBGPU_OK)
+            return rp;
+    }
     f.pending = false;
     const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
     const size_t o_out = 64 + align16((size_t)MAX_CHAINS * 4);
@@ -728,12 +744,13 @@ int settle(lvbgpu_ctx *ctx)
 
 hipError_t take_pick_slot(lvbgpu_ctx *ctx, int *slot)
 {
+    // (not the slot whose records the host has yet to read: lvbgpu_ctx::follow)
+    if (ctx->follow.pending && ctx->follow.slot == ctx->pick_slot)
+        ctx->pick_slot = (ctx->pick_slot + 1) % lvbgpu_ctx::PICK_SLOTS;
     const int s = ctx->pick_slot;
     if (ctx->pick_used[s] && ctx->collected_ord <= ctx->pick_use_ord[s])
     {
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(ctx->side_stream);
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess)
             return e;
         for (int i = 0; i < lvbgpu_ctx::PICK_SLOTS; i++)
@@ -746,10 +763,9 @@ hipError_t take_pick_slot(lvbgpu_ctx *ctx, int *slot)
     return hipSuccess;
 }
 
-// A table rebuild (side stream) rewrites the generator's tables of the listed chains in place.  A batch that is still
-// in flight may have been drawn from one of those chains (a chain may sit in both slots; the commit makes that batch's
-// candidates of the chain stale, but its generator may not even have run yet): the rebuild must not start before that
-// generator is done, or the generator reads torn tables - paths and programs from garbage, walked by the scoring kernel.
+// (A table rebuild rewrites the generator's tables of its chains in place; it runs in the post launch on the MAIN stream,
+// behind every generator that was submitted before it - a batch in the other slot may have been drawn from the same
+// chain - and in front of every later one: no generator ever reads torn tables.)
 // lvbgpu_proposal_edits names candidates of slot 0's last single-chain batch relative to the tree they were drawn
 // from: once that chain's tree has moved (and its device tables with it, so the version test there no longer sees it)
 // their rewrites mean nothing
@@ -760,87 +776,89 @@ void forget_named_candidates(lvbgpu_ctx *ctx, uint64_t chain_mask)
         p0.p_B = 0;
 }
 
-hipError_t order_rebuild_after_readers(lvbgpu_ctx *ctx, uint64_t chain_mask)
-{
-    for (lvbgpu_ctx::PropSlot &other : ctx->pslot)
-    {
-        if (!other.in_flight)
-            continue;
-        bool reads = false;
-        for (const lvbgpu_ctx::PSeg &sg : other.segs)
-            reads |= ((chain_mask >> sg.chain) & 1u) != 0;
-        if (!reads)
-            continue;
-        // mark the main stream where it stands now - behind that batch's generator (and its walk) - and hold the side
-        // stream back until then.  Only here, where it is needed: an event per submit would cost every step of the
-        // bench's pipelined loop a few microseconds of host time.
-        const hipError_t er = hipEventRecord(other.gen_ev, ctx->stream);
-        if (er != hipSuccess)
-            return er;
-        const hipError_t e = hipStreamWaitEvent(ctx->side_stream, other.gen_ev, 0);
-        if (e != hipSuccess)
-            return e;
-    }
-    return hipSuccess;
-}
 } // namespace lvbgpu_detail
 
 
 namespace lvbgpu_detail
 {
-// What accepted candidates of the batch in `ps` need on the device, enqueued (nothing is waited for): their descriptors
-// and rewrites on the way into a pinned slot (gather), the generator's tables of their chains rebuilt (side stream), and
-// their own device-built programs walked in commit form (main stream).  where[j] is the batch position of pick j.
-int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const uint32_t *where, const int32_t *chains, uint64_t chain_mask,
-                   int *slot_out, uint32_t *seq_out, bool *tables_on_device_out)
+// the layout of a pinned slot that receives picked candidates' records: [flag][gap][k x (descriptor + rewrites)]
+static inline uint32_t pick_record_stride(const lvbgpu_ctx *ctx)
 {
-    lvbgpu_batch *bt = ps.batch;
-    // a pinned slot: [flag][picks][k x (descriptor + rewrites)]
-    const uint32_t out_stride = (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
-    const size_t o_out = 64 + align16((size_t)MAX_CHAINS * 4); // (the flag, a gap the picks used to lie in, the records)
-    int slot = 0;
-    HIPCHK(ctx, take_pick_slot(ctx, &slot));
-    HIPCHK(ctx, ctx->h_pick[slot].reserve(o_out + (size_t)MAX_CHAINS * out_stride));
-    char *h = (char *)ctx->h_pick[slot].p;
-    uint32_t *flag = (uint32_t *)h;
-    const uint32_t seq = ++ctx->pick_seq;
-    const size_t old_done = ctx->d_done.cap;
-    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
-    if (ctx->d_done.cap != old_done) // once per context: both streams below use it
+    return (uint32_t)align16(sizeof(ProposalInfo) + (size_t)ctx->p_stride_e * sizeof(lvbgpu_edit_dev));
+}
+static constexpr size_t PICK_RECORDS_AT = 64 + ((size_t)MAX_CHAINS * 4 + 15) / 16 * 16;
+
+// Give the device what lvbgpu_ctx::pend holds, as ONE post launch on the main stream (kernels.hpp PostArgs): the commit
+// walk of the accepted candidates' own device-built programs and of the host-built programs (re-roots, host-made
+// candidates), the table rebuilds of the chains that moved (wave 0 of an accepted candidate's workgroup first sends its
+// record to the host), and - gen != null - the NEXT batch's generator, whose segments wait for their chains' rebuilds.
+int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
+{
+    lvbgpu_ctx::Pending &pd = ctx->pend;
+    if (!pd.any() && !gen)
+        return LVBGPU_OK;
+    const lvbgpu_ctx::Pending q = pd; // (whatever happens below, nothing stays pending)
+    pd = lvbgpu_ctx::Pending{};
+    PostArgs pa{};
+    const int32_t k = q.k_pick + q.k_ext;
+    const char *hx = q.k_ext ? (const char *)ctx->h_pick[q.ext_slot].p : nullptr;
+    if (k)
     {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t old_done = ctx->d_done.cap;
+        HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
+        if (ctx->d_done.cap != old_done) // once per context
+        {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
+        if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
+        {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
+            ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
+        }
+        HIPCHK(ctx, ctx->d_len.reserve(8));
+        // the host-built programs: read where they lie (pinned) while that is little, else copied first
+        const void *xprog = hx;
+        if (q.k_ext)
+        {
+            const uint32_t ngroups = choose_groups((uint32_t)k, ctx->ntiles, ctx->target_waves);
+            if (!(ctx->direct_steps && q.ext_o_x * ngroups <= DIRECT_READ_MAX_BYTES))
+            {
+                HIPCHK(ctx, ctx->d_commit[0].reserve(q.ext_o_x));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->d_commit[0].p, hx, q.ext_o_x, hipMemcpyHostToDevice, ctx->stream));
+                xprog = ctx->d_commit[0].p;
+            }
+        }
+        WalkArgs a;
+        if (q.k_pick)
+        {
+            lvbgpu_batch *bt = ctx->pslot[q.src_slot].batch;
+            a = resident_args(ctx, bt->d_prog.p, bt->off_toks, bt->off_dsts, ctx->d_len.p, (uint32_t)k, std::max(1, q.ext_max_stack));
+            a.use_pick = 1;
+            memcpy(a.pick_idx, q.where, (size_t)q.k_pick * 4);
+            if (q.k_ext)
+            {
+                a.n_first = (uint32_t)q.k_pick;
+                a.cands2 = (const CandDesc *)xprog;
+                a.toks2 = (const uint32_t *)((const char *)xprog + q.ext_o_t);
+                a.dsts2 = (const int32_t *)((const char *)xprog + q.ext_o_d);
+            }
+        }
+        else
+            a = resident_args(ctx, xprog, q.ext_o_t, q.ext_o_d, ctx->d_len.p, (uint32_t)k, q.ext_max_stack);
+        a.s_all_out = (unsigned long long *)ctx->d_scalars;
+        a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
+        a.tmp_stride = (uint32_t)(ctx->nb + 1);
+        a.done_count = (uint32_t *)ctx->d_done.p;
+        pa.commit = a;
     }
-    uint32_t *done = (uint32_t *)ctx->d_done.p;
-    // 1. what the host needs to follow the moves (so that it can work while the walk runs): descriptors and rewrites
-    //    are complete - the batch's lengths have been read - and nothing here touches state sets, so the gather runs
-    //    beside the commit walk; as the first workgroups of the table rebuild's launch where there is one (1b), else
-    //    as a launch of its own
-    GatherArgs gat{};
-    memcpy(gat.pick_idx, where, (size_t)k * 4);
-    gat.k = (uint32_t)k;
-    gat.info = (const ProposalInfo *)ps.d_pinfo.p;
-    gat.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
-    gat.stride_e = ctx->p_stride_e;
-    gat.out = h + o_out;
-    gat.out_stride = out_stride;
-    gat.flag = flag;
-    gat.seq = seq;
-    gat.arrived = done + MAX_CHAINS;
-    // 1b. the generator's tables of the picked chains follow their moves on the device (they describe the trees the
-    //     candidates were drawn from: the picks were checked against the chains' versions above)
-    bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
-    for (int32_t j = 0; j < k && tables_on_device; j++)
-        tables_on_device = ctx->parked[(size_t)chains[j]].d_topo_version == ctx->parked[(size_t)chains[j]].topo_version;
-    // Which first?  Both are launches of this call; the one enqueued second starts ~8 us later (a launch and an event
-    // record of host time).  The commit walk is the longer one when many chains accept together (32 picks: 28 us against
-    // the rebuild's 16), the rebuild when one chain does (8-20 us against 7-15).
-    static const int commit_first_env = [] { const char *e = getenv("LVBGPU_COMMIT_FIRST"); return e ? atoi(e) : -1; }();
-    const bool commit_first = commit_first_env >= 0 ? commit_first_env != 0 : k >= 4;
-    auto side_part = [&]() -> int {
-    if (tables_on_device)
+    // the tables: accepted candidates' chains (rewrites from the batch they were drawn in), then the host-named moves'
+    const bool reb_picks = q.k_pick && q.pick_rebuild, reb_ext = q.k_ext && q.ext_rebuild;
+    uint64_t rebuilt = 0;
+    if (q.k_pick || reb_ext)
     {
-        RebuildArgs ra{};
+        RebuildArgs &ra = pa.reb;
         ra.tables = ctx->d_topo4.p;
         ra.table_stride = ctx->gen_table_stride;
         ra.idx_bytes = ctx->gen_idx_bytes;
@@ -848,52 +866,100 @@ int enqueue_accept(lvbgpu_ctx *ctx, lvbgpu_ctx::PropSlot &ps, int32_t k, const u
         ra.nb = ctx->nb;
         ra.K = ctx->gen_kmax;
         ra.leaf_order_len = (uint32_t)ctx->n;
-        memcpy(ra.pick_idx, where, (size_t)k * 4);
-        ra.cands = (const CandDesc *)bt->d_prog.p;
-        ra.info = (const ProposalInfo *)ps.d_pinfo.p;
-        ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
-        ra.stride_e = ctx->p_stride_e;
-        HIPCHK(ctx, order_rebuild_after_readers(ctx, chain_mask));
-        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream, &gat));
-        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
-        ctx->side_pending = true;
+        ra.n_pick = (uint32_t)q.k_pick;
+        ra.rebuild_picks = reb_picks ? 1u : 0u;
+        pa.n_reb = (uint32_t)q.k_pick + (reb_ext ? (uint32_t)q.k_ext : 0u);
+        if (q.k_pick)
+        {
+            lvbgpu_ctx::PropSlot &ps = ctx->pslot[q.src_slot];
+            memcpy(ra.pick_idx, q.where, (size_t)q.k_pick * 4);
+            ra.cands = (const CandDesc *)ps.batch->d_prog.p;
+            ra.info = (const ProposalInfo *)ps.d_pinfo.p;
+            ra.edits = (const lvbgpu_edit_dev *)ps.d_pedits.p;
+            ra.stride_e = ctx->p_stride_e;
+            // ... and their records on the way to the host (the host follows the moves while the device works)
+            GatherArgs &gat = pa.gat;
+            char *h = (char *)ctx->h_pick[q.gather_slot].p;
+            memcpy(gat.pick_idx, q.where, (size_t)q.k_pick * 4);
+            gat.k = (uint32_t)q.k_pick;
+            gat.info = ra.info;
+            gat.edits = ra.edits;
+            gat.stride_e = ctx->p_stride_e;
+            gat.out = h + PICK_RECORDS_AT;
+            gat.out_stride = pick_record_stride(ctx);
+            gat.flag = (uint32_t *)h;
+            gat.seq = q.gather_seq;
+            gat.arrived = (uint32_t *)ctx->d_done.p + MAX_CHAINS;
+            if (reb_picks)
+                for (int32_t j = 0; j < q.k_pick; j++)
+                    rebuilt |= 1ull << q.pick_chain[j];
+        }
+        if (reb_ext)
+        {
+            ra.ext = (const RebuildExt *)(hx + q.ext_o_x);
+            ra.ext_edits = (const lvbgpu_edit_dev *)(hx + q.ext_o_e);
+            for (int32_t j = 0; j < q.k_ext; j++)
+                rebuilt |= 1ull << ((const RebuildExt *)(hx + q.ext_o_x))[j].chain;
+        }
     }
-    else
-        HIPCHK(ctx, launch_gather_picks(gat, ctx->side_stream));
-        return LVBGPU_OK;
-    };
-    auto commit_part = [&]() -> int {
-    // 2. the picked candidates' own programs in commit form: produced sets and change counts go to their chains'
-    //    rows, every candidate's last wave settles its chain's changes[] and S_all (fused commit)
-    HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
-    if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
+    if (gen)
     {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
-        ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
+        pa.gen = *gen;
+        uint32_t waits = 0;
+        for (uint32_t i = 0; i < pa.gen.nseg; i++)
+        {
+            pa.gen.seg[i].wait = ((rebuilt >> pa.gen.seg[i].chain) & 1u) ? 1 : 0;
+            waits += pa.gen.seg[i].wait;
+        }
+        if (waits)
+        {
+            const size_t old = ctx->d_table_ready.cap;
+            HIPCHK(ctx, ctx->d_table_ready.reserve((size_t)MAX_CHAINS * 4));
+            if (ctx->d_table_ready.cap != old)
+                HIPCHK(ctx, hipMemsetAsync(ctx->d_table_ready.p, 0, ctx->d_table_ready.cap, ctx->stream));
+            if (++ctx->post_seq == 0u)
+                ctx->post_seq = 1u;
+            pa.gen.table_ready = (const uint32_t *)ctx->d_table_ready.p;
+            pa.gen.ready_seq = ctx->post_seq;
+            pa.reb.table_ready = (uint32_t *)ctx->d_table_ready.p;
+            pa.reb.ready_seq = ctx->post_seq;
+        }
+        ctx->post_launches_with_generator++;
     }
-    HIPCHK(ctx, ctx->d_len.reserve(8));
-    WalkArgs a = resident_args(ctx, bt->d_prog.p, bt->off_toks, bt->off_dsts, ctx->d_len.p, (uint32_t)k, 1);
-    a.use_pick = 1;
-    memcpy(a.pick_idx, where, (size_t)k * 4);
-    a.s_all_out = (unsigned long long *)ctx->d_scalars;
-    a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
-    a.tmp_stride = (uint32_t)(ctx->nb + 1);
-    a.done_count = done;
-    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
+    ctx->post_launches++;
+    HIPCHK(ctx, launch_post(pa, ctx->stream));
+    return LVBGPU_OK;
+}
 
-        return LVBGPU_OK;
-    };
+// Accepted candidates of the batch in slot `src_slot` join what is pending; where[j] is the batch position of pick j.
+int defer_picks(lvbgpu_ctx *ctx, int src_slot, int32_t k, const uint32_t *where, const int32_t *chains, uint64_t chain_mask,
+                int *slot_out, uint32_t *seq_out, bool *tables_on_device_out)
+{
+    lvbgpu_ctx::Pending &pd = ctx->pend;
+    if (pd.k_pick || (pd.chains & chain_mask)) // one batch's picks and one move per chain in a launch
     {
-        const int r1 = commit_first ? commit_part() : side_part();
-        if (r1 != LVBGPU_OK)
-            return r1;
-        const int r2 = commit_first ? side_part() : commit_part();
-        if (r2 != LVBGPU_OK)
-            return r2;
+        const int rf = flush_pending(ctx, nullptr);
+        if (rf != LVBGPU_OK)
+            return rf;
     }
-
+    int slot = 0;
+    HIPCHK(ctx, take_pick_slot(ctx, &slot));
+    HIPCHK(ctx, ctx->h_pick[slot].reserve(PICK_RECORDS_AT + (size_t)MAX_CHAINS * pick_record_stride(ctx)));
+    // the generator's tables of the picked chains follow their moves on the device where they describe the trees the
+    // candidates were drawn from (the picks were checked against the chains' versions by the caller)
+    bool tables_on_device = (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
+    for (int32_t j = 0; j < k && tables_on_device; j++)
+        tables_on_device = ctx->parked[(size_t)chains[j]].d_topo_version == ctx->parked[(size_t)chains[j]].topo_version;
+    pd.k_pick = k;
+    pd.src_slot = src_slot;
+    memcpy(pd.where, where, (size_t)k * 4);
+    memcpy(pd.pick_chain, chains, (size_t)k * 4);
+    pd.pick_rebuild = tables_on_device;
+    pd.gather_slot = slot;
+    pd.gather_seq = ++ctx->pick_seq;
+    pd.chains |= chain_mask;
     *slot_out = slot;
-    *seq_out = seq;
+    *seq_out = pd.gather_seq;
     *tables_on_device_out = tables_on_device;
     return LVBGPU_OK;
 }
@@ -910,7 +976,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     HIPCHK(ctx, hipSetDevice(ctx->device));
     AllParked guard(ctx);
     {
-        const int rf = resolve_follow(ctx); // the commit before this one: long done; its pinned slot may come round again
+        const int rf = resolve_follow(ctx); // the commit before this one: long done (there is one follow record)
         if (rf != LVBGPU_OK)
             return rf;
     }
@@ -941,7 +1007,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
     uint32_t seq = 0;
     bool tables_on_device = false;
     {
-        const int ra = enqueue_accept(ctx, ps, k, where.data(), pchains.data(), seen, &slot, &seq, &tables_on_device);
+        const int ra = defer_picks(ctx, ctx->last_slot, k, where.data(), pchains.data(), seen, &slot, &seq, &tables_on_device);
         if (ra != LVBGPU_OK)
             return ra;
     }
@@ -959,7 +1025,7 @@ extern "C" int lvbgpu_chains_commit(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         cs.topo_version = ++ctx->version_counter;
         cs.cur_length_stale = true;
         if (tables_on_device)
-            cs.d_topo_version = cs.topo_version; // rebuilt in place by the launch above
+            cs.d_topo_version = cs.topo_version; // rebuilt in place by the post launch
     }
     forget_named_candidates(ctx, seen);
     ctx->last_pick_count = k;
@@ -1049,6 +1115,13 @@ int commit_rewrites(lvbgpu_ctx *ctx, int32_t k, const int32_t *chains, std::vect
     int rc = check_depth(ctx, pk.max_stack);
     if (rc != LVBGPU_OK)
         return rc;
+    // one move per chain and one block of host-built programs in a launch
+    if (ctx->pend.k_ext || (ctx->pend.chains & seen))
+    {
+        rc = flush_pending(ctx, nullptr);
+        if (rc != LVBGPU_OK)
+            return rc;
+    }
     // one pinned slot: [descriptors][tokens][destinations][what the table rebuild needs][all rewrites]
     size_t n_all_edits = 0;
     for (const auto &e : edits)
@@ -1082,53 +1155,20 @@ int commit_rewrites(lvbgpu_ctx *ctx, int32_t k, const int32_t *chains, std::vect
     bool tables_on_device = rebuild_tables && (uint32_t)ctx->nb <= REBUILD_MAX_NODES && ctx->d_topo4.p != nullptr;
     for (int32_t j = 0; j < k && tables_on_device; j++)
         tables_on_device = ctx->parked[(size_t)chains[j]].d_topo_version == ctx->parked[(size_t)chains[j]].topo_version;
-    if (tables_on_device)
+    // the device gets all of it with the next post launch (flush_pending): together with the accepted device moves of
+    // other chains, and with the next step's generator if a submit comes next
     {
-        RebuildArgs ra{};
-        ra.tables = ctx->d_topo4.p;
-        ra.table_stride = ctx->gen_table_stride;
-        ra.idx_bytes = ctx->gen_idx_bytes;
-        ra.n = (int32_t)ctx->n;
-        ra.nb = ctx->nb;
-        ra.K = ctx->gen_kmax;
-        ra.leaf_order_len = (uint32_t)ctx->n;
-        ra.ext = ext;
-        ra.ext_edits = all;
-        HIPCHK(ctx, order_rebuild_after_readers(ctx, seen));
-        HIPCHK(ctx, launch_rebuild_tables(ra, (uint32_t)k, ctx->side_stream));
-        HIPCHK(ctx, hipEventRecord(ctx->side_ev, ctx->side_stream));
-        ctx->side_pending = true;
+        lvbgpu_ctx::Pending &pd = ctx->pend;
+        pd.k_ext = k;
+        pd.ext_slot = slot;
+        pd.ext_o_t = o_t;
+        pd.ext_o_d = o_d;
+        pd.ext_o_x = o_x;
+        pd.ext_o_e = o_e;
+        pd.ext_max_stack = std::max(pk.max_stack, 1);
+        pd.ext_rebuild = tables_on_device;
+        pd.chains |= seen;
     }
-    // the commit walk: programs read where they lie while that is little, else copied first
-    const uint32_t ngroups = choose_groups((uint32_t)k, ctx->ntiles, ctx->target_waves);
-    const bool in_place = ctx->direct_steps && o_x * ngroups <= DIRECT_READ_MAX_BYTES;
-    const void *progp = h;
-    if (!in_place)
-    {
-        HIPCHK(ctx, ctx->d_commit[0].reserve(o_x));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_commit[0].p, h, o_x, hipMemcpyHostToDevice, ctx->stream));
-        progp = ctx->d_commit[0].p;
-    }
-    const size_t old_done = ctx->d_done.cap;
-    HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
-    if (ctx->d_done.cap != old_done)
-    {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    HIPCHK(ctx, ctx->d_tmp_changes.reserve((size_t)MAX_CHAINS * (size_t)(ctx->nb + 1) * 8));
-    if (ctx->tmp_changes_zeroed_cap != ctx->d_tmp_changes.cap)
-    {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_tmp_changes.p, 0, ctx->d_tmp_changes.cap, ctx->stream));
-        ctx->tmp_changes_zeroed_cap = ctx->d_tmp_changes.cap;
-    }
-    HIPCHK(ctx, ctx->d_len.reserve(8));
-    WalkArgs a = resident_args(ctx, progp, o_t, o_d, ctx->d_len.p, (uint32_t)k, pk.max_stack);
-    a.s_all_out = (unsigned long long *)ctx->d_scalars;
-    a.tmp_changes = (unsigned long long *)ctx->d_tmp_changes.p;
-    a.tmp_stride = (uint32_t)(ctx->nb + 1);
-    a.done_count = (uint32_t *)ctx->d_done.p;
-    HIPCHK(ctx, launch_walk(a, true, ctx->stream));
     // the host's topologies follow
     for (int32_t j = 0; j < k; j++)
     {
@@ -1155,10 +1195,21 @@ extern "C" int lvbgpu_chains_reroot(lvbgpu_ctx *ctx, int32_t k, const lvbgpu_cha
         return LVBGPU_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     AllParked guard(ctx);
+    // the programs below are built from the chains' topologies as they are NOW: a chain whose accepted move is still on its
+    // way to the host needs it first (and with it the post launch that sends it).  Other chains' moves may stay pending -
+    // in an annealing step the accepted moves and the re-roots are different chains nearly always, and go out together
+    if (ctx->follow.pending)
     {
-        const int rf = resolve_follow(ctx); // the programs below are built from the chains' topologies as they are NOW
-        if (rf != LVBGPU_OK)
-            return rf;
+        bool mine = false;
+        for (int32_t j = 0; j < k && !mine; j++)
+            for (int32_t i = 0; i < ctx->follow.k; i++)
+                mine |= ctx->follow.has[i] && ctx->follow.chains[i] == reqs[j].chain;
+        if (mine)
+        {
+            const int rf = resolve_follow(ctx);
+            if (rf != LVBGPU_OK)
+                return rf;
+        }
     }
     uint64_t seen = 0;
     std::vector<std::vector<Edit>> edits((size_t)k);
@@ -1249,6 +1300,11 @@ extern "C" int lvbgpu_chains_commit_edits(lvbgpu_ctx *ctx, int32_t k, const int3
     }
     if (!reuse)
         return commit_rewrites(ctx, k, chains, edits, new_roots, seen, "commit", false);
+    {
+        const int rp = flush_pending(ctx, nullptr); // (this walk is launched here and now)
+        if (rp != LVBGPU_OK)
+            return rp;
+    }
     {
         const size_t old_done = ctx->d_done.cap;
         HIPCHK(ctx, ctx->d_done.reserve((size_t)(MAX_CHAINS + 1) * 4));
@@ -1349,7 +1405,7 @@ extern "C" int lvbgpu_proposal_edits(lvbgpu_ctx *ctx, int32_t b, lvbgpu_edit *ed
         return ctx->fail(LVBGPU_E_STATE, "no device batch holds that candidate: call lvbgpu_propose_score first");
     if (ctx->d_topo_version != ctx->topo_version)
         return ctx->fail(LVBGPU_E_STATE, "the resident tree changed since that batch was drawn");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     // this candidate's descriptor, then its edits
     HIPCHK(ctx, ctx->h_pinfo.reserve(sizeof(ProposalInfo)));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinfo.p, (const ProposalInfo *)ps.d_pinfo.p + b, sizeof(ProposalInfo),
@@ -1388,7 +1444,7 @@ extern "C" int lvbgpu_proposal_stats(lvbgpu_ctx *ctx, lvbgpu_batch_stats *out)
         total += sgm.count;
     if (total <= 0 || !ps.batch || ps.in_flight)
         return ctx->fail(LVBGPU_E_STATE, "no device batch: call lvbgpu_propose_score first");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ENTER(ctx);
     std::vector<ProposalInfo> info((size_t)total);
     HIPCHK(ctx, hipMemcpyAsync(info.data(), ps.d_pinfo.p, info.size() * sizeof(ProposalInfo), hipMemcpyDeviceToHost,
                                ctx->stream));

@@ -159,12 +159,7 @@ struct lvbgpu_ctx
 {
     int device = 0;
     hipStream_t stream = nullptr;
-    // side stream: what follows an accepted device move but does not touch state sets (the rewrites' way to the host,
-    // the generator's tables) runs beside the commit walk; side_ev orders the next generator launch after it
-    hipStream_t side_stream = nullptr;
     hipStream_t copy_stream = nullptr; // read-backs of device-built batches' lengths: beside the next batch, not before it
-    hipEvent_t side_ev = nullptr;
-    bool side_pending = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     long n = 0, nwords = 0;
     int32_t nb = 0;
@@ -225,7 +220,6 @@ struct lvbgpu_ctx
         int32_t B = 0;
         hipEvent_t done_ev = nullptr; // after the lengths' read-back (on the copy stream)
         hipEvent_t walk_ev = nullptr; // after the walk (on the main stream): what the read-back waits for
-        hipEvent_t gen_ev = nullptr;  // recorded behind this batch when a table rebuild of one of its chains must wait for it
         uint64_t submit_ord = 0;      // this batch's ordinal among the context's submits (1-based)
         PinBuf h_flag;                // the watcher's word for this slot's batches (kernels.hpp WalkArgs::watcher)
         uint32_t seq = 0;
@@ -286,6 +280,34 @@ struct lvbgpu_ctx
         int32_t chains[MAX_CHAINS];
         bool has[MAX_CHAINS]; // record j exists
     } follow;
+    // What lvbgpu_chains_commit, lvbgpu_chains_reroot and lvbgpu_chains_commit_edits have been asked for but the device
+    // has not been given yet: commits of several chains are collected here and go out as ONE post launch (kernels.hpp
+    // PostArgs: commit walk + table rebuilds + the moves' records to the host) - together with the next step's generator
+    // when the next thing on this context is a submit, which in an annealing loop it is (api_propose.cpp flush_pending;
+    // every other entry point flushes first, so nobody sees a tree the device has not caught up with).
+    struct Pending
+    {
+        // accepted candidates of the device-built batch in pslot[src_slot]: launch candidates 0 .. k_pick - 1
+        int32_t k_pick = 0;
+        int src_slot = 0;
+        uint32_t where[MAX_CHAINS];
+        int32_t pick_chain[MAX_CHAINS];
+        bool pick_rebuild = false;  // their chains' tables follow on the device
+        int gather_slot = 0;        // pinned slot their records go to (lvbgpu_ctx::follow waits for gather_seq there)
+        uint32_t gather_seq = 0;
+        // moves named by the host (re-roots, host-made candidates), programs and rewrites in pinned slot ext_slot:
+        // launch candidates k_pick .. k_pick + k_ext - 1
+        int32_t k_ext = 0;
+        int ext_slot = 0;
+        size_t ext_o_t = 0, ext_o_d = 0, ext_o_x = 0, ext_o_e = 0;
+        int32_t ext_max_stack = 1;
+        bool ext_rebuild = false;
+        uint64_t chains = 0; // every chain above, as a mask: one move per chain and launch
+        bool any() const { return k_pick > 0 || k_ext > 0; }
+    } pend;
+    DevBuf d_table_ready; // uint32[MAX_CHAINS]: = post_seq once a post launch has rebuilt that chain's tables
+    uint32_t post_seq = 0;
+    int64_t post_launches = 0, post_launches_with_generator = 0; // (lvbgpu_debug_count)
     PinBuf h_pin;
     // direct steps: small batches whose programs the walk reads straight from h_pin and whose lengths its last
     // wave writes straight into the batch's pinned buffer; the host polls h_step's first word for step_seq
@@ -416,6 +438,22 @@ constexpr size_t DIRECT_READ_MAX_BYTES = 64u << 10;
 constexpr int32_t STEP_PIPELINE_PIECE = 2048; // lvbgpu_score_batch cuts a batch into up to 4 pieces of at least this size
 constexpr int32_t LPT_MIN_B = 2048; // from here on a launch is many rounds of waves and its tail shows
 
+// the first statement of every entry point that enqueues device work or reads device state: select the device and let
+// the device catch up with the commits collected in lvbgpu_ctx::pend
+#define ENTER(ctx)                                                                                                     \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t es__ = hipSetDevice((ctx)->device);                                                                 \
+        if (es__ != hipSuccess)                                                                                        \
+            return (ctx)->fail_hip(es__, "hipSetDevice");                                                              \
+        if ((ctx)->pend.any())                                                                                         \
+        {                                                                                                              \
+            const int ef__ = flush_pending((ctx), nullptr);                                                            \
+            if (ef__ != LVBGPU_OK)                                                                                     \
+                return ef__;                                                                                           \
+        }                                                                                                              \
+    } while (0)
+
 #define HIPCHK(ctx, call)                                                                                              \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -468,6 +506,9 @@ int walk_timing_drain(lvbgpu_ctx *ctx);
 int resolve_follow(lvbgpu_ctx *ctx);
 uint64_t edits_hash(const lvbgpu_edit *e, int32_t n);
 int settle(lvbgpu_ctx *ctx);
+// api_propose.cpp: give the device what lvbgpu_ctx::pend holds (one post launch; with `gen` the next batch's generator rides
+// in it).  Nothing pending and no generator: nothing happens.
+int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen);
 } // namespace lvbgpu_detail
 
 using namespace lvbgpu_detail;

@@ -1,5 +1,5 @@
-// gather.hpp - device code shared by fitch_kernels.hip (gather_picks_kernel) and propose_kernels.hip (the gather blocks
-// of rebuild_tables_kernel): one wave copies one picked candidate's descriptor and rewrites into pinned host memory.
+// gather.hpp - device code of the post launch (propose_kernels.hip): one wave copies one picked candidate's descriptor
+// and rewrites into pinned host memory.
 #pragma once
 #include "kernels.hpp"
 
@@ -13,19 +13,6 @@ __device__ __forceinline__ void gather_acknowledged()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-struct GatherArgs
-{
-    uint32_t pick_idx[MAX_CHAINS]; // batch positions of the picked candidates (in the kernel arguments)
-    uint32_t k;
-    const ProposalInfo *info;
-    const lvbgpu_edit_dev *edits;
-    uint32_t stride_e;
-    char *out;                     // pinned host memory: out + j * out_stride = [ProposalInfo][n_edits rewrites]
-    uint32_t out_stride;
-    uint32_t *flag;                // pinned: = seq once all k records are on the host
-    uint32_t seq;
-    uint32_t *arrived;             // device word, zero between launches
-};
 
 // pick j by one wave (lane = 0..63): word by word, as system-scope stores (written through to the host)
 __device__ __forceinline__ void gather_one_pick(const GatherArgs &a, uint32_t j, uint32_t lane)

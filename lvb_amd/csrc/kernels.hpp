@@ -119,6 +119,13 @@ struct WalkArgs
     uint32_t use_pick;
     uint32_t pick_idx[MAX_CHAINS];
     uint32_t tmp_stride;
+    // ... and, from launch candidate n_first on, the programs of a SECOND block (host-built: re-roots, host-made
+    // candidates), candidate j being cands2[j - n_first] with tokens / destinations relative to toks2 / dsts2: accepted
+    // device moves and re-roots of other chains in ONE commit walk.  n_first = UINT32_MAX (resident_args): no second block
+    uint32_t n_first;
+    const CandDesc *cands2;
+    const uint32_t *toks2;
+    const int32_t *dsts2;
     uint32_t flip; // walk each XCD's share of the items from its far end (filled by launch_walk)
     // two candidates per wave (fitch_walk_pair; scoring launches): pairs[2 p], pairs[2 p + 1] = the candidates of pair p
     // (the second PICK_NONE: walked alone); an item is then (tile group, pair) and nitems = npairs * ngroups
@@ -174,23 +181,27 @@ constexpr uint32_t GEN_WAVES = 16; // one copy of the tables into LDS serves 16 
                                     // candidate's time was its workgroup's copy - a thousand workgroups reading the same 34 KB)
 constexpr uint32_t GEN_THREADS = 64 * GEN_WAVES;
 constexpr uint32_t MAX_GEN_SEGS = 64; // = MAX_CHAINS: one segment of a launch per resident tree
-// one run of candidates of ONE resident tree inside a generator launch
+// one run of candidates of ONE resident tree inside a generator launch (36 bytes: 64 of them travel as kernel arguments,
+// in the post launch beside the commit walk's and the table rebuild's)
 struct GenSeg
 {
     uint32_t start, count;   // candidates [start, start + count) of the batch
-    int32_t kind_all;        // 0 NNI, 1 SPR, 2 TBR; -1 / -2 / -3: see propose_kernels.hip
     uint32_t mix_a, mix_b;
     uint32_t seed_lo, seed_hi; // the draw is a function of (seed, index within the segment)
-    uint32_t table_off;      // byte offset of this tree's tables in GenArgs::tables
-    uint32_t table_bytes;
     int32_t root;
-    uint16_t chain, K;
-    uint32_t blk_start;      // first workgroup of the launch that works on this segment (filled by launch_propose)
+    uint32_t blk_start;      // first workgroup of the launch that works on this segment (filled by the launcher)
+    int8_t kind_all;         // 0 NNI, 1 SPR, 2 TBR; -1 / -2 / -3: see propose_kernels.hip
+    uint8_t chain;           // its tables: GenArgs::tables + chain * table_stride
+    uint8_t wait;            // post launch: this tree's tables are being rebuilt by the same launch - wait for GenArgs::table_ready[chain]
+    uint8_t pad_;
 };
+static_assert(sizeof(GenSeg) == 36, "GenSeg layout");
 struct GenArgs
 {
     const void *tables;
     uint32_t idx_bytes;
+    uint32_t table_stride, table_bytes; // every tree's slot / what of it the tables fill (the same for all trees of these taxa)
+    int32_t K;                          // ancestor tables hold 2^0 .. 2^(K-1)
     int32_t n, nb;
     uint32_t leaf_order_len;
     uint32_t stride_t, stride_e;
@@ -203,11 +214,13 @@ struct GenArgs
     uint32_t *keys;              // [B] sort keys for pairing the candidates (pair_kernel; null: none; needs 16-bit tables)
     const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
     unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
-    int32_t use_lds;              // filled by launch_propose
+    const uint32_t *table_ready;  // post launch: [MAX_CHAINS], = ready_seq once that chain's tables have been rebuilt (GenSeg::wait)
+    uint32_t ready_seq;
+    int32_t use_lds;              // filled by the launcher
     uint32_t nseg;
     GenSeg seg[MAX_GEN_SEGS];
 };
-static_assert(sizeof(GenArgs) <= 4000, "GenArgs travels as a kernel argument");
+static_assert(sizeof(GenArgs) <= 2600, "GenArgs travels as a kernel argument, in the post launch beside three more structs");
 hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
 
 // who walks with whom (fitch_walk_pair): every segment's candidates ordered by their keys and handed out two by two
@@ -240,23 +253,58 @@ struct RebuildArgs
     uint32_t table_stride, idx_bytes;
     int32_t n, nb, K;
     uint32_t leaf_order_len;
-    uint32_t pick_idx[MAX_CHAINS]; // batch positions of the picked candidates (in the kernel arguments, see WalkArgs)
-    const CandDesc *cands;   // their descriptors (flags carry the chain)
+    // workgroup j < n_pick rebuilds for the picked candidate at batch position pick_idx[j] (its descriptor names the
+    // chain, its rewrites are edits + pick_idx[j] * stride_e); workgroup j >= n_pick for ext[j - n_pick] (a move that is
+    // not a candidate of a device batch: a re-root named by the host)
+    uint32_t n_pick;
+    uint32_t rebuild_picks;        // 0: the picked candidates' workgroups only send the records to the host (their tables cannot follow on the device)
+    uint32_t pick_idx[MAX_CHAINS]; // (in the kernel arguments, see WalkArgs)
+    const CandDesc *cands;   // the picked candidates' descriptors (flags carry the chain)
     const ProposalInfo *info;
     const lvbgpu_edit_dev *edits;
     uint32_t stride_e;
-    const RebuildExt *ext;   // non-null: workgroup j rebuilds for ext[j] instead of a picked candidate
+    const RebuildExt *ext;
     const lvbgpu_edit_dev *ext_edits;
+    // post launch: the generator of the SAME launch waits for a chain's tables - they are written through (agent-scope
+    // stores) and table_ready[chain] = ready_seq says when (null: plain stores, the next launch reads them)
+    uint32_t *table_ready;
+    uint32_t ready_seq;
 };
-struct GatherArgs;
-hipError_t launch_rebuild_tables(const RebuildArgs &args, uint32_t k, hipStream_t stream, const GatherArgs *gather = nullptr);
-
 // what lvbgpu_chains_commit needs on the host of every picked candidate, written straight into pinned memory
-// (gather.hpp): alone (trees too large for the device-side table rebuild), or as the first k workgroups of the rebuild
-// launch (launch_rebuild_tables with gather != null: one launch fewer on the accept path - a launch costs the host
-// 6-9 us with its event, and there the host is what a step waits for)
-struct GatherArgs;
-hipError_t launch_gather_picks(const GatherArgs &g, hipStream_t stream);
+// (gather.hpp) by wave 0 of that pick's workgroup of the post launch, before it rebuilds the chain's tables
+struct GatherArgs
+{
+    uint32_t pick_idx[MAX_CHAINS]; // batch positions of the picked candidates (in the kernel arguments)
+    uint32_t k;
+    const ProposalInfo *info;
+    const lvbgpu_edit_dev *edits;
+    uint32_t stride_e;
+    char *out;                     // pinned host memory: out + j * out_stride = [ProposalInfo][n_edits rewrites]
+    uint32_t out_stride;
+    uint32_t *flag;                // pinned: = seq once all k records are on the host
+    uint32_t seq;
+    uint32_t *arrived;             // device word, zero between launches
+};
+
+// The POST launch (propose_kernels.hip): what lies between two scoring walks of an annealing step - the table rebuilds
+// of the chains that moved, the commit walk of those moves, and the NEXT step's generator - as roles of ONE launch.
+struct PostArgs
+{
+    GenArgs gen;      // nseg == 0: no generator role
+    WalkArgs commit;  // nitems == 0: no commit walk (launch_post shapes it: tiles per wave, burst slots)
+    RebuildArgs reb;
+    GatherArgs gat;   // k == 0: nothing goes to the host
+    uint32_t n_reb;   // rebuild workgroups: reb.n_pick picked candidates, then n_reb - reb.n_pick moves named by the host
+    uint32_t n_cblk;  // filled by launch_post
+};
+static_assert(sizeof(PostArgs) <= 4000, "PostArgs travels as a kernel argument");
+// can the generator ride in a post launch (its tables must fit LDS beside nothing else)?
+bool post_can_generate(const GenArgs &g);
+hipError_t launch_post(const PostArgs &args, hipStream_t stream);
+// fills what a walk's launcher owes the kernel (tiles per group, the division constant, and for a commit walk the burst
+// slots that fit `lds_budget` bytes per workgroup of `nwaves` waves beside the operand stacks); *lds_out = dynamic LDS
+hipError_t shape_walk(WalkArgs &a, bool commit, uint32_t nwaves, size_t lds_budget, size_t *lds_out);
+bool walk_needs_wide(const WalkArgs &a); // row offsets as 64-bit bytes (tree blocks of 64 GiB and more; LVBGPU_WIDE_OFFSETS=1)
 hipError_t upload_iupac_table();
 hipError_t raise_lds_limit();
 hipError_t launch_walk(const WalkArgs &a, bool commit, hipStream_t stream, uint32_t *flip_state = nullptr);

@@ -34,6 +34,7 @@
 
 #include "kernels.hpp"
 #include "gather.hpp"
+#include "walk_body.hpp"
 
 namespace lvbgpu
 {
@@ -581,43 +582,84 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
 } // namespace
 
 #undef LVB_HEAD_SP
+// The generator's part of a launch: workgroup `blk` of the `nblk` that generate (propose_kernel: the whole grid; the post
+// launch: its last workgroups).  lds_tables: the workgroup's dynamic LDS.
 template <typename IdxT, bool IN_LDS>
-__global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
+__device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, const uint32_t nblk, uint4 *const lds_tables)
 {
-    extern __shared__ uint4 lds_tables[];
     const uint64_t t_enter = g.prof ? __builtin_readcyclecounter() : 0ull;
     // which segment (resident tree) this workgroup works for: its first workgroup is seg[s].blk_start
     uint32_t s = 0;
-    while (s + 1u < g.nseg && blockIdx.x >= g.seg[s + 1u].blk_start)
+    while (s + 1u < g.nseg && blk >= g.seg[s + 1u].blk_start)
         s++;
     const GenSeg &sg = g.seg[s];
-    const uint32_t blk_local = blockIdx.x - sg.blk_start;
-    const uint32_t seg_blocks = (s + 1u < g.nseg ? g.seg[s + 1u].blk_start : gridDim.x) - sg.blk_start;
-    const char *tables = reinterpret_cast<const char *>(g.tables) + sg.table_off;
+    const uint32_t blk_local = blk - sg.blk_start;
+    const uint32_t seg_blocks = (s + 1u < g.nseg ? g.seg[s + 1u].blk_start : nblk) - sg.blk_start;
+    const char *tables = reinterpret_cast<const char *>(g.tables) + (size_t)sg.chain * g.table_stride;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     using P = typename TabPtr<IdxT, IN_LDS>::type;
     P tab;
     if constexpr (IN_LDS)
     {
-        // one coalesced copy per workgroup; everything after it is LDS latency instead of L2 latency (1024 threads x 4
-        // loads of 16 bytes in flight: the 34 KB of a 500-taxon tree are one round trip)
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(tables);
-        const uint32_t n16 = sg.table_bytes / 16u;
-        constexpr uint32_t DEPTH = 4;
-        for (uint32_t i0 = 0; i0 < n16; i0 += DEPTH * GEN_THREADS)
+        if (sg.wait)
         {
-            uint4 v[DEPTH];
-#pragma unroll
-            for (uint32_t u = 0; u < DEPTH; u++)
+            // post launch: this tree's tables are being rebuilt by an earlier workgroup of the SAME launch (workgroups are
+            // dealt in order: it is resident or done) - wait for its word, then copy with agent-scope loads: the tables
+            // were written through, and a plain load could be served from a line this XCD's L2 still holds from the last step
+            __shared__ uint32_t gave_up;
+            if (threadIdx.x == 0)
             {
-                const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
-                v[u] = src4[i < n16 ? i : n16 - 1u]; // (unconditional: a conditionally filled array went through scratch)
+                uint32_t budget = 1u << 24; // ~ seconds: a backstop, the rebuild finishes on its own
+                while (__hip_atomic_load(g.table_ready + sg.chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.ready_seq && --budget)
+                    __builtin_amdgcn_s_sleep(16);
+                gave_up = budget == 0u ? 1u : 0u;
             }
-#pragma unroll
-            for (uint32_t u = 0; u < DEPTH; u++)
+            __syncthreads();
+            if (gave_up)
             {
-                const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
-                if (i < n16)
-                    lds_tables[i] = v[u];
+                // never walk programs made from torn tables: these candidates are "not proposals"
+                for (uint32_t bl = blk_local * GEN_WAVES + wave; bl < sg.count; bl += seg_blocks * GEN_WAVES)
+                    if (lane == 0)
+                    {
+                        CandDesc cd{};
+                        cd.tok_off = cd.dst_off = (sg.start + bl) * g.stride_t;
+                        cd.base = PROPOSAL_OVERFLOW_LENGTH;
+                        g.cands[sg.start + bl] = cd;
+                        g.len_out[sg.start + bl] = 0ull;
+                        g.info[sg.start + bl] = ProposalInfo{0, -1, -1, -1, 0, 0, 1, 0};
+                    }
+                return;
+            }
+            const unsigned long long *src8 = reinterpret_cast<const unsigned long long *>(tables);
+            unsigned long long *dst8 = reinterpret_cast<unsigned long long *>(lds_tables);
+            const uint32_t n8 = g.table_bytes / 8u;
+            for (uint32_t i = threadIdx.x; i < n8; i += GEN_THREADS)
+                dst8[i] = __hip_atomic_load(src8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else
+        {
+            // one coalesced copy per workgroup; everything after it is LDS latency instead of L2 latency (1024 threads x 4
+            // loads of 16 bytes in flight: the 34 KB of a 500-taxon tree are one round trip)
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(tables);
+            const uint32_t n16 = g.table_bytes / 16u;
+            constexpr uint32_t DEPTH = 4;
+            for (uint32_t i0 = 0; i0 < n16; i0 += DEPTH * GEN_THREADS)
+            {
+                uint4 v[DEPTH];
+#pragma unroll
+                for (uint32_t u = 0; u < DEPTH; u++)
+                {
+                    const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
+                    v[u] = src4[i < n16 ? i : n16 - 1u]; // (unconditional: a conditionally filled array went through scratch)
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < DEPTH; u++)
+                {
+                    const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
+                    if (i < n16)
+                        lds_tables[i] = v[u];
+                }
             }
         }
         __syncthreads();
@@ -639,9 +681,7 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
     t.n = g.n;
     t.nb = g.nb;
     t.root = sg.root;
-    t.K = (int32_t)sg.K;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    t.K = g.K;
     if (g.prof && lane == 0 && sg.start + blk_local * GEN_WAVES + wave < 256u)
     {
         g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 5u] = t_enter;
@@ -651,6 +691,13 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
         generate_one(t, g, sg, bl, lane);
 }
 
+template <typename IdxT, bool IN_LDS>
+__global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
+{
+    extern __shared__ uint4 lds_dyn[];
+    gen_role<IdxT, IN_LDS>(g, blockIdx.x, gridDim.x, lds_dyn);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The tables of a tree after an accepted device move, rebuilt ON the device (lvbgpu_chains_commit): one workgroup
 // per picked chain applies the candidate's rewrites to left / right in that chain's table slot and derives everything
@@ -658,21 +705,31 @@ __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 // ancestors, preorder number and first-leaf position from ONE walk of each node along its own root-ward path (no
 // level-by-level rounds: a barrier of 16 waves costs as much as a path).  No host work and no
 // upload per accepted move; with R chains accepting in one step that was most of the step.
-// With ga.k != 0 the launch's FIRST ga.k workgroups are the accepted candidates' gather (gather.hpp: wave 0 of each; they
-// are dealt first and done in a few microseconds, so the host has its flag long before the rebuilds end).
-template <typename IdxT>
-__global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const RebuildArgs g, const GatherArgs ga)
+// With ga.k != 0 wave 0 of the workgroup of pick j first sends that pick's descriptor and rewrites to the host
+// (gather.hpp: done in a few microseconds, so the host has its flag long before the rebuilds end).
+// g.table_ready != null (post launch): the generator of the SAME launch waits for these tables - they are written
+// through to where every XCD sees them (agent-scope stores), and the chain's word says when.
+template <typename T>
+__device__ __forceinline__ void store_tab(T *p, T v, bool through)
 {
-    extern __shared__ int32_t lds_i32[];
-    if (blockIdx.x < ga.k)
-    {
-        if (threadIdx.x < 64u)
-            gather_one_pick(ga, blockIdx.x, threadIdx.x);
-        return;
-    }
-    const uint32_t j = blockIdx.x - ga.k;
-    const uint32_t cand = g.ext ? 0u : g.pick_idx[j];
-    const uint32_t chain = g.ext ? (uint32_t)g.ext[j].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
+    if (through)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+template <typename IdxT>
+__device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherArgs &ga, const uint32_t j, int32_t *const lds_i32)
+{
+    const bool is_ext = j >= g.n_pick;
+    const uint32_t x = j - g.n_pick; // (is_ext)
+    const uint32_t cand = is_ext ? 0u : g.pick_idx[j];
+    if (!is_ext && j < ga.k && threadIdx.x < 64u)
+        gather_one_pick(ga, j, threadIdx.x);
+    if (!is_ext && !g.rebuild_picks)
+        return; // (uniform for the workgroup: no barrier is skipped by some)
+    const bool through = g.table_ready != nullptr;
+    const uint32_t chain = is_ext ? (uint32_t)g.ext[x].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
     IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
     const int32_t n = g.n, nb = g.nb, K = g.K;
     IdxT *t_parent = tab, *t_left = tab + nb, *t_right = tab + 2 * (size_t)nb, *t_nleaf = tab + 3 * (size_t)nb,
@@ -690,17 +747,17 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
     }
     __syncthreads();
     // the root: given with a re-root, otherwise the one node that is its own parent (device moves never re-root)
-    if (g.ext)
+    if (is_ext)
     {
         if (tid == 0)
-            shared[0] = g.ext[j].new_root;
+            shared[0] = g.ext[x].new_root;
     }
     else
         for (int32_t v = tid; v < nb; v += nt)
             if (parent[v] == v)
                 shared[0] = v;
-    const int32_t n_edits = g.ext ? g.ext[j].n_edits : g.info[cand].n_edits;
-    const lvbgpu_edit_dev *ed = g.ext ? g.ext_edits + g.ext[j].edit_off : g.edits + (size_t)cand * g.stride_e;
+    const int32_t n_edits = is_ext ? g.ext[x].n_edits : g.info[cand].n_edits;
+    const lvbgpu_edit_dev *ed = is_ext ? g.ext_edits + g.ext[x].edit_off : g.edits + (size_t)cand * g.stride_e;
     for (int32_t i = tid; i < n_edits; i += nt)
     {
         const lvbgpu_edit_dev e = ed[i];
@@ -726,10 +783,10 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
     // leaves below: every leaf counts itself into each of its ancestors (LDS atomics; no level-by-level rounds)
     for (int32_t v = tid; v < nb; v += nt)
         if (!has_children(v))
-            for (int32_t x = v; x != root;)
+            for (int32_t y = v; y != root;)
             {
-                x = parent[x];
-                atomicAdd(&nleaf[x], 1);
+                y = parent[y];
+                atomicAdd(&nleaf[y], 1);
             }
     __syncthreads();
     // What a node's root-ward walk adds at each step depends on the node stepped FROM only: from a right child the
@@ -751,57 +808,76 @@ __global__ __launch_bounds__(REBUILD_THREADS) void rebuild_tables_kernel(const R
     {
         uint32_t tv = 0, fv = 0;
         int32_t d = 0, filled = 0;
-        for (int32_t x = v; x != root;)
+        for (int32_t y = v; y != root;)
         {
-            const uint2 s = step[x];
-            tv += s.y;
-            fv += s.y >> 1;
-            x = (int32_t)s.x;
+            const uint2 st = step[y];
+            tv += st.y;
+            fv += st.y >> 1;
+            y = (int32_t)st.x;
             d++;
             if ((d & (d - 1)) == 0 && filled < K)
-                t_up[(size_t)filled++ * nb + v] = (IdxT)x; // d = 2^filled
+                store_tab(&t_up[(size_t)filled++ * nb + v], (IdxT)y, through); // d = 2^filled
         }
         for (; filled < K; filled++)
-            t_up[(size_t)filled * nb + v] = (IdxT)root;
-        t_parent[v] = (IdxT)parent[v];
-        t_left[v] = (IdxT)(has_children(v) ? left[v] : 0);
-        t_right[v] = (IdxT)(has_children(v) ? right[v] : 0);
-        t_nleaf[v] = (IdxT)nleaf[v];
-        t_depth[v] = (IdxT)d;
-        t_tin[v] = (IdxT)tv;
-        t_first[v] = (IdxT)fv;
+            store_tab(&t_up[(size_t)filled * nb + v], (IdxT)root, through);
+        store_tab(&t_parent[v], (IdxT)parent[v], through);
+        store_tab(&t_left[v], (IdxT)(has_children(v) ? left[v] : 0), through);
+        store_tab(&t_right[v], (IdxT)(has_children(v) ? right[v] : 0), through);
+        store_tab(&t_nleaf[v], (IdxT)nleaf[v], through);
+        store_tab(&t_depth[v], (IdxT)d, through);
+        store_tab(&t_tin[v], (IdxT)tv, through);
+        store_tab(&t_first[v], (IdxT)fv, through);
         if (!has_children(v))
-            t_order[fv] = (IdxT)v;
+            store_tab(&t_order[fv], (IdxT)v, through);
+    }
+    if (through)
+    {
+        // every wave's stores acknowledged (written through: in no cache of this chip), then the chain's word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(g.table_ready + chain, g.ready_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-hipError_t launch_rebuild_tables(const RebuildArgs &g, uint32_t k, hipStream_t stream, const GatherArgs *gather)
+// ---------------------------------------------------------------------------------------------
+// The POST launch: everything that lies between two scoring walks of an annealing step, in ONE launch of 1024-thread
+// workgroups with three roles -
+//   [0, n_reb)                the table rebuilds of the chains that moved (accepted device candidates: rewrites from the
+//                             batch they were drawn in; re-roots: rewrites from the host), wave 0 of each first sending an
+//                             accepted candidate's record to the host;
+//   [n_reb, n_reb + n_cblk)   the commit walk of those moves (walk_body.hpp, 16 waves = 16 items per workgroup): accepted
+//                             candidates' own device-built programs (picked by position) and host-built programs of a
+//                             second block;
+//   the rest                  the NEXT step's generator, a segment of which waits for its chain's rebuild (workgroups are
+//                             dealt in order, so whoever is waited for is resident or done).
+// Round 3 ran these as up to five launches on two streams with two event pairs (commit walk, rebuild + gather, re-root
+// walk, its rebuild, generator): every kernel boundary costs 8-9 us whatever the kernel does, a cross-stream hand-over
+// 2-5 us, and on the accept path the host's launch calls are what the device waits for.
+constexpr uint32_t POST_WAVES = GEN_THREADS / 64u;
+static_assert(GEN_THREADS == REBUILD_THREADS, "one workgroup size for every role of the post launch");
+
+template <typename IdxT, bool WIDE>
+__global__ __launch_bounds__(GEN_THREADS) void post_kernel(const PostArgs p)
 {
-    GatherArgs ga{};
-    if (gather)
-        ga = *gather;
-    if (k == 0)
-        return hipSuccess;
-    const size_t lds = (((size_t)4 * g.nb + 4 + 1) & ~(size_t)1) * sizeof(int32_t) + (size_t)g.nb * sizeof(uint2);
-    if (lds > MAX_LDS_BYTES)
-        return hipErrorInvalidValue; // the caller keeps the host path for trees this large
-    // (the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raised once per device, whichever host
-    // thread gets there first - contexts may be driven from several threads)
-    static std::once_flag raised_on[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64)
-        std::call_once(raised_on[dev], [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<uint16_t>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rebuild_tables_kernel<int32_t>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-        });
-    if (g.idx_bytes == 2)
-        hipLaunchKernelGGL(rebuild_tables_kernel<uint16_t>, dim3(k + ga.k), dim3(REBUILD_THREADS), lds, stream, g, ga);
-    else
-        hipLaunchKernelGGL(rebuild_tables_kernel<int32_t>, dim3(k + ga.k), dim3(REBUILD_THREADS), lds, stream, g, ga);
-    return hipGetLastError();
+    extern __shared__ uint4 lds_dyn[];
+    const uint32_t b = blockIdx.x;
+    if (b < p.n_reb)
+    {
+        rebuild_role<IdxT>(p.reb, p.gat, b, reinterpret_cast<int32_t *>(lds_dyn));
+        return;
+    }
+    if (b < p.n_reb + p.n_cblk)
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t item = (b - p.n_reb) * POST_WAVES + wave;
+        if (item < p.commit.nitems)
+            walk_item<true, WIDE, 0>(p.commit, lds_dyn, lane, wave, POST_WAVES, item);
+        return;
+    }
+    if (p.gen.nseg)
+        gen_role<IdxT, true>(p.gen, b - p.n_reb - p.n_cblk, gridDim.x - p.n_reb - p.n_cblk, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -960,45 +1036,43 @@ hipError_t launch_pair_sort(const PairArgs &args, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
+// the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raised once for each device a context of this
+// process launches on (the walk does the same per context, raise_lds_limit), whichever host thread gets there first
+static hipError_t raise_generator_lds()
 {
-    if (args.nseg == 0 || args.nseg > MAX_GEN_SEGS)
-        return hipErrorInvalidValue;
-    // the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raise it once for each device a
-    // context of this process launches on (the walk does the same per context, raise_lds_limit)
     static hipError_t raised_on[64];
     static std::once_flag asked_on[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    hipError_t raised = hipErrorInvalidDevice;
-    if (dev >= 0 && dev < 64)
-    {
-        std::call_once(asked_on[dev], [dev] {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<uint16_t, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (dev < 0 || dev >= 64)
+        return hipErrorInvalidDevice;
+    std::call_once(asked_on[dev], [dev] {
+        hipError_t e = hipSuccess;
+        for (const void *f : {reinterpret_cast<const void *>(&propose_kernel<uint16_t, true>),
+                              reinterpret_cast<const void *>(&propose_kernel<int32_t, true>),
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, false>),
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, true>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, false>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, true>)})
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&propose_kernel<int32_t, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-            raised_on[dev] = e;
-        });
-        raised = raised_on[dev];
-    }
-    const size_t lds_max = raised == hipSuccess ? (size_t)MAX_LDS_BYTES : (size_t)64 * 1024;
-    GenArgs g = args;
-    size_t widest = 0;
+                e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        raised_on[dev] = e;
+    });
+    return raised_on[dev];
+}
+
+static size_t rebuild_lds_bytes(int32_t nb)
+{
+    return (((size_t)4 * nb + 4 + 1) & ~(size_t)1) * sizeof(int32_t) + (size_t)nb * sizeof(uint2);
+}
+
+// one candidate per wave while the chip has room; beyond that waves take several.  Every segment gets workgroups in
+// proportion to its candidates (at least one).  per_cu: generator workgroups a CU can hold.  Returns their number.
+static uint32_t deal_generator_blocks(GenArgs &g, uint32_t per_cu)
+{
     uint32_t total = 0;
     for (uint32_t s = 0; s < g.nseg; s++)
-    {
-        widest = std::max<size_t>(widest, g.seg[s].table_bytes);
         total += g.seg[s].count;
-    }
-    if (total == 0)
-        return hipSuccess;
-    g.use_lds = widest <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
-    const size_t lds = g.use_lds ? widest : 0;
-    // one candidate per wave while the chip has room; beyond that waves take several.  Every segment gets
-    // workgroups in proportion to its candidates (at least one)
-    const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(2, lds_max / std::max<size_t>(lds, 1))) : 2u;
     const uint32_t budget = 256u * per_cu;
     const uint32_t want_all = (total + GEN_WAVES - 1) / GEN_WAVES;
     uint32_t nblk = 0;
@@ -1010,6 +1084,27 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
         g.seg[s].blk_start = nblk;
         nblk += give;
     }
+    return nblk;
+}
+
+hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
+{
+    if (args.nseg == 0 || args.nseg > MAX_GEN_SEGS)
+        return hipErrorInvalidValue;
+    const size_t lds_max = raise_generator_lds() == hipSuccess ? (size_t)MAX_LDS_BYTES : (size_t)64 * 1024;
+    GenArgs g = args;
+    uint32_t total = 0;
+    for (uint32_t s = 0; s < g.nseg; s++)
+    {
+        total += g.seg[s].count;
+        g.seg[s].wait = 0;
+    }
+    if (total == 0)
+        return hipSuccess;
+    g.use_lds = g.table_bytes <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
+    const size_t lds = g.use_lds ? g.table_bytes : 0;
+    const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(2, lds_max / std::max<size_t>(lds, 1))) : 2u;
+    const uint32_t nblk = deal_generator_blocks(g, per_cu);
     const dim3 grid(nblk), block(GEN_THREADS);
     if (g.idx_bytes == 2)
     {
@@ -1022,6 +1117,79 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
         hipLaunchKernelGGL((propose_kernel<int32_t, true>), grid, block, lds, stream, g);
     else
         hipLaunchKernelGGL((propose_kernel<int32_t, false>), grid, block, lds, stream, g);
+    return hipGetLastError();
+}
+
+bool post_can_generate(const GenArgs &g)
+{
+    return g.nseg >= 1 && g.nseg <= MAX_GEN_SEGS && g.moves == nullptr && raise_generator_lds() == hipSuccess && g.table_bytes <= MAX_LDS_BYTES;
+}
+
+hipError_t launch_post(const PostArgs &args, hipStream_t stream)
+{
+    PostArgs p = args;
+    if (raise_generator_lds() != hipSuccess)
+        return hipErrorInvalidValue;
+    size_t lds = 0;
+    if (p.n_reb)
+    {
+        lds = rebuild_lds_bytes(p.reb.nb);
+        if (lds > MAX_LDS_BYTES || p.reb.n_pick > p.n_reb)
+            return hipErrorInvalidValue;
+    }
+    uint32_t gen_total = 0, gen_blocks = 0;
+    if (p.gen.nseg)
+    {
+        if (!post_can_generate(p.gen))
+            return hipErrorInvalidValue;
+        for (uint32_t s = 0; s < p.gen.nseg; s++)
+            gen_total += p.gen.seg[s].count;
+        if (gen_total == 0)
+            p.gen.nseg = 0;
+    }
+    if (p.gen.nseg)
+    {
+        p.gen.use_lds = 1;
+        lds = std::max(lds, (size_t)p.gen.table_bytes);
+    }
+    // the commit walk's parked sets take what LDS is left - all of it while the generator's workgroups are few (one per
+    // CU is plenty then), half of it when they are many (cold chains drawing a thousand candidates each: two generator
+    // workgroups per CU matter more than the commit walk's bursts)
+    p.n_cblk = 0;
+    if (p.commit.nitems)
+    {
+        const bool many = (gen_total + GEN_WAVES - 1) / GEN_WAVES > 256u;
+        size_t budget = many ? MAX_LDS_BYTES / 2 : MAX_LDS_BYTES;
+        size_t clds = 0;
+        hipError_t e = shape_walk(p.commit, true, POST_WAVES, budget, &clds);
+        if (e != hipSuccess && many)
+            e = shape_walk(p.commit, true, POST_WAVES, MAX_LDS_BYTES, &clds);
+        if (e != hipSuccess)
+            return e;
+        p.commit.flip = 0;
+        p.commit.watcher = 0;
+        lds = std::max(lds, clds);
+        p.n_cblk = (p.commit.nitems + POST_WAVES - 1) / POST_WAVES;
+    }
+    if (p.gen.nseg)
+        gen_blocks = deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))));
+    const uint32_t nblk = p.n_reb + p.n_cblk + gen_blocks;
+    if (nblk == 0)
+        return hipSuccess;
+    const bool wide = p.commit.nitems != 0 && walk_needs_wide(p.commit);
+    const dim3 grid(nblk), block(GEN_THREADS);
+    const bool idx16 = (p.gen.nseg ? p.gen.idx_bytes : p.reb.idx_bytes) != 4;
+    if (idx16)
+    {
+        if (wide)
+            hipLaunchKernelGGL((post_kernel<uint16_t, true>), grid, block, lds, stream, p);
+        else
+            hipLaunchKernelGGL((post_kernel<uint16_t, false>), grid, block, lds, stream, p);
+    }
+    else if (wide)
+        hipLaunchKernelGGL((post_kernel<int32_t, true>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((post_kernel<int32_t, false>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

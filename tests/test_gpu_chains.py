@@ -441,14 +441,21 @@ def test_site_axis_shards_add_up(mods):
     whole.close()
 
 
-def test_random_operations_over_chains_against_the_cpu_oracle(mods):
+@pytest.mark.parametrize("pair_min", [0, 4])
+def test_random_operations_over_chains_against_the_cpu_oracle(mods, monkeypatch, pair_min):
     """A random mix of everything that can change a chain - picks from multi-chain batches, batched re-roots, commits of
-    host-built rewrites, device moves through the single-tree calls - with every chain checked against the CPU ORACLE
-    after each operation: full evaluation of the topology the library reports == the resident length, per-node changes
-    and node sets; and the next device-drawn neighbourhood scores what the oracle scores."""
+    host-built rewrites, device moves through the single-tree calls, host-made (cumulative) candidates of several chains
+    scored in one walk and accepted in one commit walk (the accepted ones' SCORED programs walked again, or programs
+    built for the commit), whole annealing steps decided and committed by the library, big batches through the walk that
+    takes two candidates per wave - with every chain checked against the CPU ORACLE after each operation: full evaluation
+    of the topology the library reports == the resident length, per-node changes and node sets; and the next device-drawn
+    neighbourhood scores what the oracle scores.  pair_min 4: the same with LVBGPU_PAIR=4 (every device- or host-built
+    batch of four candidates and more is walked two candidates per wave)."""
     from oracle import binding as ob
     from tests import helpers
     api, host = mods
+    if pair_min:
+        monkeypatch.setenv("LVBGPU_PAIR", str(pair_min))
     n, m, R = 26, 520, 4
     rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 101))
     enc = ob.encode_rows(rows)
@@ -473,9 +480,39 @@ def test_random_operations_over_chains_against_the_cpu_oracle(mods):
         assert np.array_equal(ctx.all_sets(), t.all_sets())
         return t, l, r, root
 
+    def full_length(l, r, root, edits):
+        """length of the tree the rewrites give, from the leaves up (the oracle's getplen with every node dirty)"""
+        nl, nr = helpers.apply_edits(l, r, edits)
+        t = ob.OracleTree(n, enc.shape[1], enc)
+        t.set_topology(helpers.parents_of(nl, nr), nl, nr, root)
+        return t.getplen()
+
+    def merged(first, second):
+        """cumulative rewrites: `second` was drawn on the tree `first` gives (a later rewrite of a node replaces the earlier)"""
+        out = {int(e["node"]): (int(e["left"]), int(e["right"])) for e in first}
+        out.update({int(e["node"]): (int(e["left"]), int(e["right"])) for e in second})
+        return np.array([(v, a, b) for v, (a, b) in out.items()], dtype=api.EDIT_DTYPE)
+
+    def host_made(c, k, seed):
+        """k candidates of chain c as rewrites of its resident tree: single moves and runs of two or three moves"""
+        _, l, r, root = oracle_of(c)
+        cands = []
+        for i in range(k):
+            ht = host.HostTree(left=l, right=r, root=root, seed=seed + 13 * i)
+            e = ht.propose(int(rng.integers(0, 3)))
+            cum = e
+            for _ in range(int(rng.integers(0, 3))):      # a run: the next move is drawn on the tree so far
+                ht.apply(e)
+                e = ht.propose(int(rng.integers(0, 3)))
+                cum = merged(cum, e)
+            ht.close()
+            cands.append(cum)
+        return cands, (l, r, root)
+
     rng = np.random.default_rng(12)
-    for step in range(36):
-        op = int(rng.integers(0, 4))
+    reused0, steps_taken, big_scored = ctx.commits_reusing_programs(), 0, 0
+    for step in range(48):
+        op = int(rng.integers(0, 7))
         if op == 0:      # one step over a random subset of chains, some of them accept
             active = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
             draws = [(c, int(rng.integers(2, 40)), -1, 10_000 + 97 * step + c) for c in active]
@@ -501,13 +538,67 @@ def test_random_operations_over_chains_against_the_cpu_oracle(mods):
             ht = host.HostTree(left=l, right=r, root=root, seed=500 + step)
             ctx.select_chain(c)
             ctx.commit(ht.propose(int(rng.integers(0, 3))))
-        else:            # a device move through the single-tree calls
+        elif op == 3:    # a device move through the single-tree calls
             c = int(rng.integers(0, R))
             ctx.select_chain(c)
             lens = ctx.propose_score(12, -1, 777 + step)
             b = int(rng.integers(0, 12))
             edits, _ = ctx.proposal_edits(b)
             assert ctx.commit(edits) == lens[b]
+        elif op == 4:    # host-made candidates of several chains (cumulative rewrites among them) in ONE walk, the accepted
+            #              ones in ONE commit walk.  A big batch leaves its programs on the device and the commit walks the
+            #              SCORED programs again; a small one is read in place from pinned memory and the commit builds anew
+            big = bool(rng.integers(0, 2))
+            who = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
+            chain_of, cands, trees_of = [], [], {}
+            for c in who:
+                mine, trees_of[c] = host_made(c, int(rng.integers(150, 200)) if big else int(rng.integers(2, 7)), 900 * step + c)
+                chain_of += [c] * len(mine)
+                cands += mine
+            lens = ctx.chains_score_edits(chain_of, cands)
+            sample = range(len(cands)) if not big else rng.choice(len(cands), size=24, replace=False).tolist()
+            for b in sample:
+                assert int(lens[b]) == full_length(*trees_of[chain_of[b]], cands[b]), (step, b)
+            take = {c: int(rng.choice([b for b in range(len(cands)) if chain_of[b] == c])) for c in who if rng.random() < 0.8}
+            if take:
+                before = ctx.commits_reusing_programs()
+                ctx.chains_commit_edits(list(take), [cands[b] for b in take.values()])
+                # (a batch beyond the direct-step size leaves its programs on the device: 4 chains x 150+ candidates)
+                assert (ctx.commits_reusing_programs() == before + 1) == (len(cands) > 512), (step, len(cands))
+                for c, b in take.items():
+                    ctx.select_chain(c)
+                    assert ctx.current_length() == int(lens[b]), (step, c)
+        elif op == 5:    # a whole annealing step: the library decides by decide.h's rule and commits every chain's pick
+            active = sorted(rng.choice(R, size=int(rng.integers(1, R + 1)), replace=False).tolist())
+            draws = [(c, int(rng.integers(1, 60)), [0, 1, 2, -1][(step + c) % 4], 5000 * step + c) for c in active]
+            curs = []
+            for c in active:
+                ctx.select_chain(c)
+                curs.append(ctx.current_length())
+            rules = [(curs[i], [1e-9, 1e-5, 3e-4, 5e-2][(step + 2 * c) % 4], 3.0 * m, 17 * step + c) for i, c in enumerate(active)]
+            before = {c: oracle_of(c)[1:] for c in active}
+            lens, picks = ctx.chains_step(draws, rules)
+            for i, c in enumerate(active):
+                if picks[i] >= 0:
+                    steps_taken += 1
+                    edits = ctx.chains_step_edits(i)
+                    assert int(lens[i][picks[i]]) == full_length(*before[c], edits), (step, c)
+                    ctx.select_chain(c)
+                    assert ctx.current_length() == int(lens[i][picks[i]])
+                    # a worse candidate before the pick was refused, one no worse than the tree would have been taken
+                    assert all(int(v) > curs[i] for v in lens[i][: picks[i]])
+                else:
+                    assert all(int(v) > curs[i] for v in lens[i])
+        else:            # a big device-drawn batch of one chain (with LVBGPU_PAIR: two candidates per wave), sampled
+            c = int(rng.integers(0, R))
+            _, l, r, root = oracle_of(c)
+            ctx.select_chain(c)
+            B = int(rng.integers(600, 700))
+            lens = ctx.propose_score(B, -1, 4242 + step)
+            for b in rng.choice(B, size=24, replace=False).tolist():
+                edits, _ = ctx.proposal_edits(int(b))
+                assert int(lens[b]) == full_length(l, r, root, edits), (step, c, b)
+            big_scored += 1
         for c in range(R):
             cur, l, r, root = check(c)
             # the next neighbourhood of this chain, drawn on the device, against the oracle's incremental getplen
@@ -522,7 +613,90 @@ def test_random_operations_over_chains_against_the_cpu_oracle(mods):
                 cand.set_topology(helpers.parents_of(nl, nr), nl, nr, root)
                 cand.mark_dirty([d for d in prog["dsts"] if d >= 0])
                 assert int(lens[b]) == cand.getplen(), (step, c, b)
+    # every kind of operation happened, both branches of the host-made commit among them
+    assert ctx.commits_reusing_programs() > reused0 and steps_taken > 0 and big_scored > 0
+    assert (ctx.paired_walks() > 0) == (pair_min > 0)
     ctx.close()
+
+
+def test_commits_reroots_and_the_next_generator_in_one_launch(mods):
+    """What lies between two scoring walks of an annealing step - the commit walk of the chains' accepted candidates (their
+    own device-built programs), the re-roots of other chains (host-built programs), the table rebuilds of both and the NEXT
+    step's generator, whose segments wait for their chains' rebuilds - goes out as ONE post launch when the steps take
+    turns in the two batch slots.  Same lengths, picks, trees, per-node changes and node sets as a context that is made to
+    catch up after every single call (its commits, re-roots and generators are launches of their own), and as the CPU
+    oracle's full evaluation of the final trees."""
+    from oracle import binding as ob
+    from tests import helpers
+    api, host = mods
+    n, m, R = 48, 4000, 6
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 77))
+    enc = ob.encode_rows(rows)
+    one, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
+    cur = []
+    for c_ in (one, ref):
+        c_.set_chains(R)
+    for c in range(R):
+        t = host.HostTree(n, seed=4100 + c)
+        for c_ in (one, ref):
+            c_.select_chain(c)
+            length = t.upload(c_)
+        cur.append(length)
+    roots = []
+    for c in range(R):
+        one.select_chain(c)
+        roots.append(one.topology()[3])
+    rng = np.random.default_rng(8)
+    both = rerooted = 0
+    for step in range(60):
+        slot = step & 1
+        active = sorted(rng.choice(R, size=int(rng.integers(2, R + 1)), replace=False).tolist())
+        draws = [(c, int(rng.integers(1, 70)), [1, 2, -1, 0][(step + c) % 4], 9000 * step + c) for c in active]
+        rules = [(cur[c], [1e-9, 2e-5, 4e-4, 5e-2][(step + c) % 4], float(min_len), 31 * step + c) for c in active]
+        lens, picks = one.chains_step(draws, rules, slot=slot)
+        ref.synchronize()
+        rlens, rpicks = ref.chains_step(draws, rules, slot=slot)
+        ref.synchronize()
+        assert np.array_equal(picks, rpicks), step
+        for i, c in enumerate(active):
+            assert np.array_equal(lens[i], rlens[i]), (step, c)
+            if picks[i] >= 0:
+                cur[c] = int(lens[i][picks[i]])
+        # re-roots of chains that accepted nothing (the usual case in a run: a chain's tick comes when a whole draw was
+        # refused) and now and then of one that did (its accepted move has to reach the host first: two launches)
+        who = [c for i, c in enumerate(active) if (picks[i] < 0 or rng.random() < 0.15) and rng.random() < 0.6]
+        if who:
+            reqs = []
+            for c in who:
+                roots[c] = int((roots[c] + 1 + rng.integers(0, n - 1)) % n)
+                reqs.append((c, roots[c]))
+            both += sum(1 for i, c in enumerate(active) if c in who and picks[i] >= 0)
+            rerooted += len(who)
+            one.chains_reroot(reqs)
+            ref.chains_reroot(reqs)
+            ref.synchronize()
+    posts, with_generator = one.post_launches()
+    rposts, rwith = ref.post_launches()
+    assert with_generator > 30 and rwith == 0, (posts, with_generator, rposts, rwith)
+    assert posts < rposts and rerooted > 10 and both > 0
+    for c in range(R):
+        for c_ in (one, ref):
+            c_.select_chain(c)
+        assert one.current_length() == ref.current_length() == cur[c], c
+        assert np.array_equal(one.changes(), ref.changes())
+        assert np.array_equal(one.all_sets(), ref.all_sets())
+        pm, pr = one.topology(), ref.topology()
+        assert all(np.array_equal(a, b) for a, b in zip(pm[:3], pr[:3])) and pm[3] == pr[3] == roots[c]
+        _, l, r, root = pm
+        l64, r64 = l.astype(np.int64), r.astype(np.int64)
+        t = ob.OracleTree(n, enc.shape[1], enc)
+        t.set_topology(helpers.parents_of(l64, r64), l64, r64, root)
+        assert t.getplen() == cur[c]
+        assert np.array_equal(one.changes()[n:], t.changes()[n:]) and np.array_equal(one.all_sets(), t.all_sets())
+        # ... and the generator's tables have followed: the next neighbourhoods are the same
+        assert np.array_equal(one.propose_score(40, -1, 99 + c), ref.propose_score(40, -1, 99 + c))
+    one.close()
+    ref.close()
 
 
 def test_pick_slots_survive_collects_of_batches_submitted_before_their_use(mods):
