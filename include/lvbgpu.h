@@ -100,6 +100,9 @@ int lvbgpu_encode_text(int device, long n, long m, const char *const *rows, uint
 int lvbgpu_create(lvbgpu_ctx **out, int device, long n, long nwords, const uint64_t *leaf_matrix,
                   long row_stride_words);
 int lvbgpu_create_from_text(lvbgpu_ctx **out, int device, long n, long m, const char *const *rows);
+/* a second context on the same alignment and device (the leaf rows are copied on the device; one tree slot, no tree):
+ * own stream, own batches - what two groups of chains need whose device work is to overlap (lvbhost_anneal_chains) */
+int lvbgpu_fork(lvbgpu_ctx *src, lvbgpu_ctx **out);
 void lvbgpu_destroy(lvbgpu_ctx *ctx);
 long lvbgpu_n(const lvbgpu_ctx *ctx);
 long lvbgpu_nwords(const lvbgpu_ctx *ctx);
@@ -247,6 +250,9 @@ typedef struct
 int lvbgpu_chains_step_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_draw *draws,
                               const lvbgpu_chain_rule *rules);
 int lvbgpu_chains_step_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out, int32_t *picks_out);
+/* *ready = 1 if that slot's submitted batch (or step) has its lengths on the host - the collect would not wait -, else 0;
+ * never waits: for a host that serves several contexts and takes whichever is done first */
+int lvbgpu_chains_ready(lvbgpu_ctx *ctx, int32_t slot, int32_t *ready);
 int lvbgpu_chains_step_edits(lvbgpu_ctx *ctx, int32_t i, lvbgpu_edit *edits, int32_t cap, int32_t *n_edits);
 
 /* counts of the LAST device-built batch (as lvbgpu_batch_get_stats gives for host-built ones; candidates that

@@ -149,6 +149,12 @@ typedef struct
                                  first chain's parameters counts for all.  Pays for one or two chains per context
                                  (500 x 50 000: 0.36 -> 0.28 s for one, 0.43 -> 0.38 s for two); even at four, a loss
                                  beyond: the host draws and builds ~10 us of programs per chain and step */
+    int32_t lanes;            /* lvbhost_anneal_chains: the chains are dealt to this many LANES - contexts of their own
+                                 (lvbgpu_fork: own stream and batches) that ONE host thread serves in turn, whichever
+                                 lane's lengths have arrived - so that one lane's scoring walk covers another's host work
+                                 and post launch.  0: automatic (2 from 16 chains on, else 1; LVBHOST_LANES overrides).
+                                 A chain's trajectory does not depend on it.  The first chain's value counts for all;
+                                 lockstep runs (sync_every > 0) keep one lane */
 } lvbhost_anneal_params;
 
 typedef struct

@@ -88,6 +88,8 @@ SIGNATURES = {
     "lvbgpu_chains_picked_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_chains_step_submit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "lvbgpu_chains_step_collect": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i32p]),
+    "lvbgpu_chains_ready": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lvbgpu_fork": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "lvbgpu_chains_step_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_proposal_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),
@@ -218,6 +220,14 @@ class FitchContext:
         self.n = int(self.lib.lvbgpu_n(h))
         self.nwords = int(self.lib.lvbgpu_nwords(h))
         self.nbranches = 2 * self.n - 3
+
+    def fork(self) -> "FitchContext":
+        """A second context on the same alignment (leaf rows copied on the device): own stream, one tree slot, no tree."""
+        h = C.c_void_p()
+        self._chk(self.lib.lvbgpu_fork(self.h, C.byref(h)))
+        twin = object.__new__(FitchContext)
+        twin.lib, twin.h, twin.n, twin.nwords, twin.nbranches = self.lib, h, self.n, self.nwords, self.nbranches
+        return twin
 
     def last_error(self) -> str:
         return (self.lib.lvbgpu_last_error(self.h) or b"").decode()

@@ -208,6 +208,7 @@ extern "C" void lvbhost_anneal_defaults(lvbhost_anneal_params *p)
     p->log_cap = 0;
     p->device_proposals = 2;
     p->run_levels = 0;
+    p->lanes = 0;
 }
 
 extern "C" int lvbhost_starting_temperature(lvbgpu_ctx *ctx, lvbhost_tree *tree, const lvbhost_anneal_params *p,

@@ -677,24 +677,107 @@ struct ChainRun
 
 namespace
 {
-// the chains of ONE context stepped together; wall0: the run's clock origin (shared by the groups of a grouped run)
+// One LANE: some of the run's chains in a context of their own (own stream, own batches), stepped together.  The lanes'
+// steps overlap on the device: while one lane's lengths are on their way to the host, are consumed and its next step is
+// planned and submitted, the device walks the other lane's candidates.
+struct Lane
+{
+    lvbgpu_ctx *ctx = nullptr;
+    bool forked = false;       // made here (lvbgpu_fork), destroyed here
+    int32_t first = 0, count = 0; // chains [first, first + count) of the run, chain c being slot c - first of ctx
+    // the step in flight
+    std::vector<lvbgpu_chain_draw> draws;
+    std::vector<lvbgpu_chain_rule> rules;
+    std::vector<int32_t> who; // global chain numbers, by draw
+    std::vector<int64_t> lens;
+    std::vector<int32_t> picks;
+    size_t total = 0;
+    bool active = false;
+    // the two batch slots take turns: the step being submitted draws into one while the chains' accepted candidates of
+    // the step before still lie in the other - their commit walk rides in the SAME launch as this step's generator
+    // (the library's post launch), which it could not if the generator overwrote their programs
+    int32_t slot = 0;
+    bool host_stepped = false;
+    // the host part of a step (runs of acceptances while chains are hot)
+    std::vector<ChainRun *> hot;
+    std::vector<uint8_t> hot_rerooted;
+    std::vector<int32_t> h_chain_of, h_offs, h_first, h_commit_chain, h_commit_offs;
+    std::vector<lvbgpu_edit> h_edits, h_commit_edits;
+    std::vector<int64_t> h_lens;
+    std::vector<lvbgpu_chain_root> roots;
+    int64_t steps = 0;
+};
+struct LaneGuard // the forked contexts go with the run, whichever way it ends
+{
+    std::vector<Lane> &lanes;
+    ~LaneGuard()
+    {
+        for (Lane &l : lanes)
+            if (l.forked && l.ctx)
+                lvbgpu_destroy(l.ctx);
+    }
+};
+
+// the chains of one run, in one or more lanes; wall0: the run's clock origin
 int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, const lvbhost_anneal_params *params,
                       lvbhost_anneal_result *results, double *log_seconds, int64_t *log_best, int32_t *n_log,
                       const Clock::time_point wall0)
 {
     if (!ctx || R < 1 || R > 64 || !trees || !params || !results)
         return LVBGPU_E_ARG;
-    int rc = LVBGPU_OK;
-    if (lvbgpu_chains(ctx) != R)
-        rc = lvbgpu_set_chains(ctx, R);
-    std::vector<ChainRun> runs((size_t)R);
-    for (int32_t c = 0; c < R && rc == LVBGPU_OK; c++)
-    {
+    for (int32_t c = 0; c < R; c++)
         if (!trees[c])
             return LVBGPU_E_ARG;
+    const bool lockstep = params[0].sync_every > 0;
+    if (lockstep && params[0].max_device_steps <= 0)
+        return LVBGPU_E_ARG;
+    // How many lanes.  A step is a chain: scoring walk -> lengths to the host -> the host consumes, plans, submits ->
+    // post launch (commit walk, table rebuilds, generator) -> scoring walk.  With all chains in one lane the device idles
+    // while the host works and only the post launch's few workgroups run between two walks: at 32 chains of 500 x 50 000
+    // the walk is 62 % of a step (rocprofv3: walk 102 us, post launch 35 us, host gap 27 us).  Two lanes take turns: one
+    // lane's walk covers the other's host work and post launch.  (Round 2/3 measured two groups taking turns on ONE
+    // stream - a loss, everything of one group waits behind the other's walk - and groups with host threads and contexts
+    // of their own - no gain; here ONE host thread serves whichever lane's lengths have arrived.)  From 16 chains on by
+    // default (a lane of few chains does not fill the chip); lockstep runs keep one lane (their step count is the
+    // collectives' clock).
+    int32_t nl = params[0].lanes > 0 ? params[0].lanes : (R >= 16 ? 2 : 1);
+    if (const char *e = getenv("LVBHOST_LANES"))
+        if (atoi(e) > 0)
+            nl = atoi(e);
+    nl = std::max(1, std::min({nl, R, 8}));
+    if (lockstep)
+        nl = 1;
+    std::vector<Lane> lanes((size_t)nl);
+    LaneGuard guard{lanes};
+    int rc = LVBGPU_OK;
+    for (int32_t g = 0; g < nl && rc == LVBGPU_OK; g++)
+    {
+        Lane &L = lanes[(size_t)g];
+        L.first = (int32_t)((int64_t)R * g / nl);
+        L.count = (int32_t)((int64_t)R * (g + 1) / nl) - L.first;
+        if (g == 0)
+            L.ctx = ctx;
+        else
+        {
+            rc = lvbgpu_fork(ctx, &L.ctx);
+            L.forked = rc == LVBGPU_OK;
+        }
+        if (rc == LVBGPU_OK && lvbgpu_chains(L.ctx) != L.count)
+            rc = lvbgpu_set_chains(L.ctx, L.count);
+    }
+    if (rc != LVBGPU_OK)
+        return rc;
+    std::vector<ChainRun> runs((size_t)R);
+    std::vector<int32_t> lane_of((size_t)R, 0);
+    for (int32_t g = 0; g < nl; g++)
+        for (int32_t c = lanes[(size_t)g].first; c < lanes[(size_t)g].first + lanes[(size_t)g].count; c++)
+            lane_of[(size_t)c] = g;
+    for (int32_t c = 0; c < R && rc == LVBGPU_OK; c++)
+    {
+        Lane &L = lanes[(size_t)lane_of[(size_t)c]];
         ChainRun &r = runs[(size_t)c];
-        r.chain = c;
-        r.ctx = ctx;
+        r.chain = c - L.first;
+        r.ctx = L.ctx;
         r.tree = trees[c];
         r.p = params[c];
         if (r.p.batch < 1)
@@ -703,9 +786,9 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         *r.res = lvbhost_anneal_result{};
         r.minlen = (double)r.p.min_len_tree;
         r.tree->rng = Rng(r.p.seed);
-        rc = lvbgpu_select_chain(ctx, c);
+        rc = lvbgpu_select_chain(L.ctx, r.chain);
         if (rc == LVBGPU_OK)
-            rc = lvbhost_tree_upload(ctx, r.tree, &r.cur);
+            rc = lvbhost_tree_upload(L.ctx, r.tree, &r.cur);
         r.res->start_length = r.cur;
         if (r.p.t0 > 0.0)
             r.begin_anneal(r.p.t0);
@@ -737,29 +820,10 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
     };
     log_point();
 
-    // (Stepping the chains as two groups taking turns - the host working on one group's lengths while the device draws and
-    // scores the other's - was measured in rounds 2 and 3 and LOSES on MI355X (R = 32: 1.345 -> 1.578 s): a step is mostly
-    // fixed device latency and two half-sized groups pay it twice on one in-order stream.  Groups side by side on streams
-    // and host threads of their own lost as well (1.42 s with one group, 1.86 s with eight); round 4 removed them.)
-    struct Flight
-    {
-        std::vector<lvbgpu_chain_draw> draws;
-        std::vector<lvbgpu_chain_rule> rules;
-        std::vector<int32_t> who;
-        std::vector<int64_t> lens;
-        std::vector<int32_t> picks;
-        size_t total = 0;
-        bool active = false;
-        // the two batch slots take turns: the step being submitted draws into one while the chains' accepted candidates of
-        // the step before still lie in the other - their commit walk rides in the SAME launch as this step's generator
-        // (the library's post launch), which it could not if the generator overwrote their programs
-        int32_t slot = 0;
-    } f;
-    std::vector<lvbgpu_chain_root> roots;
     int64_t steps = 0, busy_scored = 0;
     double dev_seconds = 0.0, busy_seconds = 0.0;
     double t_plan = 0, t_score = 0, t_consume = 0, t_after = 0; // LVBHOST_PROFILE=1 prints them
-    double t_submit = 0, t_reroot = 0; // ... and, of those, the submit call (part of propose_score) and the re-roots (part of plan)
+    double t_submit = 0, t_reroot = 0, t_idle = 0; // ... and, of those, the submit call (part of propose_score), the re-roots (part of plan); waiting for any lane
     const bool profile = getenv("LVBHOST_PROFILE") != nullptr;
     int64_t p_sc = 0, p_co = 0, p_ac = 0, p_cs = 0;
     auto chain_steps_now = [&] {
@@ -768,21 +832,12 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             v += r.res->device_steps;
         return v;
     };
-    const bool lockstep = params[0].sync_every > 0;
-    if (lockstep && params[0].max_device_steps <= 0)
-        return LVBGPU_E_ARG;
 
-    // Runs of acceptances in one step while chains are hot (ChainRun::hs_*): the hot chains of a step are served by the
-    // host part below - their cumulative candidates drawn here (on the context's host threads), ONE scoring walk for all of
-    // them (lvbgpu_chains_score_edits), ONE commit walk for what they accept (lvbgpu_chains_commit_edits) - the others by
-    // the device step as before; a step may have both parts.
+    // Runs of acceptances in one step while chains are hot (ChainRun::hs_*): the hot chains of a lane's step are served by
+    // the host part below - their cumulative candidates drawn here (on the context's host threads), ONE scoring walk for
+    // all of them (lvbgpu_chains_score_edits), ONE commit walk for what they accept (lvbgpu_chains_commit_edits) - the
+    // others by the device step as before; a step may have both parts.
     const int levels = std::max(0, (int)params[0].run_levels);
-    bool host_stepped = false;
-    std::vector<ChainRun *> hot;
-    std::vector<uint8_t> hot_rerooted;
-    std::vector<int32_t> h_chain_of, h_offs, h_first, h_commit_chain, h_commit_offs;
-    std::vector<lvbgpu_edit> h_edits, h_commit_edits;
-    std::vector<int64_t> h_lens;
     double hs_score_s = 0, hs_commit_s = 0, hs_prep_s = 0;
     int64_t hs_parts = 0;
     struct HotJob
@@ -792,95 +847,96 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         const int64_t *lens;
         const int32_t *first;
         int levels;
-    } hot_job{&hot, &hot_rerooted, nullptr, nullptr, levels};
-    // the host part of a step: everything for the hot chains, start to finish (nothing of it stays in flight)
-    auto host_part = [&]() -> int {
+    };
+    // the host part of a step: everything for the lane's hot chains, start to finish (nothing of it stays in flight)
+    auto host_part = [&](Lane &L) -> int {
+        HotJob hot_job{&L.hot, &L.hot_rerooted, nullptr, nullptr, levels};
         auto t0 = Clock::now();
         // re-roots first (the candidates are drawn on the re-rooted trees), all of them in one walk
-        roots.clear();
-        hot_rerooted.assign(hot.size(), 0);
-        for (size_t i = 0; i < hot.size(); i++)
+        L.roots.clear();
+        L.hot_rerooted.assign(L.hot.size(), 0);
+        for (size_t i = 0; i < L.hot.size(); i++)
         {
-            hot[i]->finish_follow();
-            if (hot[i]->rc != LVBGPU_OK)
-                return hot[i]->rc;
-            if (hot[i]->hs_wants_reroot())
+            L.hot[i]->finish_follow();
+            if (L.hot[i]->rc != LVBGPU_OK)
+                return L.hot[i]->rc;
+            if (L.hot[i]->hs_wants_reroot())
             {
-                roots.push_back({hot[i]->chain, hot[i]->pending_root});
-                hot_rerooted[i] = 1;
+                L.roots.push_back({L.hot[i]->chain, L.hot[i]->pending_root});
+                L.hot_rerooted[i] = 1;
             }
         }
-        if (!roots.empty())
+        if (!L.roots.empty())
         {
-            int rr = lvbgpu_chains_reroot(ctx, (int32_t)roots.size(), roots.data());
-            for (size_t i = 0; i < hot.size() && rr == LVBGPU_OK; i++)
-                if (hot_rerooted[i])
-                    rr = hot[i]->rerooted();
+            int rr = lvbgpu_chains_reroot(L.ctx, (int32_t)L.roots.size(), L.roots.data());
+            for (size_t i = 0; i < L.hot.size() && rr == LVBGPU_OK; i++)
+                if (L.hot_rerooted[i])
+                    rr = L.hot[i]->rerooted();
             if (rr != LVBGPU_OK)
                 return rr;
         }
-        int rp = lvbgpu_parallel_for(ctx, (int32_t)hot.size(), [](int32_t i, void *a) {
+        int rp = lvbgpu_parallel_for(L.ctx, (int32_t)L.hot.size(), [](int32_t i, void *a) {
             HotJob *j = (HotJob *)a;
             (*j->hot)[(size_t)i]->hs_draw(j->levels, (*j->rerooted)[(size_t)i] != 0); }, &hot_job);
         if (rp != LVBGPU_OK)
             return rp;
-        h_chain_of.clear();
-        h_offs.assign(1, 0);
-        h_edits.clear();
-        h_first.clear();
-        for (ChainRun *r : hot)
+        L.h_chain_of.clear();
+        L.h_offs.assign(1, 0);
+        L.h_edits.clear();
+        L.h_first.clear();
+        for (ChainRun *r : L.hot)
         {
             if (r->rc != LVBGPU_OK)
                 return r->rc;
-            h_first.push_back((int32_t)h_chain_of.size());
-            const int32_t base = (int32_t)h_edits.size();
+            L.h_first.push_back((int32_t)L.h_chain_of.size());
+            const int32_t base = (int32_t)L.h_edits.size();
             for (int32_t c = 0; c < r->hs_ncand; c++)
             {
-                h_chain_of.push_back(r->chain);
-                h_offs.push_back(base + r->offs[(size_t)c + 1]);
+                L.h_chain_of.push_back(r->chain);
+                L.h_offs.push_back(base + r->offs[(size_t)c + 1]);
             }
             const lvbgpu_edit *e = reinterpret_cast<const lvbgpu_edit *>(r->all_edits.data());
-            h_edits.insert(h_edits.end(), e, e + r->all_edits.size());
+            L.h_edits.insert(L.h_edits.end(), e, e + r->all_edits.size());
         }
-        h_lens.resize(h_chain_of.size());
+        L.h_lens.resize(L.h_chain_of.size());
         hs_prep_s += since(t0);
         t0 = Clock::now();
-        int rs = lvbgpu_chains_score_edits(ctx, (int32_t)h_chain_of.size(), h_chain_of.data(), h_offs.data(), h_edits.data(), h_lens.data());
+        int rs = lvbgpu_chains_score_edits(L.ctx, (int32_t)L.h_chain_of.size(), L.h_chain_of.data(), L.h_offs.data(), L.h_edits.data(), L.h_lens.data());
         if (rs != LVBGPU_OK)
             return rs;
         hs_score_s += since(t0);
         t0 = Clock::now();
-        hot_job.lens = h_lens.data();
-        hot_job.first = h_first.data();
-        rp = lvbgpu_parallel_for(ctx, (int32_t)hot.size(), [](int32_t i, void *a) {
+        hot_job.lens = L.h_lens.data();
+        hot_job.first = L.h_first.data();
+        rp = lvbgpu_parallel_for(L.ctx, (int32_t)L.hot.size(), [](int32_t i, void *a) {
             HotJob *j = (HotJob *)a;
             (*j->hot)[(size_t)i]->hs_consume(j->lens + j->first[(size_t)i]); }, &hot_job);
         if (rp != LVBGPU_OK)
             return rp;
-        h_commit_chain.clear();
-        h_commit_offs.assign(1, 0);
-        h_commit_edits.clear();
-        for (ChainRun *r : hot)
+        L.h_commit_chain.clear();
+        L.h_commit_offs.assign(1, 0);
+        L.h_commit_edits.clear();
+        for (ChainRun *r : L.hot)
         {
             if (r->rc != LVBGPU_OK)
                 return r->rc;
             if (r->hs_acc < 0)
                 continue;
             const lvbgpu_edit *e = reinterpret_cast<const lvbgpu_edit *>(r->all_edits.data());
-            h_commit_chain.push_back(r->chain);
-            h_commit_edits.insert(h_commit_edits.end(), e + r->offs[(size_t)r->hs_acc], e + r->offs[(size_t)r->hs_acc + 1]);
-            h_commit_offs.push_back((int32_t)h_commit_edits.size());
+            L.h_commit_chain.push_back(r->chain);
+            L.h_commit_edits.insert(L.h_commit_edits.end(), e + r->offs[(size_t)r->hs_acc], e + r->offs[(size_t)r->hs_acc + 1]);
+            L.h_commit_offs.push_back((int32_t)L.h_commit_edits.size());
         }
-        if (!h_commit_chain.empty())
+        if (!L.h_commit_chain.empty())
         {
-            const int rcm = lvbgpu_chains_commit_edits(ctx, (int32_t)h_commit_chain.size(), h_commit_chain.data(), h_commit_offs.data(),
-                                                       h_commit_edits.data());
+            const int rcm = lvbgpu_chains_commit_edits(L.ctx, (int32_t)L.h_commit_chain.size(), L.h_commit_chain.data(), L.h_commit_offs.data(),
+                                                       L.h_commit_edits.data());
             if (rcm != LVBGPU_OK)
                 return rcm;
-            rp = lvbgpu_parallel_for(ctx, (int32_t)hot.size(), [](int32_t i, void *a) { (*((HotJob *)a)->hot)[(size_t)i]->hs_follow(); }, &hot_job);
+            rp = lvbgpu_parallel_for(L.ctx, (int32_t)L.hot.size(), [](int32_t i, void *a) { (*((HotJob *)a)->hot)[(size_t)i]->hs_follow(); }, &hot_job);
             if (rp != LVBGPU_OK)
                 return rp;
-            for (ChainRun *r : hot)
+            for (ChainRun *r : L.hot)
                 if (r->rc != LVBGPU_OK)
                     return r->rc;
         }
@@ -889,97 +945,100 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         return LVBGPU_OK;
     };
 
-    // plan the chains and enqueue their step (nothing if every chain is done)
-    auto submit_step = [&]() -> int {
-        hot.clear();
-        host_stepped = false;
+    // plan the lane's chains and enqueue their step (nothing if every chain is done)
+    auto submit_step = [&](Lane &L) -> int {
+        L.hot.clear();
+        L.host_stepped = false;
         if (levels > 0)
-            for (ChainRun &r : runs)
-                if (r.wants_host_step(levels))
-                    hot.push_back(&r);
-        f.draws.clear();
-        f.rules.clear();
-        f.who.clear();
-        f.total = 0;
-        f.active = false;
+            for (int32_t c = L.first; c < L.first + L.count; c++)
+                if (runs[(size_t)c].wants_host_step(levels))
+                    L.hot.push_back(&runs[(size_t)c]);
+        L.draws.clear();
+        L.rules.clear();
+        L.who.clear();
+        L.total = 0;
+        L.active = false;
         auto tp = Clock::now();
-        for (ChainRun &r : runs)
+        for (int32_t c = L.first; c < L.first + L.count; c++)
         {
+            ChainRun &r = runs[(size_t)c];
             lvbgpu_chain_draw d{};
             lvbgpu_chain_rule rule{};
             if (r.hot)
                 continue; // (served by the host part)
             if (r.plan(d, rule))
             {
-                f.draws.push_back(d);
-                f.rules.push_back(rule);
-                f.who.push_back(r.chain);
-                f.total += (size_t)d.count;
+                L.draws.push_back(d);
+                L.rules.push_back(rule);
+                L.who.push_back(c);
+                L.total += (size_t)d.count;
             }
             else if (r.rc != LVBGPU_OK)
                 return r.rc;
         }
         // the chains whose re-root tick has come: all of them in one commit walk, before their candidates are drawn
-        roots.clear();
-        for (int32_t c : f.who)
+        L.roots.clear();
+        for (int32_t c : L.who)
             if (runs[(size_t)c].pending_root >= 0)
             {
                 runs[(size_t)c].finish_follow(); // the re-root's rewrites are made from the tree as it is NOW
                 if (runs[(size_t)c].rc != LVBGPU_OK)
                     return runs[(size_t)c].rc;
-                roots.push_back({c, runs[(size_t)c].pending_root});
+                L.roots.push_back({runs[(size_t)c].chain, runs[(size_t)c].pending_root});
             }
-        if (!roots.empty())
+        if (!L.roots.empty())
         {
             auto tr = Clock::now();
-            int rr = lvbgpu_chains_reroot(ctx, (int32_t)roots.size(), roots.data());
+            int rr = lvbgpu_chains_reroot(L.ctx, (int32_t)L.roots.size(), L.roots.data());
             t_reroot += since(tr);
-            for (size_t i = 0; i < roots.size() && rr == LVBGPU_OK; i++)
-                rr = runs[(size_t)roots[i].chain].rerooted();
+            for (size_t i = 0; i < L.roots.size() && rr == LVBGPU_OK; i++)
+                rr = runs[(size_t)(L.first + L.roots[i].chain)].rerooted();
             if (rr != LVBGPU_OK)
                 return rr;
         }
         t_plan += since(tp);
         int r = LVBGPU_OK;
-        if (!f.draws.empty())
+        if (!L.draws.empty())
         {
-            f.lens.resize(f.total);
-            f.picks.resize(f.draws.size());
+            L.lens.resize(L.total);
+            L.picks.resize(L.draws.size());
             auto td = Clock::now();
-            f.slot ^= 1;
-            r = lvbgpu_chains_step_submit(ctx, f.slot, (int32_t)f.draws.size(), f.draws.data(), f.rules.data());
+            L.slot ^= 1;
+            r = lvbgpu_chains_step_submit(L.ctx, L.slot, (int32_t)L.draws.size(), L.draws.data(), L.rules.data());
             dev_seconds += since(td);
             t_score += since(td);
             t_submit += since(td);
-            f.active = r == LVBGPU_OK;
+            L.active = r == LVBGPU_OK;
         }
-        if (r == LVBGPU_OK && !hot.empty()) // (while the device draws and walks the others' candidates)
+        if (r == LVBGPU_OK && !L.hot.empty()) // (while the device draws and walks the others' candidates)
         {
             auto td = Clock::now();
-            r = host_part();
+            r = host_part(L);
             dev_seconds += since(td);
             t_score += since(td);
-            host_stepped = r == LVBGPU_OK;
+            L.host_stepped = r == LVBGPU_OK;
         }
         return r;
     };
-    // the trees of the chains that accepted in the step before follow their moves now, while the device works
-    auto follow_all = [&]() -> int {
+    // the trees of the lane's chains that accepted in the step before follow their moves now, while the device works
+    auto follow_all = [&](Lane &L) -> int {
         auto tf = Clock::now();
-        for (ChainRun &r : runs)
+        for (int32_t c = L.first; c < L.first + L.count; c++)
+        {
+            ChainRun &r = runs[(size_t)c];
             if (r.deferred_pick >= 0)
             {
                 r.finish_follow();
                 if (r.rc != LVBGPU_OK)
                     return r.rc;
             }
+        }
         t_after += since(tf);
         return LVBGPU_OK;
     };
     // after every step: the log, when each chain stopped, until when at least half of them were still at it
     auto account = [&] {
         log_point(); // R comparisons: nothing next to a device step
-        // when did each chain stop, and until when was at least half of them still at it
         int32_t active = 0;
         int64_t scored_now = 0;
         const double now = since(wall0);
@@ -997,25 +1056,25 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             busy_scored = scored_now;
         }
     };
-    // the step's lengths and picks are back (or are waited for): every chain books its own; the accepted moves are
+    // the lane's lengths and picks are back (or are waited for): every chain books its own; the accepted moves are
     // committed already (lvbgpu_chains_step_*)
-    auto finish_step = [&]() -> int {
-        if (!f.active)
+    auto finish_step = [&](Lane &L) -> int {
+        if (!L.active)
             return LVBGPU_OK;
-        f.active = false;
+        L.active = false;
         auto td = Clock::now();
-        int r = lvbgpu_chains_step_collect(ctx, f.slot, f.lens.data(), f.picks.data());
+        int r = lvbgpu_chains_step_collect(L.ctx, L.slot, L.lens.data(), L.picks.data());
         dev_seconds += since(td);
         t_score += since(td);
         if (r != LVBGPU_OK)
             return r;
         size_t off = 0;
         auto tp = Clock::now();
-        for (size_t i = 0; i < f.draws.size(); i++)
+        for (size_t i = 0; i < L.draws.size(); i++)
         {
-            ChainRun &cr = runs[(size_t)f.who[i]];
-            const int b = cr.consume(f.lens.data() + off, f.picks[i]);
-            off += (size_t)f.draws[i].count;
+            ChainRun &cr = runs[(size_t)L.who[i]];
+            const int b = cr.consume(L.lens.data() + off, L.picks[i]);
+            off += (size_t)L.draws[i].count;
             if (cr.rc != LVBGPU_OK)
                 return cr.rc;
             if (b >= 0)
@@ -1026,23 +1085,86 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             }
         }
         t_consume += since(tp);
-        account();
         return LVBGPU_OK;
     };
-    rc = submit_step();
-    while (rc == LVBGPU_OK)
+    // which lane next: one whose step is the host's alone, else the first whose lengths have arrived (asked in turn,
+    // starting behind the lane served last; never waits inside the library - memory is polled)
+    int32_t last_served = nl - 1;
+    auto next_lane = [&](int32_t *out) -> int {
+        int32_t live = 0;
+        for (const Lane &L : lanes)
+            live += (L.active || L.host_stepped) ? 1 : 0;
+        if (!live)
+        {
+            *out = -1;
+            return LVBGPU_OK;
+        }
+        auto tw = Clock::now();
+        for (uint64_t spins = 1;; spins++)
+        {
+            for (int32_t k = 1; k <= nl; k++)
+            {
+                const int32_t g = (last_served + k) % nl;
+                Lane &L = lanes[(size_t)g];
+                int32_t ready = 0;
+                if (!L.active)
+                    ready = L.host_stepped ? 1 : 0;
+                else if (nl == 1)
+                    ready = 1; // (the collect waits, with the library's own deadline)
+                else
+                {
+                    const int rr = lvbgpu_chains_ready(L.ctx, L.slot, &ready);
+                    if (rr != LVBGPU_OK)
+                        return rr;
+                }
+                if (ready)
+                {
+                    *out = g;
+                    t_idle += since(tw);
+                    return LVBGPU_OK;
+                }
+            }
+            if ((spins & 0xFFFFu) == 0 && since(tw) > 60.0) // (the collect reports what is stuck)
+            {
+                for (int32_t g = 0; g < nl; g++)
+                    if (lanes[(size_t)g].active)
+                    {
+                        *out = g;
+                        return LVBGPU_OK;
+                    }
+            }
+        }
+    };
+
+    for (Lane &L : lanes)
     {
-        if (!lockstep && !f.active && !host_stepped)
-            break;
-        if (f.active)
-            rc = finish_step(); // (accounts for the step)
-        else
-            account(); // the host part was the whole step
-        host_stepped = false;
+        rc = submit_step(L);
         if (rc != LVBGPU_OK)
             break;
+    }
+    while (rc == LVBGPU_OK)
+    {
+        int32_t g = -1;
+        rc = next_lane(&g);
+        if (rc != LVBGPU_OK)
+            break;
+        if (g < 0)
+        {
+            if (!lockstep)
+                break;
+            g = 0; // a lockstep run keeps stepping (nothing to score) so that the collectives pair up
+        }
+        Lane &L = lanes[(size_t)g];
+        last_served = g;
+        if (L.active)
+            rc = finish_step(L);
+        L.host_stepped = false;
+        if (rc != LVBGPU_OK)
+            break;
+        account();
+        L.steps++;
         steps++;
-        if (profile && steps % 1000 == 0) // how full the batches are and how often a proposal is accepted, as the run goes
+        if (profile && steps % (1000 * (int64_t)nl) == 0) // how full the batches are and how often a proposal is accepted, as the run goes
         {
             int64_t sc = 0, co = 0, ac = 0;
             for (const ChainRun &r : runs)
@@ -1053,7 +1175,7 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             }
             fprintf(stderr, "[anneal_chains] step %lld at %.3f s: scored %lld (+%lld), consumed +%lld, accepted +%lld  => %.1f candidates per chain-step, "
                             "acceptance %.3f per consumed proposal\n",
-                    (long long)steps, since(wall0), (long long)sc, (long long)(sc - p_sc), (long long)(co - p_co), (long long)(ac - p_ac),
+                    (long long)(steps / nl), since(wall0), (long long)sc, (long long)(sc - p_sc), (long long)(co - p_co), (long long)(ac - p_ac),
                     (double)(sc - p_sc) / std::max<int64_t>(1, chain_steps_now() - p_cs), (double)(ac - p_ac) / std::max<int64_t>(1, co - p_co));
             p_sc = sc;
             p_co = co;
@@ -1063,9 +1185,9 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         bool stop = false;
         if (params[0].max_seconds > 0 && since(wall0) >= params[0].max_seconds)
             stop = true;
-        if (params[0].max_device_steps > 0 && steps >= params[0].max_device_steps)
-            stop = true;
-        if (lockstep) // every rank runs the same number of steps so that the collectives pair up
+        if (params[0].max_device_steps > 0 && L.steps >= params[0].max_device_steps)
+            stop = true; // (every lane gets that many steps: the others run on until they have theirs)
+        if (lockstep) // every rank runs the same number of steps so that the collectives pair up (one lane)
         {
             stop = steps >= params[0].max_device_steps;
             if (steps % params[0].sync_every == 0 || stop)
@@ -1079,22 +1201,43 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             }
         }
         if (stop)
-            break;
-        rc = submit_step();
+        {
+            if (params[0].max_seconds > 0 && since(wall0) >= params[0].max_seconds)
+                break; // out of time: whatever the other lanes have in flight is dropped with the run
+            if (lockstep)
+                break;
+            continue; // this lane has had its steps; the others finish theirs
+        }
+        rc = submit_step(L);
         if (rc == LVBGPU_OK)
-            rc = follow_all();
+            rc = follow_all(L);
     }
-    if (rc == LVBGPU_OK)
-        rc = follow_all(); // (a run that stopped right after a step)
+    // what is still in flight (a run that ran out of time while other lanes were at work) is booked like any other step -
+    // the collect commits its picks, so the chains' counters have to follow - and the trees follow their last moves
+    for (Lane &L : lanes)
+    {
+        if (rc == LVBGPU_OK && L.active)
+        {
+            rc = finish_step(L);
+            if (rc == LVBGPU_OK)
+            {
+                account();
+                L.steps++;
+                steps++;
+            }
+        }
+        if (rc == LVBGPU_OK)
+            rc = follow_all(L); // (a run that stopped right after a step)
+    }
     if (rc != LVBGPU_OK)
         return rc;
     const double secs = since(wall0);
-    if (getenv("LVBHOST_PROFILE"))
-        fprintf(stderr, "[anneal_chains] R=%d steps=%lld  per step (us): plan %.1f (re-roots %.1f)  step submit + collect %.1f (submit %.1f)  "
-                        "consume + bookkeeping %.1f  trees following %.1f  total %.1f\n",
-                R, (long long)steps, 1e6 * t_plan / steps, 1e6 * t_reroot / steps, 1e6 * t_score / steps, 1e6 * t_submit / steps,
-                1e6 * t_consume / steps, 1e6 * t_after / steps, 1e6 * secs / steps);
-    if (getenv("LVBHOST_PROFILE") && hs_parts)
+    if (profile && steps > 0)
+        fprintf(stderr, "[anneal_chains] R=%d lanes=%d lane-steps=%lld  per lane-step (us): plan %.1f (re-roots %.1f)  step submit + collect %.1f (submit %.1f)  "
+                        "consume + bookkeeping %.1f  trees following %.1f  waiting for a lane %.1f  wall per round of all lanes %.1f\n",
+                R, nl, (long long)steps, 1e6 * t_plan / steps, 1e6 * t_reroot / steps, 1e6 * t_score / steps, 1e6 * t_submit / steps,
+                1e6 * t_consume / steps, 1e6 * t_after / steps, 1e6 * t_idle / steps, 1e6 * secs * nl / steps);
+    if (profile && hs_parts)
     {
         int64_t chain_steps = 0, cands = 0;
         double draw_s = 0, consume_s = 0;

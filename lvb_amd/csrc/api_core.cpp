@@ -419,6 +419,41 @@ extern "C" int lvbgpu_create_from_text(lvbgpu_ctx **out, int device, long n, lon
     return LVBGPU_OK;
 }
 
+// A second context on the same alignment: the leaf rows are copied on the device (a tile's leaf rows are one piece of
+// the tile-major block), everything else starts empty - one resident-tree slot, no tree.
+extern "C" int lvbgpu_fork(lvbgpu_ctx *src, lvbgpu_ctx **out)
+{
+    if (!src || !out)
+        return LVBGPU_E_ARG;
+    *out = nullptr;
+    HIPCHK(src, hipSetDevice(src->device));
+    lvbgpu_ctx *ctx = new (std::nothrow) lvbgpu_ctx();
+    if (!ctx)
+        return LVBGPU_E_NOMEM;
+    int rc = context_common_init(ctx, src->device, src->n, src->nwords);
+    if (rc == LVBGPU_OK)
+    {
+        ctx->target_waves = src->target_waves;
+        ctx->wait_limit_s = src->wait_limit_s;
+        hipError_t e = hipMemsetAsync(ctx->d_rows, 0xFF, (size_t)ctx->rows_total() * ctx->stride_words * 8, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(ctx->d_rows, (size_t)ctx->rows_total() * 1024u, src->d_rows, (size_t)src->rows_total() * 1024u,
+                                 (size_t)src->n * 1024u, (size_t)src->ntiles, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess)
+            rc = ctx->fail_hip(e, "copy of the leaf rows");
+    }
+    if (rc != LVBGPU_OK)
+    {
+        src->last_error = ctx->last_error;
+        lvbgpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return LVBGPU_OK;
+}
+
 extern "C" long lvbgpu_n(const lvbgpu_ctx *ctx) { return ctx ? ctx->n : 0; }
 extern "C" long lvbgpu_nwords(const lvbgpu_ctx *ctx) { return ctx ? ctx->nwords : 0; }
 

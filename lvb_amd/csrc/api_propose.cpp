@@ -672,6 +672,37 @@ extern "C" int lvbgpu_chains_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, co
     return propose_submit(ctx, slot, k, draws, nullptr);
 }
 
+extern "C" int lvbgpu_chains_ready(lvbgpu_ctx *ctx, int32_t slot, int32_t *ready)
+{
+    if (!ctx || slot < 0 || slot >= lvbgpu_ctx::PROP_SLOTS || !ready)
+        return LVBGPU_E_ARG;
+    lvbgpu_ctx::PropSlot &ps = ctx->pslot[slot];
+    if (!ps.in_flight)
+        return ctx->fail(LVBGPU_E_STATE, "nothing was submitted in that slot");
+    *ready = 0;
+    if (ps.watched)
+    {
+        // (memory only, as the collect: every watcher wave's word, a "gave up" word counts as done - the collect reports it)
+        const uint32_t *flag = (const uint32_t *)ps.h_flag.p;
+        for (uint32_t w = 0; w < WATCH_WAVES; w++)
+        {
+            const uint32_t seen = __atomic_load_n(flag + w, __ATOMIC_ACQUIRE);
+            if (seen == 0xFFFFFFFFu)
+                break;
+            if (seen != ps.seq)
+                return LVBGPU_OK;
+        }
+        *ready = 1;
+        return LVBGPU_OK;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const hipError_t q = hipEventQuery(ps.done_ev);
+    if (q != hipSuccess && q != hipErrorNotReady)
+        return ctx->fail_hip(q, "hipEventQuery(done_ev)");
+    *ready = q == hipSuccess ? 1 : 0;
+    return LVBGPU_OK;
+}
+
 extern "C" int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out)
 {
     if (ctx && slot >= 0 && slot < lvbgpu_ctx::PROP_SLOTS && ctx->pslot[slot].in_flight && ctx->pslot[slot].step)

@@ -607,15 +607,24 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
             // post launch: this tree's tables are being rebuilt by an earlier workgroup of the SAME launch (workgroups are
             // dealt in order: it is resident or done) - wait for its word, then copy with agent-scope loads: the tables
             // were written through, and a plain load could be served from a line this XCD's L2 still holds from the last step
-            __shared__ uint32_t gave_up;
+            // (every wave polls for itself and they agree through a word of the DYNAMIC LDS, which the tables overwrite
+            // afterwards: with any static LDS in this kernel - __syncthreads_or has some - the dynamic-LDS ceiling of
+            // 160 KiB cannot be asked for)
+            volatile uint32_t *const agree = reinterpret_cast<volatile uint32_t *>(lds_tables);
             if (threadIdx.x == 0)
+                *agree = 0u;
+            __syncthreads();
+            uint32_t budget = 1u << 24; // ~ seconds: a backstop, the rebuild finishes on its own
+            if (lane == 0)
             {
-                uint32_t budget = 1u << 24; // ~ seconds: a backstop, the rebuild finishes on its own
                 while (__hip_atomic_load(g.table_ready + sg.chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.ready_seq && --budget)
                     __builtin_amdgcn_s_sleep(16);
-                gave_up = budget == 0u ? 1u : 0u;
+                if (budget == 0u)
+                    *agree = 1u;
             }
             __syncthreads();
+            const uint32_t gave_up = *agree;
+            __syncthreads(); // (read by all before the copy below overwrites it)
             if (gave_up)
             {
                 // never walk programs made from torn tables: these candidates are "not proposals"

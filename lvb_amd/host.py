@@ -24,7 +24,7 @@ class AnnealParams(C.Structure):
                 ("maxaccept", C.c_int64), ("maxpropose", C.c_int64), ("maxfail", C.c_int64),
                 ("min_len_tree", C.c_int64), ("max_proposals", C.c_int64), ("max_seconds", C.c_double),
                 ("max_device_steps", C.c_int64), ("sync_every", C.c_int32), ("log_cap", C.c_int32),
-                ("device_proposals", C.c_int32), ("run_levels", C.c_int32)]
+                ("device_proposals", C.c_int32), ("run_levels", C.c_int32), ("lanes", C.c_int32)]
 
 
 class AnnealResult(C.Structure):

@@ -24,6 +24,7 @@ struct lvbgpu_ctx
     long *todo;
     int64_t cur_len;
     int have_tree;
+    struct dbl_multi *g; /* its multi-chain state (below), made when first needed */
 };
 
 lvbgpu_ctx *lvbgpu_double_new(long n, long nwords, const uint64_t *enc)
@@ -47,7 +48,7 @@ void lvbgpu_double_free(lvbgpu_ctx *c)
 {
     if (!c)
         return;
-    chains_release(c);
+    chains_release(c); /* (frees the multi-chain state too) */
     free(c->enc);
     free(c->cur);
     free(c->cand);
@@ -254,10 +255,19 @@ typedef struct
     int in_flight;
 } dbl_slot;
 
-/* (per THREAD: lvbhost_anneal_chain_groups runs every group - one context each - on a thread of its own) */
-static __thread struct
+/* Every context has its own multi-chain state (lvbhost_anneal_chains serves several contexts - lanes - from one thread);
+ * G is the state of the context the current call is about (enter(), first thing in every function that touches it). */
+#include "../../lvb_amd/csrc/decide.h"
+struct dbl_multi
 {
-    lvbgpu_ctx *owner;                            /* one multi-chain context at a time (and thread) is all the tests need */
+    struct
+    {
+        int32_t k;
+        DecideRule rule[DBL_MAX_CHAINS];
+        int32_t map[DBL_MAX_CHAINS];
+        int active;
+    } step;                                       /* the step in flight (lvbgpu_chains_step_*) */
+    lvbgpu_ctx *owner;                            /* the context itself once it has chains, else NULL */
     int32_t R, sel;
     dbl_chain ch[DBL_MAX_CHAINS];
     dbl_slot slot[2];
@@ -267,10 +277,21 @@ static __thread struct
     lvbgpu_edit *picked;
     size_t picked_cap;
     uint64_t versions;
-} G;
+};
+static __thread struct dbl_multi *Gcur;
+#define G (*Gcur)
+static void enter(const lvbgpu_ctx *cc)
+{
+    lvbgpu_ctx *c = (lvbgpu_ctx *)cc;
+    if (!c->g)
+        c->g = (struct dbl_multi *)calloc(1, sizeof(struct dbl_multi));
+    Gcur = c->g;
+}
+
 
 static void store_selected(lvbgpu_ctx *c)
 {
+    enter(c);
     if (G.owner != c)
         return;
     dbl_chain *h = &G.ch[G.sel];
@@ -282,6 +303,7 @@ static void store_selected(lvbgpu_ctx *c)
 
 static void load_selected(lvbgpu_ctx *c)
 {
+    enter(c);
     dbl_chain *h = &G.ch[G.sel];
     c->cur = h->cur;
     c->root = h->root;
@@ -291,6 +313,7 @@ static void load_selected(lvbgpu_ctx *c)
 
 static void mirror_of_selected(lvbgpu_ctx *c)
 {
+    enter(c);
     /* (re)build the selected chain's mirror topology from its node records */
     dbl_chain *h = &G.ch[G.sel];
     int32_t *l = (int32_t *)malloc((size_t)c->nb * 4), *r = (int32_t *)malloc((size_t)c->nb * 4);
@@ -309,6 +332,7 @@ static void mirror_of_selected(lvbgpu_ctx *c)
 
 static void chains_follow_selected(lvbgpu_ctx *c)
 {
+    enter(c);
     if (G.owner != c)
         return;
     store_selected(c);
@@ -318,13 +342,17 @@ static void chains_follow_selected(lvbgpu_ctx *c)
 void lvbgpu_double_chains_reset(void);
 static void chains_release(lvbgpu_ctx *c)
 {
+    enter(c);
     if (G.owner == c)
         lvbgpu_double_chains_reset();
+    free(c->g);
+    c->g = NULL;
+    Gcur = NULL;
 }
 
 void lvbgpu_double_chains_reset(void)
 {
-    if (!G.owner)
+    if (!Gcur || !G.owner)
         return;
     lvbgpu_ctx *c = G.owner;
     store_selected(c);
@@ -347,11 +375,12 @@ void lvbgpu_double_chains_reset(void)
         free(G.slot[s].len);
     }
     free(G.picked);
-    memset(&G, 0, sizeof(G));
+    memset(Gcur, 0, sizeof(struct dbl_multi));
 }
 
 int lvbgpu_set_chains(lvbgpu_ctx *c, int32_t r)
 {
+    enter(c);
     if (!c || r < 1 || r > DBL_MAX_CHAINS)
         return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
     if (G.owner)
@@ -372,6 +401,7 @@ int lvbgpu_set_chains(lvbgpu_ctx *c, int32_t r)
 
 int lvbgpu_select_chain(lvbgpu_ctx *c, int32_t k)
 {
+    enter(c);
     if (G.owner != c)
         return k == 0 ? LVBGPU_OK : LVBGPU_E_ARG;
     if (k < 0 || k >= G.R)
@@ -382,11 +412,16 @@ int lvbgpu_select_chain(lvbgpu_ctx *c, int32_t k)
     return LVBGPU_OK;
 }
 
-int32_t lvbgpu_chains(const lvbgpu_ctx *c) { return G.owner == c ? G.R : 1; }
+int32_t lvbgpu_chains(const lvbgpu_ctx *c)
+{
+    enter(c);
+    return G.owner == c ? G.R : 1;
+}
 
 /* a context that never asked for chains has one (lvbgpu_chains() == 1): the chain calls work on it all the same */
 static void adopt(lvbgpu_ctx *c)
 {
+    enter(c);
     if (c && G.owner != c)
         lvbgpu_set_chains(c, 1);
 }
@@ -401,6 +436,7 @@ static uint64_t mix64(uint64_t x)
 
 int lvbgpu_chains_submit(lvbgpu_ctx *c, int32_t s, int32_t k, const lvbgpu_chain_draw *d)
 {
+    enter(c);
     adopt(c);
     if (G.owner != c || s < 0 || s > 1 || k < 1 || k > G.R || !d)
         return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
@@ -482,6 +518,7 @@ int lvbgpu_chains_submit(lvbgpu_ctx *c, int32_t s, int32_t k, const lvbgpu_chain
 
 int lvbgpu_chains_collect(lvbgpu_ctx *c, int32_t s, int64_t *l)
 {
+    enter(c);
     if (G.owner != c || s < 0 || s > 1 || !l)
         return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
     dbl_slot *sl = &G.slot[s];
@@ -495,6 +532,7 @@ int lvbgpu_chains_collect(lvbgpu_ctx *c, int32_t s, int64_t *l)
 
 int lvbgpu_chains_propose_score(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_draw *d, int64_t *l)
 {
+    enter(c);
     const int rc = lvbgpu_chains_submit(c, 0, k, d);
     return rc != LVBGPU_OK ? rc : lvbgpu_chains_collect(c, 0, l);
 }
@@ -502,6 +540,7 @@ int lvbgpu_chains_propose_score(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_dra
 /* edits (+ a new root) on chain h's tree and on its mirror */
 static int commit_on_chain(lvbgpu_ctx *c, dbl_chain *h, int32_t ne, const lvbgpu_edit *e, long new_root, int64_t expect)
 {
+    enter(c);
     const long keep_root = c->root;
     c->root = h->root;
     long root = new_root >= 0 ? new_root : h->root;
@@ -516,6 +555,7 @@ static int commit_on_chain(lvbgpu_ctx *c, dbl_chain *h, int32_t ne, const lvbgpu
 
 int lvbgpu_chains_commit(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_pick *p)
 {
+    enter(c);
     adopt(c);
     if (G.owner != c || k < 1 || k > G.R || !p)
         return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
@@ -554,6 +594,7 @@ int lvbgpu_chains_commit(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_pick *p)
 
 int lvbgpu_chains_picked_edits(lvbgpu_ctx *c, int32_t j, lvbgpu_edit *e, int32_t cap, int32_t *n)
 {
+    enter(c);
     if (G.owner != c || j < 0 || j >= G.npicked || !e || !n)
         return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
     const int32_t ne = G.picked_off[j + 1] - G.picked_off[j];
@@ -566,17 +607,11 @@ int lvbgpu_chains_picked_edits(lvbgpu_ctx *c, int32_t j, lvbgpu_edit *e, int32_t
 
 /* a whole step (include/lvbgpu.h lvbgpu_chains_step_*): the rule rides with the batch; the double decides at the
  * collect with the product's own rule function (lvb_amd/csrc/decide.h: plain C) and commits the picks */
-#include "../../lvb_amd/csrc/decide.h"
-static __thread struct
-{
-    int32_t k;
-    DecideRule rule[DBL_MAX_CHAINS];
-    int32_t map[DBL_MAX_CHAINS];
-    int active;
-} STEP;
+#define STEP (G.step) /* (per context, as everything about its chains) */
 
 int lvbgpu_chains_step_submit(lvbgpu_ctx *c, int32_t s, int32_t k, const lvbgpu_chain_draw *d, const lvbgpu_chain_rule *r)
 {
+    enter(c);
     if (!r)
         return LVBGPU_E_ARG;
     const int rc = lvbgpu_chains_submit(c, s, k, d);
@@ -600,6 +635,7 @@ int lvbgpu_chains_step_submit(lvbgpu_ctx *c, int32_t s, int32_t k, const lvbgpu_
 
 int lvbgpu_chains_step_collect(lvbgpu_ctx *c, int32_t s, int64_t *l, int32_t *picks)
 {
+    enter(c);
     if (!STEP.active || !picks)
         return LVBGPU_E_STATE;
     STEP.active = 0;
@@ -629,6 +665,7 @@ int lvbgpu_chains_step_collect(lvbgpu_ctx *c, int32_t s, int64_t *l, int32_t *pi
 
 int lvbgpu_chains_step_edits(lvbgpu_ctx *c, int32_t i, lvbgpu_edit *e, int32_t cap, int32_t *n)
 {
+    enter(c);
     if (i < 0 || i >= DBL_MAX_CHAINS || STEP.map[i] < 0)
         return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d (i %d k %d)\n", __LINE__, i, STEP.k) : 0, LVBGPU_E_ARG);
     return lvbgpu_chains_picked_edits(c, STEP.map[i], e, cap, n);
@@ -652,6 +689,7 @@ static void *dbl_par_run(void *p)
 }
 int lvbgpu_parallel_for(lvbgpu_ctx *c, int32_t n, lvbgpu_task_fn fn, void *arg)
 {
+    enter(c);
     if (!c || n < 0 || !fn)
         return LVBGPU_E_ARG;
     enum { T = 3 };
@@ -687,6 +725,7 @@ int lvbgpu_parallel_for(lvbgpu_ctx *c, int32_t n, lvbgpu_task_fn fn, void *arg)
 int lvbgpu_chains_score_edits(lvbgpu_ctx *c, int32_t B, const int32_t *chain_of, const int32_t *off, const lvbgpu_edit *edits,
                               int64_t *lengths_out)
 {
+    enter(c);
     adopt(c);
     if (G.owner != c || B < 1 || !chain_of || !off || !lengths_out)
         return LVBGPU_E_ARG;
@@ -713,6 +752,7 @@ int lvbgpu_chains_score_edits(lvbgpu_ctx *c, int32_t B, const int32_t *chain_of,
 
 int lvbgpu_chains_commit_edits(lvbgpu_ctx *c, int32_t k, const int32_t *chains, const int32_t *off, const lvbgpu_edit *edits)
 {
+    enter(c);
     adopt(c);
     if (G.owner != c || k < 1 || k > G.R || !chains || !off || !edits)
         return LVBGPU_E_ARG;
@@ -733,6 +773,7 @@ int lvbgpu_chains_commit_edits(lvbgpu_ctx *c, int32_t k, const int32_t *chains, 
 
 int lvbgpu_chains_reroot(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_root *r)
 {
+    enter(c);
     adopt(c);
     if (G.owner != c || k < 1 || k > G.R || !r)
         return (getenv("DBL_DEBUG") ? fprintf(stderr, "double: E_ARG at line %d\n", __LINE__) : 0, LVBGPU_E_ARG);
@@ -755,4 +796,25 @@ int lvbgpu_chains_reroot(lvbgpu_ctx *c, int32_t k, const lvbgpu_chain_root *r)
     free(tmp);
     load_selected(c);
     return rc;
+}
+
+/* a second context on the same alignment (lvbhost_anneal_chains' lanes) */
+int lvbgpu_fork(lvbgpu_ctx *src, lvbgpu_ctx **out)
+{
+    if (!src || !out)
+        return LVBGPU_E_ARG;
+    *out = lvbgpu_double_new(src->n, src->nwords, src->enc);
+    return *out ? LVBGPU_OK : LVBGPU_E_NOMEM;
+}
+
+void lvbgpu_destroy(lvbgpu_ctx *c) { lvbgpu_double_free(c); }
+
+/* everything is computed at the submit: a submitted batch is always ready */
+int lvbgpu_chains_ready(lvbgpu_ctx *c, int32_t s, int32_t *ready)
+{
+    enter(c);
+    if (G.owner != c || s < 0 || s > 1 || !ready)
+        return LVBGPU_E_ARG;
+    *ready = 1;
+    return LVBGPU_OK;
 }

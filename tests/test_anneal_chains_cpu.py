@@ -23,7 +23,7 @@ def double():
     return lib, new_ctx, free_ctx
 
 
-def run_chains(double, rows, min_len, n, seeds, max_proposals, algorithm, batch=64, run_levels=0):
+def run_chains(double, rows, min_len, n, seeds, max_proposals, algorithm, batch=64, run_levels=0, lanes=1):
     from lvb_amd import host
     lib, new_ctx, free_ctx = double
     ctx = new_ctx(rows)
@@ -39,15 +39,17 @@ def run_chains(double, rows, min_len, n, seeds, max_proposals, algorithm, batch=
         p.max_proposals = max_proposals
         p.log_cap = 64
         p.run_levels = run_levels
+        p.lanes = lanes
         params.append(p)
     try:
         res, log = host.anneal_chains(ctx, trees, params, lib=lib)
         final = []
         for c, t in enumerate(trees):
-            assert lib.lvbgpu_select_chain(ctx, c) == 0
-            length = C.c_int64()
-            assert lib.lvbgpu_current_length(ctx, C.byref(length)) == 0
-            assert length.value == res[c]["final_length"]          # the resident length is what the chain believes
+            if lanes == 1:                                             # (with more lanes the other lanes' contexts are gone)
+                assert lib.lvbgpu_select_chain(ctx, c) == 0
+                length = C.c_int64()
+                assert lib.lvbgpu_current_length(ctx, C.byref(length)) == 0
+                assert length.value == res[c]["final_length"]          # the resident length is what the chain believes
             _, l, r = t.arrays()
             final.append((l.copy(), r.copy(), t.root, t.best_count()))
     finally:
@@ -77,6 +79,26 @@ def test_a_chains_trajectory_does_not_depend_on_the_chains_beside_it(double, alg
     assert all(r["consumed"] == 1500 and r["best_length"] <= r["start_length"] for r in many)
     assert all(r["reroots"] >= 1 for r in many)                     # one per 1000 proposals and per temperature sample
     assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)    # the shared log only ever improves
+    assert log[-1][1] == min(r["best_length"] for r in many)
+
+
+@pytest.mark.parametrize("lanes,run_levels", [(2, 0), (3, 0), (2, 2)])
+def test_lanes_leave_every_chains_trajectory_alone(double, lanes, run_levels):
+    """lvbhost_anneal_params::lanes: the chains dealt to contexts of their own (lvbgpu_fork) that one host thread serves in
+    turn.  Every chain's counters, final tree and kept trees are what one lane gives it - device-drawn and with runs of
+    accepted moves -, the shared log only improves and ends at the best length over all chains."""
+    from lvb_amd import host
+    lib = double[0]
+    n, m = 20, 500
+    rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 44), lib)
+    seeds = [11, 12, 13, 14, 15, 16, 17]
+    one, one_final, _ = run_chains(double, rows, min_len, n, seeds, 1200, 1, run_levels=run_levels)
+    many, many_final, log = run_chains(double, rows, min_len, n, seeds, 1200, 1, run_levels=run_levels, lanes=lanes)
+    for c in range(len(seeds)):
+        assert {k: many[c][k] for k in KEYS} == {k: one[c][k] for k in KEYS}, c
+        assert np.array_equal(many_final[c][0], one_final[c][0]) and np.array_equal(many_final[c][1], one_final[c][1])
+        assert many_final[c][2:] == one_final[c][2:]
+    assert [b for _, b in log] == sorted((b for _, b in log), reverse=True)
     assert log[-1][1] == min(r["best_length"] for r in many)
 
 

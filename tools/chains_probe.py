@@ -19,6 +19,7 @@ for spec in [a for a in sys.argv[1:] if not a.startswith("--")] or ["1", "16"]:
         p = host.anneal_defaults()
         p.seed = 9 * 7919 + c + 1; p.algorithm = 11; p.batch = 4096; p.t0 = float(os.environ.get("PROBE_T0", "0")); p.min_len_tree = min_len
         p.max_seconds = 8.0; p.log_cap = 4096
+        p.lanes = int(os.environ.get("PROBE_LANES", "0"))          # 0: the library's default (2 from 16 chains on)
         p.run_levels = int(os.environ.get("PROBE_RUN_LEVELS", "0"))   # one chain: runs of acceptances in one step (host-drawn hot phase)
         if os.environ.get("PROBE_NO_REROOT"):
             p.reroot_interval = 0   # upper bound of what cheaper re-roots could give (the trajectories change)
