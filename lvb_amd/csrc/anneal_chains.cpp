@@ -715,6 +715,8 @@ struct LaneGuard // the forked contexts go with the run, whichever way it ends
         for (Lane &l : lanes)
             if (l.forked && l.ctx)
                 lvbgpu_destroy(l.ctx);
+            else if (l.ctx)
+                (void)lvbgpu_set_sharing(l.ctx, 0);
     }
 };
 
@@ -764,6 +766,8 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         }
         if (rc == LVBGPU_OK && lvbgpu_chains(L.ctx) != L.count)
             rc = lvbgpu_set_chains(L.ctx, L.count);
+        if (rc == LVBGPU_OK && nl > 1)
+            rc = lvbgpu_set_sharing(L.ctx, 1); // (the lanes' kernels run beside one another)
     }
     if (rc != LVBGPU_OK)
         return rc;

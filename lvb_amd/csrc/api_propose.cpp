@@ -958,7 +958,7 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
         ctx->post_launches_with_generator++;
     }
     ctx->post_launches++;
-    HIPCHK(ctx, launch_post(pa, ctx->stream));
+    HIPCHK(ctx, launch_post(pa, ctx->stream, ctx->sharing));
     return LVBGPU_OK;
 }
 

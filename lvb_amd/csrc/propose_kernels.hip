@@ -598,6 +598,7 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
     const char *tables = reinterpret_cast<const char *>(g.tables) + (size_t)sg.chain * g.table_stride;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6; // (16 waves; 4 in the narrow post launch)
     using P = typename TabPtr<IdxT, IN_LDS>::type;
     P tab;
     if constexpr (IN_LDS)
@@ -628,7 +629,7 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
             if (gave_up)
             {
                 // never walk programs made from torn tables: these candidates are "not proposals"
-                for (uint32_t bl = blk_local * GEN_WAVES + wave; bl < sg.count; bl += seg_blocks * GEN_WAVES)
+                for (uint32_t bl = blk_local * nwaves + wave; bl < sg.count; bl += seg_blocks * nwaves)
                     if (lane == 0)
                     {
                         CandDesc cd{};
@@ -643,7 +644,7 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
             const unsigned long long *src8 = reinterpret_cast<const unsigned long long *>(tables);
             unsigned long long *dst8 = reinterpret_cast<unsigned long long *>(lds_tables);
             const uint32_t n8 = g.table_bytes / 8u;
-            for (uint32_t i = threadIdx.x; i < n8; i += GEN_THREADS)
+            for (uint32_t i = threadIdx.x; i < n8; i += nthreads)
                 dst8[i] = __hip_atomic_load(src8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         else
@@ -653,19 +654,19 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
             const uint4 *src4 = reinterpret_cast<const uint4 *>(tables);
             const uint32_t n16 = g.table_bytes / 16u;
             constexpr uint32_t DEPTH = 4;
-            for (uint32_t i0 = 0; i0 < n16; i0 += DEPTH * GEN_THREADS)
+            for (uint32_t i0 = 0; i0 < n16; i0 += DEPTH * nthreads)
             {
                 uint4 v[DEPTH];
 #pragma unroll
                 for (uint32_t u = 0; u < DEPTH; u++)
                 {
-                    const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
+                    const uint32_t i = i0 + u * nthreads + threadIdx.x;
                     v[u] = src4[i < n16 ? i : n16 - 1u]; // (unconditional: a conditionally filled array went through scratch)
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < DEPTH; u++)
                 {
-                    const uint32_t i = i0 + u * GEN_THREADS + threadIdx.x;
+                    const uint32_t i = i0 + u * nthreads + threadIdx.x;
                     if (i < n16)
                         lds_tables[i] = v[u];
                 }
@@ -691,12 +692,12 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
     t.nb = g.nb;
     t.root = sg.root;
     t.K = g.K;
-    if (g.prof && lane == 0 && sg.start + blk_local * GEN_WAVES + wave < 256u)
+    if (g.prof && lane == 0 && sg.start + blk_local * nwaves + wave < 256u)
     {
-        g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 5u] = t_enter;
-        g.prof[(sg.start + blk_local * GEN_WAVES + wave) * 8u + 6u] = __builtin_readcyclecounter();
+        g.prof[(sg.start + blk_local * nwaves + wave) * 8u + 5u] = t_enter;
+        g.prof[(sg.start + blk_local * nwaves + wave) * 8u + 6u] = __builtin_readcyclecounter();
     }
-    for (uint32_t bl = blk_local * GEN_WAVES + wave; bl < sg.count; bl += seg_blocks * GEN_WAVES)
+    for (uint32_t bl = blk_local * nwaves + wave; bl < sg.count; bl += seg_blocks * nwaves)
         generate_one(t, g, sg, bl, lane);
 }
 
@@ -863,11 +864,13 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
 // Round 3 ran these as up to five launches on two streams with two event pairs (commit walk, rebuild + gather, re-root
 // walk, its rebuild, generator): every kernel boundary costs 8-9 us whatever the kernel does, a cross-stream hand-over
 // 2-5 us, and on the accept path the host's launch calls are what the device waits for.
-constexpr uint32_t POST_WAVES = GEN_THREADS / 64u;
 static_assert(GEN_THREADS == REBUILD_THREADS, "one workgroup size for every role of the post launch");
-
-template <typename IdxT, bool WIDE>
-__global__ __launch_bounds__(GEN_THREADS) void post_kernel(const PostArgs p)
+// WAVES per workgroup: 16, or 4 - the NARROW form for a context that shares the device (lvbgpu_set_sharing: lanes).  A
+// 1024-thread workgroup with 100+ KB of LDS finds no CU to run on while another queue's scoring walk keeps all of them
+// full of 4-wave workgroups: measured with two lanes, a post launch that started beside the other lane's walk took 86 us
+// instead of 36.  A 4-wave workgroup with 38 KB takes the place of any walk workgroup that retires.
+template <typename IdxT, bool WIDE, uint32_t WAVES>
+__global__ __launch_bounds__(WAVES * 64u) void post_kernel(const PostArgs p)
 {
     extern __shared__ uint4 lds_dyn[];
     const uint32_t b = blockIdx.x;
@@ -880,9 +883,9 @@ __global__ __launch_bounds__(GEN_THREADS) void post_kernel(const PostArgs p)
     {
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const uint32_t item = (b - p.n_reb) * POST_WAVES + wave;
+        const uint32_t item = (b - p.n_reb) * WAVES + wave;
         if (item < p.commit.nitems)
-            walk_item<true, WIDE, 0>(p.commit, lds_dyn, lane, wave, POST_WAVES, item);
+            walk_item<true, WIDE, 0>(p.commit, lds_dyn, lane, wave, WAVES, item);
         return;
     }
     if (p.gen.nseg)
@@ -1059,10 +1062,14 @@ static hipError_t raise_generator_lds()
         hipError_t e = hipSuccess;
         for (const void *f : {reinterpret_cast<const void *>(&propose_kernel<uint16_t, true>),
                               reinterpret_cast<const void *>(&propose_kernel<int32_t, true>),
-                              reinterpret_cast<const void *>(&post_kernel<uint16_t, false>),
-                              reinterpret_cast<const void *>(&post_kernel<uint16_t, true>),
-                              reinterpret_cast<const void *>(&post_kernel<int32_t, false>),
-                              reinterpret_cast<const void *>(&post_kernel<int32_t, true>)})
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, false, 16>),
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, true, 16>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, false, 16>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, true, 16>),
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, false, 4>),
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, true, 4>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, false, 4>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, true, 4>)})
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         raised_on[dev] = e;
@@ -1077,17 +1084,17 @@ static size_t rebuild_lds_bytes(int32_t nb)
 
 // one candidate per wave while the chip has room; beyond that waves take several.  Every segment gets workgroups in
 // proportion to its candidates (at least one).  per_cu: generator workgroups a CU can hold.  Returns their number.
-static uint32_t deal_generator_blocks(GenArgs &g, uint32_t per_cu)
+static uint32_t deal_generator_blocks(GenArgs &g, uint32_t per_cu, uint32_t waves = GEN_WAVES)
 {
     uint32_t total = 0;
     for (uint32_t s = 0; s < g.nseg; s++)
         total += g.seg[s].count;
     const uint32_t budget = 256u * per_cu;
-    const uint32_t want_all = (total + GEN_WAVES - 1) / GEN_WAVES;
+    const uint32_t want_all = (total + waves - 1) / waves;
     uint32_t nblk = 0;
     for (uint32_t s = 0; s < g.nseg; s++)
     {
-        const uint32_t want = (g.seg[s].count + GEN_WAVES - 1) / GEN_WAVES;
+        const uint32_t want = (g.seg[s].count + waves - 1) / waves;
         uint32_t give = want_all <= budget ? want : (uint32_t)((uint64_t)want * budget / want_all);
         give = std::max(1u, std::min(give, std::max(want, 1u)));
         g.seg[s].blk_start = nblk;
@@ -1134,11 +1141,12 @@ bool post_can_generate(const GenArgs &g)
     return g.nseg >= 1 && g.nseg <= MAX_GEN_SEGS && g.moves == nullptr && raise_generator_lds() == hipSuccess && g.table_bytes <= MAX_LDS_BYTES;
 }
 
-hipError_t launch_post(const PostArgs &args, hipStream_t stream)
+hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow)
 {
     PostArgs p = args;
     if (raise_generator_lds() != hipSuccess)
         return hipErrorInvalidValue;
+    const uint32_t waves = narrow ? 4u : GEN_WAVES;
     size_t lds = 0;
     if (p.n_reb)
     {
@@ -1163,42 +1171,54 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream)
     }
     // the commit walk's parked sets take what LDS is left - all of it while the generator's workgroups are few (one per
     // CU is plenty then), half of it when they are many (cold chains drawing a thousand candidates each: two generator
-    // workgroups per CU matter more than the commit walk's bursts)
+    // workgroups per CU matter more than the commit walk's bursts); the narrow form takes no more than the other roles
+    // need anyway, at least 8 slots' worth: its workgroups are to fit beside another queue's walk
     p.n_cblk = 0;
     if (p.commit.nitems)
     {
-        const bool many = (gen_total + GEN_WAVES - 1) / GEN_WAVES > 256u;
+        const bool many = (gen_total + waves - 1) / waves > 256u;
         size_t budget = many ? MAX_LDS_BYTES / 2 : MAX_LDS_BYTES;
+        if (narrow)
+            budget = std::max(lds, (size_t)waves * (p.commit.stack_depth * 1024u + 8u * 1088u));
         size_t clds = 0;
-        hipError_t e = shape_walk(p.commit, true, POST_WAVES, budget, &clds);
-        if (e != hipSuccess && many)
-            e = shape_walk(p.commit, true, POST_WAVES, MAX_LDS_BYTES, &clds);
+        hipError_t e = shape_walk(p.commit, true, waves, budget, &clds);
+        if (e != hipSuccess && (many || narrow))
+            e = shape_walk(p.commit, true, waves, MAX_LDS_BYTES, &clds);
         if (e != hipSuccess)
             return e;
         p.commit.flip = 0;
         p.commit.watcher = 0;
         lds = std::max(lds, clds);
-        p.n_cblk = (p.commit.nitems + POST_WAVES - 1) / POST_WAVES;
+        p.n_cblk = (p.commit.nitems + waves - 1) / waves;
     }
     if (p.gen.nseg)
-        gen_blocks = deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))));
+        gen_blocks = deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(narrow ? 4 : 2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))), waves);
     const uint32_t nblk = p.n_reb + p.n_cblk + gen_blocks;
     if (nblk == 0)
         return hipSuccess;
     const bool wide = p.commit.nitems != 0 && walk_needs_wide(p.commit);
-    const dim3 grid(nblk), block(GEN_THREADS);
+    const dim3 grid(nblk), block(waves * 64u);
     const bool idx16 = (p.gen.nseg ? p.gen.idx_bytes : p.reb.idx_bytes) != 4;
+#define LVB_POST(I, W)                                                                                                 \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (narrow)                                                                                                    \
+            hipLaunchKernelGGL((post_kernel<I, W, 4>), grid, block, lds, stream, p);                                   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((post_kernel<I, W, 16>), grid, block, lds, stream, p);                                  \
+    } while (0)
     if (idx16)
     {
         if (wide)
-            hipLaunchKernelGGL((post_kernel<uint16_t, true>), grid, block, lds, stream, p);
+            LVB_POST(uint16_t, true);
         else
-            hipLaunchKernelGGL((post_kernel<uint16_t, false>), grid, block, lds, stream, p);
+            LVB_POST(uint16_t, false);
     }
     else if (wide)
-        hipLaunchKernelGGL((post_kernel<int32_t, true>), grid, block, lds, stream, p);
+        LVB_POST(int32_t, true);
     else
-        hipLaunchKernelGGL((post_kernel<int32_t, false>), grid, block, lds, stream, p);
+        LVB_POST(int32_t, false);
+#undef LVB_POST
     return hipGetLastError();
 }
 

@@ -28,6 +28,25 @@ print("\ngap between consecutive kernels (end -> start), by pair: count, mean us
 for k, v in sorted(gap_after.items(), key=lambda kv: -sum(kv[1]))[:14]:
     v2 = sorted(v)
     print(f"{k[0]:40s} -> {k[1]:40s} {len(v):6d} {sum(v)/len(v)/1000:9.2f} {v2[len(v2)//2]/1000:9.2f}")
+# lanes: what does a post launch meet on the device?  For every post launch: was a scoring walk of ANOTHER queue running
+# when it started, and how long did it take then
+walks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"]) for r in rows if "fitch_walk<false" in r["Kernel_Name"]]
+import bisect
+ws = sorted(walks)
+starts = [w[0] for w in ws]
+alone, beside = [], []
+for r in rows:
+    if "post_kernel" not in r["Kernel_Name"]:
+        continue
+    st, en, q = int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"]
+    i = bisect.bisect_right(starts, st)
+    other = any(w[2] != q and w[0] <= st < w[1] for w in ws[max(0, i - 4):i])
+    (beside if other else alone).append(en - st)
+if beside:
+    print(f"\npost launches that started while another queue's walk ran: {len(beside)}, mean {sum(beside)/len(beside)/1000:.2f} us; "
+          f"others: {len(alone)}, mean {sum(alone)/max(1,len(alone))/1000:.2f} us")
+queues = sorted({r["Queue_Id"] for r in rows})
+print("queues:", queues)
 t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
 print(f"\nspan {(t1-t0)/1e6:.3f} ms, kernels busy {busy/1e6:.3f} ms ({100*busy/(t1-t0):.1f} %)")
