@@ -127,7 +127,7 @@ struct ChainRun
     // nothing (done, or an error in rc)
     static double spec_factor()
     {
-        static const double f = [] { const char *e = getenv("LVBHOST_SPEC_FACTOR"); const double v = e ? atof(e) : 3.0; return v > 0.1 ? v : 3.0; }();
+        static const double f = [] { const char *e = getenv("LVBHOST_SPEC_FACTOR"); const double v = e ? atof(e) : 4.0; return v > 0.1 ? v : 4.0; }();
         return f;
     }
 
@@ -152,10 +152,11 @@ struct ChainRun
         else
         {
             // Speculation depth follows the acceptance rate: when most proposals are accepted, all but the first few
-            // of a batch would be thrown away; when acceptances are rare the whole batch is consumed.  3 / rate leaves
-            // one step in twenty without an acceptance (e^-3); measured 500 x 50 000, SPR: factor 2 / 3 / 4 / 6 reach
-            // the reference program's 20 s length after 0.270-0.284 / 0.248 / 0.251 / 0.252 s with one chain and
-            // 0.466-0.472 / 0.463 / 0.468 / 0.451 s with 32 (LVBHOST_SPEC_FACTOR)
+            // of a batch would be thrown away; when acceptances are rare the whole batch is consumed.  4 / rate leaves
+            // one step in fifty without an acceptance (e^-4); measured 500 x 50 000, SPR (LVBHOST_SPEC_FACTOR), round 3:
+            // factor 2 / 3 / 4 / 6 reach the reference program's 20 s length after 0.270-0.284 / 0.248 / 0.251 / 0.252 s
+            // with one chain and 0.466-0.472 / 0.463 / 0.468 / 0.451 s with 32; round 4 (post launch, two lanes), 32 chains,
+            // factor 3 / 4 / 6 / 8: 0.399 / 0.386 / 0.381 / 0.402 s, all frozen after 1.209 / 1.211 / 1.248 / 1.326 s
             int64_t room = std::min<int64_t>(p.batch, std::max<int64_t>(8, (int64_t)std::ceil(spec_factor() / accept_rate)));
             if (p.reroot_interval > 0)
             {
@@ -766,8 +767,6 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
         }
         if (rc == LVBGPU_OK && lvbgpu_chains(L.ctx) != L.count)
             rc = lvbgpu_set_chains(L.ctx, L.count);
-        if (rc == LVBGPU_OK && nl > 1)
-            rc = lvbgpu_set_sharing(L.ctx, 1); // (the lanes' kernels run beside one another)
     }
     if (rc != LVBGPU_OK)
         return rc;
@@ -1008,6 +1007,16 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             L.picks.resize(L.draws.size());
             auto td = Clock::now();
             L.slot ^= 1;
+            if (nl > 1)
+            {
+                // the post launch goes out narrow when another lane has a big walk on the device: a 16-wave workgroup
+                // finds no room beside it; beside small walks (the hot phase) the 16-wave form is the faster one
+                size_t beside = 0;
+                for (const Lane &o : lanes)
+                    if (&o != &L && o.active)
+                        beside += o.total;
+                (void)lvbgpu_set_sharing(L.ctx, beside >= 2048 ? 1 : 0);
+            }
             r = lvbgpu_chains_step_submit(L.ctx, L.slot, (int32_t)L.draws.size(), L.draws.data(), L.rules.data());
             dev_seconds += since(td);
             t_score += since(td);

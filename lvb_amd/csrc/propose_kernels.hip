@@ -873,6 +873,10 @@ template <typename IdxT, bool WIDE, uint32_t WAVES>
 __global__ __launch_bounds__(WAVES * 64u) void post_kernel(const PostArgs p)
 {
     extern __shared__ uint4 lds_dyn[];
+    // (what this launch does is a chain of latencies that the next scoring walk waits for; beside another context's walk
+    // - eight waves per SIMD that keep the memory path full - its few waves should at least be issued first)
+    if constexpr (WAVES == 4)
+        __builtin_amdgcn_s_setprio(3);
     const uint32_t b = blockIdx.x;
     if (b < p.n_reb)
     {

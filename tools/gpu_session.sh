@@ -23,6 +23,10 @@ for s in "$@"; do
     probe32l1) PROBE_LANES=1 step probe32l1 200 python tools/chains_probe.py 32 ;;
     probe32l3) PROBE_LANES=3 step probe32l3 200 python tools/chains_probe.py 32 ;;
     probe32l4) PROBE_LANES=4 step probe32l4 200 python tools/chains_probe.py 32 ;;
+    probe32f4) LVBHOST_SPEC_FACTOR=4 step probe32f4 200 python tools/chains_probe.py 32 --quiet ;;
+    probe32f6) LVBHOST_SPEC_FACTOR=6 step probe32f6 200 python tools/chains_probe.py 32 --quiet ;;
+    probe32f8) LVBHOST_SPEC_FACTOR=8 step probe32f8 200 python tools/chains_probe.py 32 --quiet ;;
+    probe1f6) LVBHOST_SPEC_FACTOR=6 step probe1f6 200 python tools/chains_probe.py 1 --quiet ;;
     probe1r)  PROBE_RUN_LEVELS=3 step probe1r 200 python tools/chains_probe.py 1 ;;
     anyorder) step anyorder 60 ./tools/anyorder_probe.bin ;;
     bench)    step bench 600 python bench.py ;;
