@@ -98,6 +98,10 @@ def parse_args(argv=None):
     ap.add_argument("--headline-only", action="store_true",
                     help="the timed region and its roofline only (profiling runs: every scoring walk of the process is "
                          "then one of the headline's device-built batches)")
+    ap.add_argument("--comm-init-seconds", type=float, default=90.0,
+                    help="N > 1: how long a rank waits for the library's own RCCL communicator (lvbgpu_comm_init) before "
+                         "every rank falls back to torch.distributed for the min-reduce")
+    ap.add_argument("--dry-stuck-rank", type=int, default=-1, help="--dry-ranks: that rank's communicator set-up never returns")
     ap.add_argument("--dry-ranks", action="store_true",
                     help="rehearse the N-rank flow without GPUs: ranks are spawned, meet over gloo, reduce a fake best "
                          "length; no scoring (CPU test of the launch plumbing)")
@@ -198,11 +202,23 @@ def timed_steps(run, synchronize, ranks, steps: int, seed0: int, reduce_best=Non
 def dry_rank_main(args) -> None:
     """The rank flow of rank_main with the GPU taken out: rendezvous, the timed region's skeleton (timed_steps: warm-up
     reduce, barriers, max-over-ranks timing) and a min-reduce of a stand-in best length, all over gloo."""
-    from lvb_amd.launch import Ranks
+    from lvb_amd.launch import Ranks, call_with_deadline, pin_to_share_of_cores
+    host_share = pin_to_share_of_cores()
     ranks = Ranks(backend="gloo")
     if ranks.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}")
     reduces = []
+    # the library's communicator set-up, rehearsed: a collective call under a deadline; --dry-stuck-rank R: rank R's never
+    # returns - every rank must then agree on the fallback and the run must still end
+    own_comm, stuck = False, False
+    if ranks.world > 1:
+        def stand_in():
+            if ranks.rank == args.dry_stuck_rank:
+                time.sleep(3600)
+            return True
+        done, _ = call_with_deadline(stand_in, args.comm_init_seconds if args.dry_stuck_rank < 0 else 1.0)
+        stuck = not done
+        own_comm = bool(ranks.sum_over_ranks(int(done)) == ranks.world)
 
     def reduce_best(best_local: int) -> int:
         reduces.append(int(best_local))
@@ -214,6 +230,7 @@ def dry_rank_main(args) -> None:
     head = timed_steps(run, lambda: None, ranks, args.steps, 1000, reduce_best if ranks.world > 1 else None)
     per_rank = ranks.all_values(float(ranks.rank + 1))
     seeds = ranks.sum_over_ranks(ranks.restart_seed(args.seed))
+    cores_of_ranks = ranks.all_values(float(host_share["cores_per_rank"]))
     if ranks.rank == 0:
         print(json.dumps({
             "metric": "candidate trees scored/sec (Fitch getplen), 500 taxa x 50k sites", "value": 0.0,
@@ -225,8 +242,14 @@ def dry_rank_main(args) -> None:
                                       "best length min-reduced by lvbgpu_allreduce_min over RCCL)",
                        "best_length": int(head["best"]), "seed_sum": seeds, "reduce_ms": head["reduce_ms"],
                        "order": head["order"], "reduces": len(reduces), "per_rank": per_rank,
-                       "reducer": "gloo (dry)", "comm_size": ranks.world}}), flush=True)
+                       "reducer": "gloo (dry)", "comm_size": ranks.world, "own_comm": own_comm,
+                       "cores_per_rank": host_share["cores_per_rank"], "host_threads_per_rank": host_share["threads"],
+                       "pinned_to_share_of_cores": host_share["pinned"],
+                       "cores_of_ranks": cores_of_ranks}}), flush=True)
     ranks.close()
+    if stuck:
+        sys.stdout.flush()
+        os._exit(0)
 
 
 # ----------------------------------------------------------------------------------------- workload pieces
@@ -634,7 +657,9 @@ def config_leg(ranks, device: int, cfg: str, taxa: int, sites: int, move: str, b
 # ----------------------------------------------------------------------------------------- one rank
 
 def rank_main(args) -> None:
-    from lvb_amd.launch import Ranks
+    from lvb_amd.launch import Ranks, call_with_deadline, pin_to_share_of_cores
+    # this rank's share of the host's cores, before the scoring library (its thread pool) is loaded
+    host_share = pin_to_share_of_cores()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("NCCL_DEBUG", "WARN")   # read when RCCL is first initialised: a failing CommInitRank says why
     ranks = Ranks()                       # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
@@ -657,6 +682,7 @@ def rank_main(args) -> None:
     setup_s = time.perf_counter() - t_setup
 
     own_comm = False
+    comm_init_stuck = False
     if world > 1:
         # RCCL communicator of the scoring library itself (not torch's).  Its init is collective, so the
         # ranks first agree (through torch) that every one of them can take part: a rank that cannot must not
@@ -670,12 +696,19 @@ def rank_main(args) -> None:
                     print(f"[rank 0] lvbgpu_comm_unique_id failed ({exc})", file=sys.stderr)
             uid = ranks.share_bytes(uid)           # None from rank 0: every rank skips the library's communicator
             if uid is not None:
-                try:
-                    ctx.comm_init(world, rank, uid)
-                    own_comm = True
-                except api.LvbGpuError as exc:   # keep the scaling run alive: same reduction through torch's RCCL
-                    print(f"[rank {rank}] lvbgpu_comm_init failed ({exc}); min-reduce falls back to torch.distributed",
+                # ncclCommInitRank has no deadline of its own: a rank that never arrives would hang all the others.  Waited
+                # for at most --comm-init-seconds; a rank that gives up says so, every rank then takes the torch fallback
+                # (the agreement below), and the process ends through os._exit (the stuck call keeps its thread)
+                done, res = call_with_deadline(lambda: ctx.comm_init(world, rank, uid), args.comm_init_seconds)
+                if not done:
+                    comm_init_stuck = True
+                    print(f"[rank {rank}] lvbgpu_comm_init did not return within {args.comm_init_seconds:.0f} s; "
+                          "min-reduce falls back to torch.distributed", file=sys.stderr)
+                elif isinstance(res, BaseException):   # keep the scaling run alive: same reduction through torch's RCCL
+                    print(f"[rank {rank}] lvbgpu_comm_init failed ({res}); min-reduce falls back to torch.distributed",
                           file=sys.stderr)
+                else:
+                    own_comm = True
         own_comm = bool(ranks.sum_over_ranks(int(own_comm)) == world)
 
     def reduce_best(best_local: int) -> int:
@@ -724,6 +757,8 @@ def rank_main(args) -> None:
                                                              if own_comm else "torch.distributed all_reduce (fallback)"),
             "comm_size": ctx.comm_size() if own_comm else world, "reduce_ms": round(head["reduce_ms"], 4),
             "per_rank_trees_per_s": [round(v) for v in per_rank],
+            "cores_per_rank": host_share["cores_per_rank"], "host_threads_per_rank": host_share["threads"],
+            "pinned_to_share_of_cores": host_share["pinned"],
             "timed_region": "one untimed min-reduce + barrier, t0, K steps, min-reduce of the best length (reduce_ms), "
                             "synchronize, barrier, t1; value = all ranks' candidates / max over ranks of (t1 - t0)",
         },
@@ -867,11 +902,16 @@ def rank_main(args) -> None:
         out["mixed_walk"]["cpu_baseline"] = cpu_reference_on_tree(rows, kind, args.cpu_seconds, mixed_arrays, mixed_len,
                                                                   (args.taxa, args.sites, args.seed, args.dist), all_cores=False)
     tree.close()
-    ctx.close()
+    if not comm_init_stuck:   # (destroying the context would reach into a communicator that is still being set up)
+        ctx.close()
     ranks.barrier()   # rank 0 has more legs than the others: nobody tears the process group down under it
     ranks.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm_init_stuck:       # the call that never came back keeps its thread: end the process under it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def main() -> int:

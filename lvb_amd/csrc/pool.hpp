@@ -1,5 +1,8 @@
 // pool.hpp - a few persistent host threads (program building, proposal generation)
 #pragma once
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include <atomic>
 #include <chrono>
@@ -130,15 +133,34 @@ class Pool
 };
 
 
-// how many host threads to use (env LVBGPU_THREADS, default 16 - the share of host cores one GPU of an 8-GPU node
-// comes with -, never more than the machine has)
+// how many host threads to use: env LVBGPU_THREADS, else this process's share of the cores it may run on - its affinity
+// mask divided by LOCAL_WORLD_SIZE (one process per GPU: eight ranks with sixteen workers each and no affinity would
+// fight over the host) - at least 2, at most 16 (the share of host cores one GPU of an 8-GPU node comes with); never more
+// than the process may run on
 inline int host_threads()
 {
+    int allowed = (int)std::thread::hardware_concurrency();
+#if defined(__linux__)
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0)
+            allowed = CPU_COUNT(&set);
+    }
+#endif
     const char *e = getenv("LVBGPU_THREADS");
-    int n = e ? atoi(e) : 16;
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0 && n > hw)
-        n = hw;
+    int n;
+    if (e)
+        n = atoi(e);
+    else
+    {
+        const char *lw = getenv("LOCAL_WORLD_SIZE");
+        const int ranks_here = lw && atoi(lw) > 0 ? atoi(lw) : 1;
+        n = allowed > 0 ? allowed / ranks_here : 16;
+        n = n < 2 ? 2 : (n > 16 ? 16 : n);
+    }
+    if (allowed > 0 && n > allowed)
+        n = allowed;
     return n < 1 ? 1 : n;
 }
 

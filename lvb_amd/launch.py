@@ -8,6 +8,58 @@ the communicator id is created on rank 0 and shared through `share_bytes`.
 from __future__ import annotations
 
 import os
+import threading
+
+
+def pin_to_share_of_cores() -> dict:
+    """One process per GPU: keep this rank on ITS share of the cores the job may run on - the affinity mask cut into
+    LOCAL_WORLD_SIZE contiguous pieces - and size the library's thread pool to it (LVBGPU_THREADS, unless set).  Call it
+    before the scoring library is loaded (its pool reads the mask then) and before anything starts threads.  Eight ranks
+    with a spinning submit / collect loop and sixteen pool threads each, all free to run anywhere, is how a scaling run
+    loses on the host what the GPUs deliver.  -> what was done, for the result line."""
+    lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+    lr = int(os.environ.get("LOCAL_RANK", "0") or 0) % lws
+    info = {"local_world_size": lws, "pinned": False}
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = list(range(os.cpu_count() or 1))
+    share = cores[len(cores) * lr // lws: len(cores) * (lr + 1) // lws] or cores
+    if lws > 1 and share and len(share) < len(cores) and os.environ.get("LVBGPU_NO_PIN") is None:
+        try:
+            os.sched_setaffinity(0, share)
+            info["pinned"] = True
+        except (AttributeError, OSError):
+            share = cores
+    else:
+        share = cores if lws == 1 else share
+    threads = max(2, min(16, len(share)))
+    os.environ.setdefault("LVBGPU_THREADS", str(threads))
+    info.update(cores_allowed=len(cores), cores_per_rank=len(share), threads=int(os.environ["LVBGPU_THREADS"]))
+    return info
+
+
+def call_with_deadline(fn, seconds: float):
+    """fn() on a helper thread, waited for at most `seconds` -> (done, result or exception).  For collective set-up calls
+    that can hang when one rank never arrives (ncclCommInitRank has no deadline of its own): the caller falls back or gives
+    up instead of hanging the whole job.  A call that did not come back keeps its (daemon) thread; the caller should end
+    the process with os._exit once its work is reported, never start another program from it."""
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as exc:   # noqa: BLE001 - handed to the caller
+            box["error"] = exc
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return False, None
+    if "error" in box:
+        return True, box["error"]
+    return True, box.get("value")
 
 
 class Ranks:

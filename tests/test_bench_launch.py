@@ -53,3 +53,31 @@ def test_under_a_launcher_the_world_size_must_match():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-ranks"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_eight_ranks_share_the_hosts_cores():
+    """The driver's scaling run is --gpus 8 on one node: rehearsed over gloo.  Every rank keeps to ITS share of the cores
+    the job may run on (affinity mask / LOCAL_WORLD_SIZE, set before the scoring library and its thread pool are loaded)
+    and sizes the pool to it: eight ranks with sixteen free-running workers each is how a >= 6x target is lost on the host."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--dry-ranks", "--steps", "2"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["comm_size"] == 8 and c["own_comm"] is True
+    assert c["best_length"] == 1000 and c["per_rank"] == [float(r + 1) for r in range(8)]
+    cores = len(os.sched_getaffinity(0))
+    assert sum(c["cores_of_ranks"]) <= cores or cores < 8          # the shares do not overlap ...
+    assert all(v >= 1 for v in c["cores_of_ranks"])
+    assert c["pinned_to_share_of_cores"] == (cores >= 8 and cores // 8 < cores)
+    assert 2 <= c["host_threads_per_rank"] <= max(2, min(16, int(max(c["cores_of_ranks"]))))
+
+
+def test_a_rank_whose_communicator_never_comes_up_does_not_hang_the_run():
+    """lvbgpu_comm_init is collective and has no deadline of its own (ncclCommInitRank): bench.py waits for it under one.
+    Rehearsed: rank 1's set-up never returns - every rank agrees on the fallback, the line is printed, the run ends with 0."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--dry-ranks", "--steps", "2", "--dry-stuck-rank", "1"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 3 and d["config"]["own_comm"] is False and d["config"]["best_length"] == 1000
