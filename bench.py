@@ -98,6 +98,8 @@ def parse_args(argv=None):
     ap.add_argument("--headline-only", action="store_true",
                     help="the timed region and its roofline only (profiling runs: every scoring walk of the process is "
                          "then one of the headline's device-built batches)")
+    ap.add_argument("--long-steps", type=int, default=200,
+                    help="steps of the same pipelined loop run BEHIND the timed region and reported as value_long (0: none)")
     ap.add_argument("--comm-init-seconds", type=float, default=90.0,
                     help="N > 1: how long a rank waits for the library's own RCCL communicator (lvbgpu_comm_init) before "
                          "every rank falls back to torch.distributed for the min-reduce")
@@ -272,7 +274,7 @@ def random_walk(ctx, tree, kind: int, moves: int) -> int:
 
 
 def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, seed0: int, reduce_best=None, settle: int = 0,
-                      depth: int = 2):
+                      depth: int = 2, long_steps: int = 0):
     """The metric's step, `steps` times: draw + program + score B neighbours on the GPU, lengths on the host.
     -> dict(elapsed_s [max over ranks], launch_ms [mean walk duration, HIP events], best, stats).
     depth 2 (default): two batches in flight (lvbgpu_chains_submit / _collect) - while the host reads step i's
@@ -291,14 +293,19 @@ def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, se
         draw[0]["seed"] = seed & 0xFFFFFFFFFFFFFFFF
         ctx._chk(lib.lvbgpu_chains_submit(h, slot, 1, draw.ctypes.data))
 
+    stamps = []   # when each step of the last run() had its lengths on the host
+
     def run(n, first_seed):
         """n pipelined steps; -> best length seen"""
         best = np.iinfo(np.int64).max
+        del stamps[:]
+        stamps.append(time.perf_counter())
         for j in range(min(depth, n)):
             submit(j % 2, first_seed + j)
         for i in range(n):
             slot = i % 2 if depth > 1 else 0
             ctx._chk(lib.lvbgpu_chains_collect(h, slot, outs[slot]))
+            stamps.append(time.perf_counter())
             best = min(best, int(outs[slot].min()))
             if i + depth < n:
                 submit(slot, first_seed + i + depth)
@@ -312,13 +319,24 @@ def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, se
         ctx.walk_timing(WALK_TIMING_EVERY)   # a pair of events costs the step ~20 us: sample
         gc.disable()                         # a collection inside a few-millisecond region would be most of it
 
+    paired_before = ctx.paired_walks()
     head = timed_steps(run, ctx.synchronize, ranks, steps, seed0, reduce_best,
                        warm_best if warmup > 0 else 1 << 40, before_t0)
+    step_gaps = np.diff(np.array(stamps)) if len(stamps) > 1 else np.zeros(1)
     if gc_was:
         gc.enable()
     best, best_global, t_steps, elapsed = head["best_local"], head["best"], head["steps_s_local"], head["elapsed_local"]
     walk_ms, walks = ctx.walk_timing_read()
     ctx.walk_timing(False)
+    paired = ctx.paired_walks() > paired_before   # the library pairs by itself where the programs are long
+    # a longer look at the same loop, behind the timed region (a region of K = 20 steps is 2 ms: one stalled step halves
+    # its figure, and nothing in K steps says whether one did): `long_steps` more steps on this rank's own clock
+    long_rate, long_n = None, 0
+    if long_steps > 0:
+        tl = time.perf_counter()
+        run(long_steps, (seed0 + 50000) & 0x7FFFFFFF)
+        ctx.synchronize()
+        long_n, long_rate = long_steps, time.perf_counter() - tl
     # what those batches cost: the draw is a function of (seed, b), so re-drawing a few of the timed seeds
     # (outside the timed region) gives exactly their counts
     picks = sorted({seed0 + int(round(k * (steps - 1) / 7)) for k in range(8)}) if steps > 0 else []
@@ -331,7 +349,9 @@ def submit_to_lengths(ctx, ranks, B: int, kind: int, steps: int, warmup: int, se
         "elapsed_s": head["elapsed_s"], "elapsed_local": elapsed, "steps_s_local": t_steps, "reduce_ms": head["reduce_ms"],
         "order": head["order"], "launch_ms": walk_ms / max(walks, 1), "walks": walks, "best": best_global, "best_local": best,
         "alg_bytes": mean("algorithmic_bytes"), "mean_dirty": mean("dirty_nodes") / max(mean("candidates"), 1.0),
-        "scored_per_step": mean("candidates"),
+        "scored_per_step": mean("candidates"), "paired": bool(paired),
+        "longest_step_ms": 1e3 * float(step_gaps.max()), "median_step_ms": 1e3 * float(np.median(step_gaps)),
+        "long_steps": long_n, "long_seconds": long_rate,
     }
 
 
@@ -371,13 +391,16 @@ def kernel_only(ctx, tree, B: int, kind: int, nbatches: int, steps: int, warmup:
                     "lengths read once after the loop"}
 
 
-def roofline_block(ctx, B: int, alg_bytes: float, launch_ms: float, mean_dirty: float, traffic, probe_reps: int = 20):
+def roofline_block(ctx, B: int, alg_bytes: float, launch_ms: float, mean_dirty: float, traffic, probe_reps: int = 20,
+                   paired: bool = False):
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     probe = ctx.probe_l2(B, max(8, int(round(mean_dirty + 3))), probe_reps)
     # which variant the pipelined loop launches: small launches (B x tiles < 32768 waves) hand their lengths over through
     # watcher waves (<.., 2>, api_propose.cpp WATCH_PIPELINED_MAX_ITEMS), the others are copied back (<.., 0>)
     ntiles = (int(ctx.nwords) + 127) // 128
     kernel = KERNEL if ("pair" in KERNEL or B * ntiles >= 32768) else KERNEL.replace(", 0>", ", 2>")
+    if paired and "pair" not in kernel:   # the library paired these batches by itself (long programs: DESIGN.md section 3)
+        kernel = "lvbgpu::fitch_walk_pair<false, false>" if B * ntiles >= 32768 else "lvbgpu::fitch_walk_pair<false, true>"
     out = {
         "bound": "l2", "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
         "traffic": traffic, "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -389,9 +412,14 @@ def roofline_block(ctx, B: int, alg_bytes: float, launch_ms: float, mean_dirty: 
     }
     if traffic:
         gbs = traffic / (launch_ms * 1e-3) / 1e9
+        out["traffic"] = float(traffic)
         out["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                       "reuse": alg_bytes / traffic,
-                      "source": "rocprofv3 PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, profiles/traffic.json"}
+                      "source": "rocprofv3 PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, profiles/traffic.json"
+                                + (f" ({traffic.source})" if getattr(traffic, "source", "") else ""),
+                      # the counters were collected in another run than this one: true when the walk's sources have
+                      # changed since (the entry carries their hash)
+                      "stale": bool(getattr(traffic, "stale", True))}
     return out
 
 
@@ -566,6 +594,27 @@ def load_traffic(args, mixed: bool):
     return traffic_for(args.taxa, args.sites, args.batch, args.move, mixed)
 
 
+KERNEL_SOURCES = ("lvb_amd/csrc/fitch_kernels.hip", "lvb_amd/csrc/walk_body.hpp", "lvb_amd/csrc/kernels.hpp",
+                  "lvb_amd/csrc/api_propose.cpp")
+
+
+def kernel_source_sha() -> str:
+    """What an HBM-traffic entry of profiles/traffic.json was measured on: the scoring walk, its launcher and the batch
+    builder.  The PMC passes run on another box at another time than a bench run; the entry carries this hash and the
+    line says `stale` when the sources have moved since."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        hsh.update((ROOT / rel).read_bytes())
+    return hsh.hexdigest()[:16]
+
+
+class Traffic(float):
+    """HBM bytes per launch from profiles/traffic.json, with where it came from"""
+    stale = True
+    source = ""
+
+
 def traffic_for(taxa: int, sites: int, batch: int, move: str, mixed: bool = False):
     tfile = ROOT / "profiles" / "traffic.json"
     if not tfile.exists():
@@ -574,7 +623,10 @@ def traffic_for(taxa: int, sites: int, batch: int, move: str, mixed: bool = Fals
     for e in t if isinstance(t, list) else [t]:
         if (e.get("taxa"), e.get("sites"), e.get("batch"), e.get("move"), bool(e.get("mixed_walk", False))) == \
                 (taxa, sites, batch, move, mixed):
-            return e["hbm_bytes_per_launch"]   # rocprofv3 PMC passes (profiles/collect.sh), gfx950-corrected
+            v = Traffic(e["hbm_bytes_per_launch"])   # rocprofv3 PMC passes (profiles/collect.sh), gfx950-corrected
+            v.stale = e.get("kernel_sha") != kernel_source_sha()
+            v.source = e.get("source", "")
+            return v
     return None
 
 
@@ -600,7 +652,7 @@ def config_leg(ranks, device: int, cfg: str, taxa: int, sites: int, move: str, b
             "value": r["scored_per_step"] * steps / r["elapsed_s"], "unit": "trees/s", "ms_per_step": 1e3 * r["elapsed_s"] / steps,
             "steps": steps, "walk_us": 1e3 * r["launch_ms"], "mean_dirty_nodes": round(r["mean_dirty"], 2),
             "roofline": roofline_block(ctx, B, r["alg_bytes"], r["launch_ms"], r["mean_dirty"],
-                                       traffic_for(taxa, sites, B, move), 6 if taxa >= 1000 else 20),
+                                       traffic_for(taxa, sites, B, move), 6 if taxa >= 1000 else 20, paired=r["paired"]),
         }
     if multi_chain:
         # small shapes do not fill the chip with one chain's batch (cfg2: 1024 candidates x 5 tiles = 5120 waves against
@@ -720,7 +772,7 @@ def rank_main(args) -> None:
 
     # ---- the timed region: K steps of submit -> lengths on the host (+ the min-reduce over ranks)
     head = submit_to_lengths(ctx, ranks, B, kind, args.steps, args.warmup, 1000, reduce_best if world > 1 else None,
-                             settle=args.settle)
+                             settle=args.settle, long_steps=args.long_steps)
     per_step = head["scored_per_step"] if head["scored_per_step"] else B
     total_trees = per_step * args.steps * world
     per_rank = ranks.all_values(per_step * args.steps / head["elapsed_local"])   # each rank's own clock around ITS region
@@ -763,8 +815,16 @@ def rank_main(args) -> None:
                             "synchronize, barrier, t1; value = all ranks' candidates / max over ranks of (t1 - t0)",
         },
         "roofline": roofline_block(ctx, B, head["alg_bytes"], head["launch_ms"], head["mean_dirty"],
-                                   load_traffic(args, False)),
+                                   load_traffic(args, False), paired=head["paired"]),
+        # did a step of the timed region stall?  Its longest and median step (lengths on the host to lengths on the host,
+        # this rank), and the same loop for `long_steps` more steps BEHIND the timed region (this rank's own clock)
+        "timed_region_steps": {"longest_ms": round(head["longest_step_ms"], 4), "median_ms": round(head["median_step_ms"], 4)},
     }
+    if head["long_steps"]:
+        out["value_long"] = {"value": per_step * head["long_steps"] * world / head["long_seconds"], "unit": "trees/s",
+                             "steps": head["long_steps"], "ms_per_step": 1e3 * head["long_seconds"] / head["long_steps"],
+                             "what": "the same pipelined loop for more steps, right behind the timed region (rank 0's clock, "
+                                     "times the number of ranks)"}
     steps_side = max(20, min(args.steps, 100))
     if not args.headline_only:
         one = submit_to_lengths(ctx, ranks, B, kind, steps_side, 5, 3000, depth=1)
@@ -815,7 +875,9 @@ def rank_main(args) -> None:
             "accepted_moves": args.walk + args.mixed_walk, "mean_dirty_nodes": round(m["mean_dirty"], 2),
             "value": m["scored_per_step"] * steps_side / m["elapsed_s"], "unit": "trees/s",
             "ms_per_step": 1e3 * m["elapsed_s"] / steps_side, "steps": steps_side,
-            "roofline": roofline_block(ctx, B, m["alg_bytes"], m["launch_ms"], m["mean_dirty"], load_traffic(args, True), 10),
+            "roofline": roofline_block(ctx, B, m["alg_bytes"], m["launch_ms"], m["mean_dirty"], load_traffic(args, True), 10,
+                                       paired=m["paired"]),
+            "two_candidates_per_wave": m["paired"],
             "kernel_only": kernel_only(ctx, mtree, B, kind, args.nbatches, steps_side, 5),
         }
         mixed_arrays, mixed_len = tree_arrays_of(mtree), mlen

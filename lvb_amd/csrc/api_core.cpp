@@ -121,7 +121,13 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     if (const char *lp = getenv("LVBGPU_LPT"))
         ctx->lpt_order = lp[0] != '0';
     if (const char *pr = getenv("LVBGPU_PAIR"))
+    {
         ctx->pair_min = std::max(0, atoi(pr));
+        ctx->pair_auto = false; // said explicitly: from n candidates on, or (0) never
+    }
+    if (const char *pt = getenv("LVBGPU_PAIR_TOKENS"))
+        if (atof(pt) > 0.0)
+            ctx->pair_tokens_min = atof(pt);
     if (const char *pl = getenv("LVBGPU_PIPELINE"))
         ctx->pipeline_steps = pl[0] != '0';
     static_assert(lvbgpu_ctx::STEP_PIPELINE == 4, "lvbgpu_destroy lists the step batches");
@@ -288,6 +294,8 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     delete ctx->pool;
     ctx->pool = nullptr;
     ctx->d_topo4.release();
+    ctx->d_gen_ticks.release();
+    ctx->d_table_ready.release();
     for (lvbgpu_ctx::PropSlot &ps : ctx->pslot)
     {
         ps.d_pedits.release();

@@ -372,7 +372,33 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     ga.len_out = (unsigned long long *)bt->d_len.p;
     // two candidates per wave (fitch_walk_pair): big launches only - a small one is a chain of latencies, not of loads -
     // and only where every segment's keys fit the sorting workgroup's LDS and preorder numbers fit 16 bits
-    bool pair_up = ctx->pair_min > 0 && B >= ctx->pair_min && ctx->gen_idx_bytes == 2;
+    // LVBGPU_PAIR=n: every batch of n candidates and more; unset: by itself (pair_auto) where it pays - big launches of
+    // long programs.  The paired walk loads the rows two programs share once, which is worth the more the longer the
+    // common way to the root is: measured 500 x 50 000 SPR, B = 4096, walk 86.5 -> 82.3 us on a fresh tree (D = 20) but
+    // 147.9 -> 133.0 us on one mixed by 3000 moves (D = 43); the order costs the generator's launch ~3 us (its last
+    // workgroups sort).  The programs' length is estimated from the trees' mean node depth (D ~ 1.45 x mean depth + 3 for
+    // SPR / TBR on these trees: tools/down_set_estimate.py's neighbour, measured), which the host has without asking the
+    // device.
+    bool pair_up = ctx->gen_idx_bytes == 2 && !moves;
+    if (ctx->pair_min > 0)
+        pair_up = pair_up && B >= ctx->pair_min;
+    else if (ctx->pair_auto && B >= 2048)
+    {
+        double est = 0.0;
+        for (int32_t i = 0; i < k; i++)
+        {
+            ChainSlot &cs = ctx->parked[(size_t)draws[i].chain];
+            if (cs.depth_version != cs.topo_version)
+            {
+                cs.mean_depth = cs.topo.mean_depth();
+                cs.depth_version = cs.topo_version;
+            }
+            est += (1.45 * cs.mean_depth + 6.0) * draws[i].count;
+        }
+        pair_up = pair_up && est / B >= ctx->pair_tokens_min;
+    }
+    else
+        pair_up = false;
     for (int32_t i = 0; i < k && pair_up; i++)
         pair_up = (uint32_t)draws[i].count <= PAIR_SEG_MAX;
     bt->npairs = 0;
@@ -383,7 +409,21 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
             np += ((uint32_t)draws[i].count + 1u) / 2u;
         HIPCHK(ctx, ps.d_keys.reserve((size_t)B * 4));
         HIPCHK(ctx, bt->d_pairs.reserve((size_t)np * 8));
+        const size_t old_ticks = ctx->d_gen_ticks.cap;
+        HIPCHK(ctx, ctx->d_gen_ticks.reserve(64));
+        if (ctx->d_gen_ticks.cap != old_ticks) // once per context: the running count starts at zero, with the host's
+        {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_gen_ticks.p, 0, ctx->d_gen_ticks.cap, ctx->stream));
+            ctx->gen_ticks_total = 0;
+        }
         ga.keys = (uint32_t *)ps.d_keys.p;
+        ga.pairs = (uint32_t *)bt->d_pairs.p;
+        ga.gen_done = (uint32_t *)ctx->d_gen_ticks.p;
+        uint32_t bits = 1;
+        while ((1u << bits) < (uint32_t)ctx->nb + 1u)
+            bits++;
+        ga.major_bits = bits > 12u ? 12u : bits; // buckets by preorder number (coarser for very large trees)
+        ga.major_shift = bits > 12u ? bits - 12u : 0u;
         bt->npairs = np;
     }
     ga.moves = d_moves;
@@ -430,7 +470,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         {
             rc = flush_pending(ctx, nullptr);
             if (rc == LVBGPU_OK)
-                HIPCHK(ctx, launch_propose(ga, ctx->stream));
+                HIPCHK(ctx, launch_propose(ga, ctx->stream, &ctx->gen_ticks_total));
         }
         if (rc != LVBGPU_OK)
         {
@@ -439,29 +479,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         }
     }
     else
-        HIPCHK(ctx, launch_propose(ga, ctx->stream));
-    if (pair_up)
-    {
-        PairArgs pa{};
-        pa.keys = ga.keys;
-        pa.pairs = (uint32_t *)bt->d_pairs.p;
-        pa.nseg = (uint32_t)k;
-        uint32_t bits = 1;
-        while ((1u << bits) < (uint32_t)ctx->nb + 1u)
-            bits++;
-        pa.major_bits = bits > 12u ? 12u : bits; // buckets by preorder number (coarser for very large trees)
-        pa.major_shift = bits > 12u ? bits - 12u : 0u;
-        uint32_t st = 0, pb = 0;
-        for (int32_t i = 0; i < k; i++)
-        {
-            pa.seg_start[i] = st;
-            pa.seg_count[i] = (uint32_t)draws[i].count;
-            pa.pair_base[i] = pb;
-            st += (uint32_t)draws[i].count;
-            pb += ((uint32_t)draws[i].count + 1u) / 2u;
-        }
-        HIPCHK(ctx, launch_pair_sort(pa, ctx->stream));
-    }
+        HIPCHK(ctx, launch_propose(ga, ctx->stream, &ctx->gen_ticks_total));
     bt->len_zeroed = true; // by the generator
     // Only the lengths come back per step (a move's descriptor and edits are fetched when, and only when, the caller
     // wants that candidate - lvbgpu_proposal_edits - or accepts it - lvbgpu_chains_commit).  One batch at a time the
@@ -958,7 +976,7 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
         ctx->post_launches_with_generator++;
     }
     ctx->post_launches++;
-    HIPCHK(ctx, launch_post(pa, ctx->stream, ctx->sharing));
+    HIPCHK(ctx, launch_post(pa, ctx->stream, ctx->sharing, &ctx->gen_ticks_total));
     return LVBGPU_OK;
 }
 

@@ -211,7 +211,15 @@ struct GenArgs
     CandDesc *cands;
     ProposalInfo *info;
     unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
-    uint32_t *keys;              // [B] sort keys for pairing the candidates (pair_kernel; null: none; needs 16-bit tables)
+    uint32_t *keys;              // [B] sort keys for pairing the candidates (sort_role; null: none; needs 16-bit tables)
+    // two candidates per wave: the launch's LAST workgroups (n_sort_blocks of them, dealt behind the generator's) put
+    // every segment's candidates in the order of their keys and hand them out two by two - pairs[2 p], pairs[2 p + 1] -
+    // once all the generator's workgroups have ticked gen_done (a running count: they wait for gen_done_target)
+    uint32_t *pairs;
+    uint32_t *gen_done;
+    uint32_t gen_done_target, n_sort_blocks, n_gen_blocks;
+    uint32_t major_bits, major_shift; // buckets of the counting sort: (key >> 16) >> major_shift, below 2^major_bits
+    uint32_t sort_cap;                // the longest segment (what a sorting workgroup's LDS arrays hold)
     const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
     unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
     const uint32_t *table_ready;  // post launch: [MAX_CHAINS], = ready_seq once that chain's tables have been rebuilt (GenSeg::wait)
@@ -221,22 +229,13 @@ struct GenArgs
     GenSeg seg[MAX_GEN_SEGS];
 };
 static_assert(sizeof(GenArgs) <= 2600, "GenArgs travels as a kernel argument, in the post launch beside three more structs");
-hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
+// ticks_total: the caller's running count of generator workgroups (what the sorting workgroups of a pairing launch wait for)
+hipError_t launch_propose(const GenArgs &args, hipStream_t stream, uint32_t *ticks_total = nullptr);
 
 // who walks with whom (fitch_walk_pair): every segment's candidates ordered by their keys and handed out two by two
-constexpr uint32_t PAIR_THREADS = 1024;
 constexpr uint32_t PAIR_SEG_MAX = 4096; // candidates of one segment whose keys and order fit LDS beside the histogram (longer: no pairing)
-struct PairArgs
-{
-    const uint32_t *keys; // [B] (GenArgs::keys)
-    uint32_t *pairs;      // [2 * npairs]: segment s's pairs from pair_base[s] on, ceil(count / 2) of them
-    uint32_t nseg;
-    uint32_t major_bits, major_shift; // buckets of the counting sort: (key >> 16) >> major_shift, below 2^major_bits
-    uint32_t seg_start[MAX_GEN_SEGS], seg_count[MAX_GEN_SEGS], pair_base[MAX_GEN_SEGS];
-    uint32_t blk_start[MAX_GEN_SEGS]; // first workgroup of each segment, and what a workgroup's LDS arrays hold (filled by launch_pair_sort)
-    uint32_t cap;
-};
-hipError_t launch_pair_sort(const PairArgs &args, hipStream_t stream);
+// sorting workgroups of a segment of `count` candidates (one per ~512 candidates, at most 8; they never talk to each other)
+__host__ __device__ inline uint32_t sort_blocks_of(uint32_t count) { return count / 512u < 1u ? 1u : (count / 512u > 8u ? 8u : count / 512u); }
 
 // rebuild the generator's tables of the picked candidates' chains on the device (one workgroup per pick)
 constexpr uint32_t REBUILD_THREADS = 1024;
@@ -301,7 +300,7 @@ static_assert(sizeof(PostArgs) <= 4000, "PostArgs travels as a kernel argument")
 // can the generator ride in a post launch (its tables must fit LDS beside nothing else)?
 bool post_can_generate(const GenArgs &g);
 // narrow: 4-wave workgroups with little LDS, which find room beside another queue's scoring walk (lvbgpu_set_sharing)
-hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow = false);
+hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow = false, uint32_t *ticks_total = nullptr);
 // fills what a walk's launcher owes the kernel (tiles per group, the division constant, and for a commit walk the burst
 // slots that fit `lds_budget` bytes per workgroup of `nwaves` waves beside the operand stacks); *lds_out = dynamic LDS
 hipError_t shape_walk(WalkArgs &a, bool commit, uint32_t nwaves, size_t lds_budget, size_t *lds_out);

@@ -572,9 +572,12 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
         g.cands[b] = cd;
         g.len_out[b] = 0ull; // the walk accumulates into it: cleared here, so a step needs no clearing pass of its own
         g.info[b] = ProposalInfo{kind, pi_a, pi_b, pi_c, pi_flag, (int32_t)e.o.nedit, overflow ? 1 : 0, (int32_t)e.o.ndst};
-        if (g.keys) // preorder numbers of the two chain starts: neighbours in this order end alike (pair_kernel)
-            g.keys[b] = (overflow || key_major < 0) ? 0xFFFFFFFFu
-                                                    : ((uint32_t)t.tin[key_major] << 16) | (key_minor >= 0 ? (uint32_t)t.tin[key_minor] & 0xFFFFu : 0u);
+        if (g.keys) // preorder numbers of the two chain starts: neighbours in this order end alike (sort_role, in this launch:
+                    // written through, its workgroups sit on other XCDs)
+            __hip_atomic_store(g.keys + b,
+                               (overflow || key_major < 0) ? 0xFFFFFFFFu
+                                                           : ((uint32_t)t.tin[key_major] << 16) | (key_minor >= 0 ? (uint32_t)t.tin[key_minor] & 0xFFFFu : 0u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(4);
 }
@@ -699,13 +702,172 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
     }
     for (uint32_t bl = blk_local * nwaves + wave; bl < sg.count; bl += seg_blocks * nwaves)
         generate_one(t, g, sg, bl, lane);
+    if (g.n_sort_blocks)
+    {
+        // this workgroup's keys are out (acknowledged: written through): tell the sorting workgroups at the launch's end
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicAdd(g.gen_done, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Who walks with whom (fitch_walk_pair): a segment's candidates are put in order of their keys - the preorder number of
+// the node the program's LAST chain starts at, then of the one its first chain starts at: programs that agree on these
+// share their ends - and pair p is whoever stands at places 2p and 2p + 1.  The order is made by the LAST workgroups of
+// the generator's own launch (round 3: a kernel of its own behind it - 8.7 us of a step for what is 3 us of work, more
+// than the paired walk saved at D = 20): they wait until every generating workgroup has ticked, then several workgroups
+// per segment that never talk to each other: workgroup r of a segment's R owns the r-th range of major keys; it reads ALL
+// the segment's keys (a few KB), counts how many fall below its range - that is where its output starts - and sorts the
+// ones inside: counting sort by major key (LDS atomics; the order inside a bucket is whatever the atomics gave), then
+// every candidate finds its own place in its bucket by counting who comes before it in (key, index) order (buckets hold
+// a handful: four candidates per node at B = 4096, n = 500), so the result does not depend on timing.
+__device__ __forceinline__ void sort_role(const GenArgs &g, const uint32_t sblk, uint32_t *const lds_u32)
+{
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    // which segment, which range of it: segment s has sort_blocks_of(count) workgroups, its pairs start at pair_base
+    uint32_t s = 0, first = 0, pair_base = 0;
+    for (; s + 1u < g.nseg && sblk >= first + sort_blocks_of(g.seg[s].count); s++)
+    {
+        first += sort_blocks_of(g.seg[s].count);
+        pair_base += (g.seg[s].count + 1u) / 2u;
+    }
+    const uint32_t r = sblk - first, R = sort_blocks_of(g.seg[s].count);
+    const uint32_t start = g.seg[s].start, count = g.seg[s].count;
+    // every generating workgroup has ticked?  (dealt before this one: resident or done; a word of LDS says what thread 0 saw)
+    volatile uint32_t *const agree = reinterpret_cast<volatile uint32_t *>(lds_u32);
+    if (tid == 0)
+    {
+        uint32_t budget = 1u << 24;
+        while (__hip_atomic_load(g.gen_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.gen_done_target && --budget)
+            __builtin_amdgcn_s_sleep(8);
+        *agree = budget == 0u ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool gave_up = *agree != 0u;
+    __syncthreads();
+    uint32_t *out = g.pairs + 2u * pair_base;
+    if (gave_up)
+    {
+        // never pair by keys that may not be there: everybody walks in the order of the draw (any order is a valid pairing)
+        const uint32_t lo = (uint32_t)((uint64_t)count * r / R), hi = (uint32_t)((uint64_t)count * (r + 1u) / R);
+        for (uint32_t i = lo + tid; i < hi; i += nt)
+            out[i] = start + i;
+        if (r == R - 1u && tid == 0u && (count & 1u))
+            out[count] = PICK_NONE;
+        return;
+    }
+    const uint32_t NB = 1u << g.major_bits;
+    auto bucket_of = [&](uint32_t key) { return key == 0xFFFFFFFFu ? NB - 1u : (key >> 16) >> g.major_shift; };
+    const uint32_t b_lo = (uint32_t)((uint64_t)NB * r / R), b_hi = (uint32_t)((uint64_t)NB * (r + 1u) / R); // my buckets
+    const uint32_t nbk = b_hi - b_lo;
+    // LDS: mine[cap] keys | idx[cap] | order[cap] | sorted[cap] | hist[nbk + 1] | scan scratch[64] | counters[2]
+    const uint32_t cap = g.sort_cap;
+    uint32_t *mkey = lds_u32, *midx = mkey + cap, *order = midx + cap, *sorted = order + cap, *hist = sorted + cap,
+             *part = hist + nbk + 1u, *ctr = part + 64u;
+    for (uint32_t b = tid; b <= nbk; b += nt)
+        hist[b] = 0u;
+    if (tid < 2u)
+        ctr[tid] = 0u;
+    __syncthreads();
+    // one pass over all keys: how many lie below my range, and mine into LDS
+    uint32_t below = 0;
+    for (uint32_t i = tid; i < count; i += nt)
+    {
+        const uint32_t k = __hip_atomic_load(g.keys + start + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = bucket_of(k);
+        below += b < b_lo ? 1u : 0u;
+        if (b >= b_lo && b < b_hi)
+        {
+            const uint32_t at = atomicAdd(&ctr[1], 1u);
+            if (at < cap)
+            {
+                mkey[at] = k;
+                midx[at] = i;
+                atomicAdd(&hist[b - b_lo + 1u], 1u);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        below += (uint32_t)__shfl_xor((int)below, off);
+    if ((tid & 63u) == 0u)
+        atomicAdd(&ctr[0], below);
+    __syncthreads();
+    const uint32_t base = ctr[0], mine = ctr[1] < cap ? ctr[1] : cap; // (cap = the longest segment: never exceeded)
+    // exclusive scan of my buckets' counts (hist[b + 1] becomes bucket b's start): buckets dealt to the threads, the
+    // threads' sums scanned inside the waves by shuffles and across them through LDS
+    {
+        const uint32_t per = (nbk + nt - 1u) / nt;
+        const uint32_t b0 = tid * per;
+        uint32_t sum = 0;
+        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
+            sum += hist[b + 1u];
+        const uint32_t ln = tid & 63u, wv = tid >> 6, nwv = (nt + 63u) >> 6;
+        uint32_t incl = sum;
+        for (uint32_t d = 1; d < 64u; d <<= 1)
+        {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, (int)d);
+            if (ln >= d)
+                incl += v;
+        }
+        if (ln == 63u)
+            part[wv] = incl;
+        __syncthreads();
+        if (tid < 64u)
+        {
+            const uint32_t w = tid < nwv ? part[tid] : 0u;
+            uint32_t wi = w;
+            for (uint32_t d = 1; d < 64u; d <<= 1)
+            {
+                const uint32_t v = (uint32_t)__shfl_up((int)wi, (int)d);
+                if (tid >= d)
+                    wi += v;
+            }
+            part[tid] = wi - w; // exclusive
+        }
+        __syncthreads();
+        uint32_t run = part[wv] + incl - sum;
+        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
+        {
+            const uint32_t c = hist[b + 1u];
+            hist[b + 1u] = run;
+            run += c;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < mine; i += nt) // scatter: hist[b + 1] is bucket b's cursor, afterwards its end
+        order[atomicAdd(&hist[bucket_of(mkey[i]) - b_lo + 1u], 1u)] = i;
+    __syncthreads();
+    for (uint32_t pos = tid; pos < mine; pos += nt)
+    {
+        const uint32_t x = order[pos], b = bucket_of(mkey[x]) - b_lo;
+        const uint32_t lo = b ? hist[b] : 0u, hi = hist[b + 1u];
+        const uint64_t kx = ((uint64_t)mkey[x] << 32) | midx[x];
+        uint32_t before = 0;
+        for (uint32_t j = lo; j < hi; j++)
+        {
+            const uint32_t y = order[j];
+            before += ((((uint64_t)mkey[y]) << 32) | midx[y]) < kx ? 1u : 0u;
+        }
+        sorted[lo + before] = start + midx[x];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < mine; i += nt)
+        out[base + i] = sorted[i];
+    if (r == R - 1u && tid == 0u && (count & 1u))
+        out[count] = PICK_NONE; // an odd segment's last candidate walks alone
 }
 
 template <typename IdxT, bool IN_LDS>
 __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 {
     extern __shared__ uint4 lds_dyn[];
-    gen_role<IdxT, IN_LDS>(g, blockIdx.x, gridDim.x, lds_dyn);
+    if (blockIdx.x >= g.n_gen_blocks)
+    {
+        sort_role(g, blockIdx.x - g.n_gen_blocks, reinterpret_cast<uint32_t *>(lds_dyn));
+        return;
+    }
+    gen_role<IdxT, IN_LDS>(g, blockIdx.x, g.n_gen_blocks, lds_dyn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -893,163 +1055,13 @@ __global__ __launch_bounds__(WAVES * 64u) void post_kernel(const PostArgs p)
         return;
     }
     if (p.gen.nseg)
-        gen_role<IdxT, true>(p.gen, b - p.n_reb - p.n_cblk, gridDim.x - p.n_reb - p.n_cblk, lds_dyn);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Who walks with whom (fitch_walk_pair): a segment's candidates are put in order of their keys - the preorder number of
-// the node the program's LAST chain starts at, then of the one its first chain starts at: programs that agree on these
-// share their ends - and pair p is whoever stands at places 2p and 2p + 1.  The order is made by several workgroups per
-// segment that never talk to each other: workgroup r of a segment's R owns the r-th range of major keys; it reads ALL
-// the segment's keys (a few KB from L2), counts how many fall below its range - that is where its output starts - and
-// sorts the ones inside: counting sort by major key (LDS atomics; the order inside a bucket is whatever the atomics
-// gave), then every candidate finds its own place in its bucket by counting who comes before it in (key, index) order
-// (buckets hold a handful: four candidates per node at B = 4096, n = 500), so the result does not depend on timing.
-// One workgroup sorting a whole segment of 4096 took 10 us - more than the paired walk saves.
-__global__ __launch_bounds__(PAIR_THREADS) void pair_kernel(const PairArgs g)
-{
-    extern __shared__ uint32_t lds_u32[];
-    // which segment, which range of it
-    uint32_t s = 0;
-    while (s + 1u < g.nseg && blockIdx.x >= g.blk_start[s + 1u])
-        s++;
-    const uint32_t r = blockIdx.x - g.blk_start[s];
-    const uint32_t R = (s + 1u < g.nseg ? g.blk_start[s + 1u] : gridDim.x) - g.blk_start[s];
-    const uint32_t start = g.seg_start[s], count = g.seg_count[s];
-    uint32_t *out = g.pairs + 2u * g.pair_base[s];
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t NB = 1u << g.major_bits;
-    auto bucket_of = [&](uint32_t key) { return key == 0xFFFFFFFFu ? NB - 1u : (key >> 16) >> g.major_shift; };
-    const uint32_t b_lo = (uint32_t)((uint64_t)NB * r / R), b_hi = (uint32_t)((uint64_t)NB * (r + 1u) / R); // my buckets
-    const uint32_t nbk = b_hi - b_lo;
-    // LDS: mine[cap] keys | idx[cap] | order[cap] | sorted[cap] | hist[nbk + 1] | scan scratch[64] | counters[2]
-    const uint32_t cap = g.cap;
-    uint32_t *mkey = lds_u32, *midx = mkey + cap, *order = midx + cap, *sorted = order + cap, *hist = sorted + cap,
-             *part = hist + nbk + 1u, *ctr = part + 64u;
-    for (uint32_t b = tid; b <= nbk; b += nt)
-        hist[b] = 0u;
-    if (tid < 2u)
-        ctr[tid] = 0u;
-    __syncthreads();
-    // one pass over all keys: how many lie below my range, and mine into LDS
-    uint32_t below = 0;
-    for (uint32_t i = tid; i < count; i += nt)
     {
-        const uint32_t k = g.keys[start + i], b = bucket_of(k);
-        below += b < b_lo ? 1u : 0u;
-        if (b >= b_lo && b < b_hi)
-        {
-            const uint32_t at = atomicAdd(&ctr[1], 1u);
-            if (at < cap)
-            {
-                mkey[at] = k;
-                midx[at] = i;
-                atomicAdd(&hist[b - b_lo + 1u], 1u);
-            }
-        }
+        const uint32_t gb = b - p.n_reb - p.n_cblk;
+        if (gb >= p.gen.n_gen_blocks)
+            sort_role(p.gen, gb - p.gen.n_gen_blocks, reinterpret_cast<uint32_t *>(lds_dyn));
+        else
+            gen_role<IdxT, true>(p.gen, gb, p.gen.n_gen_blocks, lds_dyn);
     }
-    for (int off = 32; off > 0; off >>= 1)
-        below += (uint32_t)__shfl_xor((int)below, off);
-    if ((tid & 63u) == 0u)
-        atomicAdd(&ctr[0], below);
-    __syncthreads();
-    const uint32_t base = ctr[0], mine = ctr[1] < cap ? ctr[1] : cap; // (cap = the segment's length: never exceeded)
-    // exclusive scan of my buckets' counts (hist[b + 1] becomes bucket b's start): buckets dealt to the threads, the
-    // threads' sums scanned inside the waves by shuffles and across them through LDS
-    {
-        const uint32_t per = (nbk + nt - 1u) / nt;
-        const uint32_t b0 = tid * per;
-        uint32_t sum = 0;
-        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
-            sum += hist[b + 1u];
-        const uint32_t ln = tid & 63u, wv = tid >> 6, nwv = (nt + 63u) >> 6;
-        uint32_t incl = sum;
-        for (uint32_t d = 1; d < 64u; d <<= 1)
-        {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, (int)d);
-            if (ln >= d)
-                incl += v;
-        }
-        if (ln == 63u)
-            part[wv] = incl;
-        __syncthreads();
-        if (tid < 64u)
-        {
-            const uint32_t w = tid < nwv ? part[tid] : 0u;
-            uint32_t wi = w;
-            for (uint32_t d = 1; d < 64u; d <<= 1)
-            {
-                const uint32_t v = (uint32_t)__shfl_up((int)wi, (int)d);
-                if (tid >= d)
-                    wi += v;
-            }
-            part[tid] = wi - w; // exclusive
-        }
-        __syncthreads();
-        uint32_t run = part[wv] + incl - sum;
-        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
-        {
-            const uint32_t c = hist[b + 1u];
-            hist[b + 1u] = run;
-            run += c;
-        }
-        __syncthreads();
-    }
-    for (uint32_t i = tid; i < mine; i += nt) // scatter: hist[b + 1] is bucket b's cursor, afterwards its end
-        order[atomicAdd(&hist[bucket_of(mkey[i]) - b_lo + 1u], 1u)] = i;
-    __syncthreads();
-    for (uint32_t pos = tid; pos < mine; pos += nt)
-    {
-        const uint32_t x = order[pos], b = bucket_of(mkey[x]) - b_lo;
-        const uint32_t lo = b ? hist[b] : 0u, hi = hist[b + 1u];
-        const uint64_t kx = ((uint64_t)mkey[x] << 32) | midx[x];
-        uint32_t before = 0;
-        for (uint32_t j = lo; j < hi; j++)
-        {
-            const uint32_t y = order[j];
-            before += ((((uint64_t)mkey[y]) << 32) | midx[y]) < kx ? 1u : 0u;
-        }
-        sorted[lo + before] = start + midx[x];
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < mine; i += nt)
-        out[base + i] = sorted[i];
-    if (r == R - 1u && tid == 0u && (count & 1u))
-        out[count] = PICK_NONE; // an odd segment's last candidate walks alone
-}
-
-hipError_t launch_pair_sort(const PairArgs &args, hipStream_t stream)
-{
-    if (args.nseg == 0)
-        return hipSuccess;
-    PairArgs g = args;
-    // workgroups per segment: one per ~512 candidates, at most 8; each must be able to hold the whole segment in the
-    // worst case (every key in one range)
-    uint32_t nblk = 0, longest = 0, most_buckets = 0;
-    const uint32_t NB = 1u << g.major_bits;
-    for (uint32_t s = 0; s < g.nseg; s++)
-    {
-        if (g.seg_count[s] > PAIR_SEG_MAX)
-            return hipErrorInvalidValue; // the caller does not pair such batches
-        const uint32_t R = std::max(1u, std::min(8u, g.seg_count[s] / 512u));
-        g.blk_start[s] = nblk;
-        nblk += R;
-        longest = std::max(longest, g.seg_count[s]);
-        most_buckets = std::max(most_buckets, (NB + R - 1u) / R + 1u);
-    }
-    g.cap = longest;
-    const size_t lds = ((size_t)4 * longest + most_buckets + 1 + 64 + 2) * 4;
-    static std::once_flag raised_on[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64)
-        std::call_once(raised_on[dev], [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-        });
-    if (lds > MAX_LDS_BYTES)
-        return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pair_kernel, dim3(nblk), dim3(PAIR_THREADS), lds, stream, g);
-    return hipGetLastError();
 }
 
 // the dynamic-LDS ceiling is an attribute of the function ON A DEVICE: raised once for each device a context of this
@@ -1107,7 +1119,33 @@ static uint32_t deal_generator_blocks(GenArgs &g, uint32_t per_cu, uint32_t wave
     return nblk;
 }
 
-hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
+// the sorting workgroups behind the generator's (GenArgs::pairs != null): how many, what LDS they need, and the count of
+// generator ticks they wait for (*ticks_total: the caller's running count of generator workgroups launched so far)
+static size_t shape_sorters(GenArgs &g, uint32_t n_gen_blocks, uint32_t *ticks_total)
+{
+    g.n_gen_blocks = n_gen_blocks;
+    g.n_sort_blocks = 0;
+    if (!g.pairs || !g.keys || !g.gen_done || !ticks_total)
+    {
+        g.pairs = nullptr;
+        return 0;
+    }
+    const uint32_t NB = 1u << g.major_bits;
+    uint32_t longest = 0, most_buckets = 0;
+    for (uint32_t s = 0; s < g.nseg; s++)
+    {
+        const uint32_t R = sort_blocks_of(g.seg[s].count);
+        g.n_sort_blocks += R;
+        longest = std::max(longest, g.seg[s].count);
+        most_buckets = std::max(most_buckets, (NB + R - 1u) / R + 1u);
+    }
+    g.sort_cap = longest;
+    *ticks_total += n_gen_blocks;
+    g.gen_done_target = *ticks_total;
+    return ((size_t)4 * longest + most_buckets + 1 + 64 + 2) * 4;
+}
+
+hipError_t launch_propose(const GenArgs &args, hipStream_t stream, uint32_t *ticks_total)
 {
     if (args.nseg == 0 || args.nseg > MAX_GEN_SEGS)
         return hipErrorInvalidValue;
@@ -1122,9 +1160,16 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
     if (total == 0)
         return hipSuccess;
     g.use_lds = g.table_bytes <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
-    const size_t lds = g.use_lds ? g.table_bytes : 0;
+    size_t lds = g.use_lds ? g.table_bytes : 0;
     const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(2, lds_max / std::max<size_t>(lds, 1))) : 2u;
-    const uint32_t nblk = deal_generator_blocks(g, per_cu);
+    const uint32_t gen_blocks = deal_generator_blocks(g, per_cu);
+    {
+        const size_t slds = shape_sorters(g, gen_blocks, ticks_total);
+        if (slds > lds_max) // (cannot happen below PAIR_SEG_MAX candidates per segment)
+            return hipErrorInvalidValue;
+        lds = std::max(lds, slds);
+    }
+    const uint32_t nblk = gen_blocks + g.n_sort_blocks;
     const dim3 grid(nblk), block(GEN_THREADS);
     if (g.idx_bytes == 2)
     {
@@ -1145,7 +1190,7 @@ bool post_can_generate(const GenArgs &g)
     return g.nseg >= 1 && g.nseg <= MAX_GEN_SEGS && g.moves == nullptr && raise_generator_lds() == hipSuccess && g.table_bytes <= MAX_LDS_BYTES;
 }
 
-hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow)
+hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow, uint32_t *ticks_total)
 {
     PostArgs p = args;
     if (raise_generator_lds() != hipSuccess)
@@ -1196,7 +1241,16 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow)
         p.n_cblk = (p.commit.nitems + waves - 1) / waves;
     }
     if (p.gen.nseg)
+    {
         gen_blocks = deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(narrow ? 4 : 2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))), waves);
+        const size_t slds = shape_sorters(p.gen, gen_blocks, ticks_total);
+        if (slds > MAX_LDS_BYTES)
+            return hipErrorInvalidValue;
+        lds = std::max(lds, slds);
+        gen_blocks += p.gen.n_sort_blocks;
+    }
+    else
+        p.gen.n_gen_blocks = p.gen.n_sort_blocks = 0;
     const uint32_t nblk = p.n_reb + p.n_cblk + gen_blocks;
     if (nblk == 0)
         return hipSuccess;

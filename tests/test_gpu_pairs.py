@@ -120,3 +120,43 @@ def test_long_programs_walk_alone_and_small_batches_are_left_alone(mods):
         assert thresh.paired_walks() == walks
     plain.close()
     thresh.close()
+
+
+def test_long_programs_are_paired_without_being_asked(mods):
+    """LVBGPU_PAIR unset: the library walks two candidates per wave where it pays - device-built batches of 2048 candidates
+    and more whose programs are long (estimated from the tree's mean node depth) - and nowhere else; the order is made by
+    the last workgroups of the generator's own launch.  Same lengths as the plain walk (LVBGPU_PAIR=0) either way."""
+    api, host = mods
+    n, m = 200, 6000
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 41))
+    never, _ = _contexts(api, rows, 0)                # LVBGPU_PAIR=0 ...
+    _.close()
+    old = os.environ.pop("LVBGPU_PAIR", None)
+    try:
+        auto = api.FitchContext(text_rows=rows)       # ... and unset
+    finally:
+        if old is not None:
+            os.environ["LVBGPU_PAIR"] = old
+    tree = host.HostTree(n, seed=7)
+    assert tree.upload(never) == tree.upload(auto)
+    # a fresh random tree is shallow: short programs, nothing is paired
+    assert np.array_equal(auto.propose_score(2500, 1, 11), never.propose_score(2500, 1, 11))
+    assert auto.paired_walks() == 0
+    # mixed by accepted moves its paths get long: big batches are paired, small ones never
+    for _ in range(600):
+        e = tree.propose(1)
+        never.commit(e)
+        auto.commit(e)
+        tree.apply(e)
+    for B, kind in ((2048, 1), (4096, 2), (3000, -1)):
+        assert np.array_equal(auto.propose_score(B, kind, 13 + B), never.propose_score(B, kind, 13 + B)), B
+    assert auto.paired_walks() == 3 and never.paired_walks() == 0
+    assert np.array_equal(auto.propose_score(2047, 1, 5), never.propose_score(2047, 1, 5)) and auto.paired_walks() == 3
+    # two batches in flight, both paired
+    counts = auto.chains_submit(0, [(0, 2100, 1, 21)])
+    auto.chains_submit(1, [(0, 2100, 1, 22)])
+    a0, a1 = auto.chains_collect(0, counts)[0], auto.chains_collect(1, counts)[0]
+    assert np.array_equal(a0, never.propose_score(2100, 1, 21)) and np.array_equal(a1, never.propose_score(2100, 1, 22))
+    assert auto.paired_walks() == 5
+    never.close()
+    auto.close()
