@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievabl
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
 MOVES = {"nni": 0, "spr": 1, "tbr": 2}
 KERNEL = "lvbgpu::fitch_walk<false, false, 0>"   # <COMMIT, WIDE, HANDOVER>: the plain scoring walk
-if int(os.environ.get("LVBGPU_PAIR", "0") or 0) > 0:   # an A/B run with two candidates per wave (off by default)
+if (os.environ.get("LVBGPU_PAIR", "0") or "0").isdigit() and int(os.environ.get("LVBGPU_PAIR", "0") or 0) > 0:   # an A/B run with two candidates per wave (off by default)
     KERNEL = "lvbgpu::fitch_walk_pair<false, false>"
 WALK_TIMING_EVERY = 4   # HIP events around every 4th scoring walk of the timed region
 

@@ -122,8 +122,12 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
         ctx->lpt_order = lp[0] != '0';
     if (const char *pr = getenv("LVBGPU_PAIR"))
     {
-        ctx->pair_min = std::max(0, atoi(pr));
-        ctx->pair_auto = false; // said explicitly: from n candidates on, or (0) never
+        // n: batches of n candidates and more are walked two candidates per wave; auto: big device-built batches whose
+        // programs are long; unset / 0: never (the default: measured, the order costs what the walk gains - DESIGN.md 3)
+        if (pr[0] == 'a')
+            ctx->pair_auto = true;
+        else
+            ctx->pair_min = std::max(0, atoi(pr));
     }
     if (const char *pt = getenv("LVBGPU_PAIR_TOKENS"))
         if (atof(pt) > 0.0)
@@ -285,6 +289,7 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream)
         (void)hipStreamSynchronize(ctx->copy_stream);
+
     if (ctx->d_rows)
         (void)hipFree(ctx->d_rows);
     if (ctx->d_changes)
@@ -358,6 +363,7 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
         (void)hipEventDestroy(ctx->ev1);
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
+
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;

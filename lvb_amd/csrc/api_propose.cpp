@@ -372,13 +372,14 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     ga.len_out = (unsigned long long *)bt->d_len.p;
     // two candidates per wave (fitch_walk_pair): big launches only - a small one is a chain of latencies, not of loads -
     // and only where every segment's keys fit the sorting workgroup's LDS and preorder numbers fit 16 bits
-    // LVBGPU_PAIR=n: every batch of n candidates and more; unset: by itself (pair_auto) where it pays - big launches of
-    // long programs.  The paired walk loads the rows two programs share once, which is worth the more the longer the
-    // common way to the root is: measured 500 x 50 000 SPR, B = 4096, walk 86.5 -> 82.3 us on a fresh tree (D = 20) but
-    // 147.9 -> 133.0 us on one mixed by 3000 moves (D = 43); the order costs the generator's launch ~3 us (its last
-    // workgroups sort).  The programs' length is estimated from the trees' mean node depth (D ~ 1.45 x mean depth + 3 for
-    // SPR / TBR on these trees: tools/down_set_estimate.py's neighbour, measured), which the host has without asking the
-    // device.
+    // LVBGPU_PAIR=n: every batch of n candidates and more; LVBGPU_PAIR=auto: big launches of long programs - the paired walk
+    // loads the rows two programs share once, which is worth the more the longer the common way to the root is: measured
+    // 500 x 50 000 SPR, B = 4096, walk 88.0 -> 83.4 us on a fresh tree (D = 20), 185.8 -> 175.4 us on one mixed by 3000
+    // moves (D = 52).  The order is made by the last workgroups of the generator's own launch and costs ~9 us whether it is
+    // a kernel of its own (round 3) or not: that is the sort's own chain of passes, not a kernel boundary - so a step gains
+    // nothing at D = 20 (102.1 -> 106.3 us) and 1 us at D = 52 (200.0 -> 199.1): off unless asked for.  The programs'
+    // length is estimated from the trees' mean node depth (D ~ 1.45 x mean depth + 3 for SPR / TBR on these trees),
+    // which the host has without asking the device.
     bool pair_up = ctx->gen_idx_bytes == 2 && !moves;
     if (ctx->pair_min > 0)
         pair_up = pair_up && B >= ctx->pair_min;
@@ -976,6 +977,10 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
         ctx->post_launches_with_generator++;
     }
     ctx->post_launches++;
+    // (beside another context's walk the post launch takes twice as long - 36 -> 81 us at 32 chains in two lanes.  Tried
+    // against that and measured no better or worse: 4-wave workgroups throughout, s_setprio for its waves (both kept for
+    // the case they were made for: a big walk beside it), and a stream of the highest priority for it, ordered against the
+    // main stream by two events: 1.216 -> 1.359 s for the 32-chain run.)
     HIPCHK(ctx, launch_post(pa, ctx->stream, ctx->sharing, &ctx->gen_ticks_total));
     return LVBGPU_OK;
 }

@@ -332,7 +332,7 @@ struct lvbgpu_ctx
     int64_t commits_reusing_programs = 0;
     int64_t paired_walks = 0; // scoring walks launched two candidates per wave (lvbgpu_debug_paired_walks)
     int pair_min = 0;         // env LVBGPU_PAIR=n: batches of n candidates and more are walked two candidates per wave
-    bool pair_auto = true;    // LVBGPU_PAIR unset: device-built batches of 2048 candidates and more whose programs are long (LVBGPU_PAIR=0: never)
+    bool pair_auto = false;   // LVBGPU_PAIR=auto: device-built batches of 2048 candidates and more whose programs are long
     double pair_tokens_min = 38.0; // ... "long": estimated tokens per candidate (env LVBGPU_PAIR_TOKENS)
     DevBuf d_gen_ticks;       // the running count of generator workgroups (the sorting workgroups of a pairing launch wait for it)
     uint32_t gen_ticks_total = 0;

@@ -122,20 +122,23 @@ def test_long_programs_walk_alone_and_small_batches_are_left_alone(mods):
     thresh.close()
 
 
-def test_long_programs_are_paired_without_being_asked(mods):
-    """LVBGPU_PAIR unset: the library walks two candidates per wave where it pays - device-built batches of 2048 candidates
-    and more whose programs are long (estimated from the tree's mean node depth) - and nowhere else; the order is made by
-    the last workgroups of the generator's own launch.  Same lengths as the plain walk (LVBGPU_PAIR=0) either way."""
+def test_long_programs_are_paired_when_the_library_is_left_to_choose(mods):
+    """LVBGPU_PAIR=auto: the library walks two candidates per wave where the loads saved are many - device-built batches of
+    2048 candidates and more whose programs are long (estimated from the tree's mean node depth) - and nowhere else; the
+    order is made by the last workgroups of the generator's own launch.  Same lengths as the plain walk either way."""
     api, host = mods
     n, m = 200, 6000
     rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 41))
-    never, _ = _contexts(api, rows, 0)                # LVBGPU_PAIR=0 ...
-    _.close()
-    old = os.environ.pop("LVBGPU_PAIR", None)
+    other, never = _contexts(api, rows, 0)            # LVBGPU_PAIR=0 ...
+    other.close()
+    old = os.environ.get("LVBGPU_PAIR")
+    os.environ["LVBGPU_PAIR"] = "auto"
     try:
-        auto = api.FitchContext(text_rows=rows)       # ... and unset
+        auto = api.FitchContext(text_rows=rows)       # ... and left to the library
     finally:
-        if old is not None:
+        if old is None:
+            os.environ.pop("LVBGPU_PAIR", None)
+        else:
             os.environ["LVBGPU_PAIR"] = old
     tree = host.HostTree(n, seed=7)
     assert tree.upload(never) == tree.upload(auto)

@@ -16,10 +16,19 @@ step() { # name, seconds, command...
 for s in "$@"; do
   case $s in
     newtests) step newtests 600 python -m pytest tests/test_gpu_chains.py -x -q -m gpu -k "one_launch or oracle or decides or trajectory or runs_of or lanes" ;;
+    pairs)    step pairs 500 python -m pytest tests/test_gpu_pairs.py tests/test_gpu_device_proposals.py -x -q -m gpu ;;
+    walkab)   step walkab 300 python tools/walk_ab.py ;;
+    walkab_np) LVBGPU_PAIR=0 step walkab_np 300 python tools/walk_ab.py ;;
+    walkabm)  step walkabm 300 python tools/walk_ab.py 4096 3075 ;;
+    walkabm_np) LVBGPU_PAIR=0 step walkabm_np 300 python tools/walk_ab.py 4096 3075 ;;
+    walkabm_p) LVBGPU_PAIR=2048 step walkabm_p 300 python tools/walk_ab.py 4096 3075 ;;
+    walkab_p) LVBGPU_PAIR=2048 step walkab_p 300 python tools/walk_ab.py ;;
     chains)   step chains 400 python -m pytest tests/test_gpu_chains.py -x -q -m gpu ;;
     suite)    step suite 1000 python -m pytest tests -x -q -m gpu ;;
     probe1)   step probe1 200 python tools/chains_probe.py 1 ;;
     probe32)  step probe32 200 python tools/chains_probe.py 32 ;;
+    probe32q) step probe32q 200 python tools/chains_probe.py 32 --quiet ;;
+    probe32l3q) PROBE_LANES=3 step probe32l3q 200 python tools/chains_probe.py 32 --quiet ;;
     probe32l1) PROBE_LANES=1 step probe32l1 200 python tools/chains_probe.py 32 ;;
     probe32l3) PROBE_LANES=3 step probe32l3 200 python tools/chains_probe.py 32 ;;
     probe32l4) PROBE_LANES=4 step probe32l4 200 python tools/chains_probe.py 32 ;;
