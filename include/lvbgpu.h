@@ -310,6 +310,10 @@ int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds);
 /* test hook: keeps the context's stream busy for about `ms` milliseconds (1 .. 2000) with a kernel that only watches
  * the clock, so that what is enqueued behind it cannot complete before then */
 int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms);
+/* diagnostic (LVBGPU_POST_PROFILE set): out[0] = workgroups of the last post launch, then {role (1 table rebuild, 2 commit
+ * walk, 3 generator, 4 sort), start, -, end} of each of the first 1000 (100 MHz clock), then 8 x 8 stamps of the first
+ * rebuilding workgroups' phases: tools/post_profile.py */
+int lvbgpu_debug_post_stamps(lvbgpu_ctx *ctx, unsigned long long *out4065);
 /* test hook: counters of what results cannot show (they are the same either way): scoring walks launched two
  * candidates per wave (LVBGPU_PAIR=n when the context was created; fitch_walk_pair);
  * lvbgpu_chains_commit_edits calls that walked the SCORED programs of the last lvbgpu_chains_score_edits call

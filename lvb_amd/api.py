@@ -105,6 +105,7 @@ SIGNATURES = {
     "lvbgpu_stream": (C.c_void_p, [C.c_void_p]),
     "lvbgpu_set_wait_limit": (C.c_int, [C.c_void_p, C.c_double]),
     "lvbgpu_debug_stall": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lvbgpu_debug_post_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lvbgpu_debug_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "lvbgpu_comm_available": (C.c_int, []),
     "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),

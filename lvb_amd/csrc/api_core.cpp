@@ -315,6 +315,7 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     ctx->h_pinfo.release();
     ctx->h_topo.release();
     ctx->d_gen_prof.release();
+    ctx->d_post_prof.release();
     ctx->d_done.release();
     for (int i = 0; i < lvbgpu_ctx::PICK_SLOTS; i++)
         ctx->h_pick[i].release();

@@ -675,6 +675,18 @@ extern "C" int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvb
     return propose_core(ctx, k, draws, lengths_out, nullptr);
 }
 
+// diagnostic (LVBGPU_POST_PROFILE set): the clock stamps of the last post launch's workgroups: out[0] = their number, then
+// {role (1 rebuild, 2 commit walk, 3 generator, 4 sort), start, -, end} per workgroup (100 MHz clock), the first 1000
+extern "C" int lvbgpu_debug_post_stamps(lvbgpu_ctx *ctx, unsigned long long *out4065)
+{
+    if (!ctx || !out4065 || !ctx->d_post_prof.p)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out4065, ctx->d_post_prof.p, (1 + 4 * 1000 + 64) * 8, hipMemcpyDeviceToHost));
+    return LVBGPU_OK;
+}
+
 // diagnostic (LVBGPU_GEN_PROFILE set): the clock stamps the last generator launch left for its first 256 candidates
 extern "C" int lvbgpu_debug_generator_stamps(lvbgpu_ctx *ctx, unsigned long long *out2048)
 {
@@ -916,6 +928,9 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
         ra.nb = ctx->nb;
         ra.K = ctx->gen_kmax;
         ra.leaf_order_len = (uint32_t)ctx->n;
+        ra.table_bytes = ctx->parked.empty() ? 0u : ctx->parked[0].gen_table_bytes; // (the same for every tree of these taxa)
+        for (const ChainSlot &cs : ctx->parked)
+            ra.table_bytes = std::max(ra.table_bytes, cs.gen_table_bytes);
         ra.n_pick = (uint32_t)q.k_pick;
         ra.rebuild_picks = reb_picks ? 1u : 0u;
         pa.n_reb = (uint32_t)q.k_pick + (reb_ext ? (uint32_t)q.k_ext : 0u);
@@ -975,6 +990,14 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
             pa.reb.ready_seq = ctx->post_seq;
         }
         ctx->post_launches_with_generator++;
+    }
+    static const bool post_profile = getenv("LVBGPU_POST_PROFILE") != nullptr;
+    if (post_profile)
+    {
+        HIPCHK(ctx, ctx->d_post_prof.reserve((1 + 4 * 1000 + 64) * 8));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_post_prof.p, 0, (1 + 4 * 1000 + 64) * 8, ctx->stream));
+        pa.prof = (unsigned long long *)ctx->d_post_prof.p;
+        pa.reb.prof = pa.prof + 1 + 4 * 1000;
     }
     ctx->post_launches++;
     // (beside another context's walk the post launch takes twice as long - 36 -> 81 us at 32 chains in two lanes.  Tried

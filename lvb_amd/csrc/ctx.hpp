@@ -239,6 +239,7 @@ struct lvbgpu_ctx
     double wait_limit_s = 30.0;     // lvbgpu_set_wait_limit
     uint32_t flip_counter = 0;      // direction of this context's next big scoring launch (launch_walk)
     DevBuf d_gen_prof; // LVBGPU_GEN_PROFILE: clock stamps of the generator (diagnostic)
+    DevBuf d_post_prof; // LVBGPU_POST_PROFILE: clock stamps of the last post launch's workgroups (diagnostic)
     DevBuf d_topo4; // the generator's tables of the resident topologies, gen_table_stride each
     uint32_t gen_table_stride = 0;
     int32_t gen_kmax = 1; // ancestor tables hold 2^0 .. 2^(kmax-1): 2^kmax exceeds any depth of a tree of these taxa

@@ -193,7 +193,7 @@ struct GenSeg
     int8_t kind_all;         // 0 NNI, 1 SPR, 2 TBR; -1 / -2 / -3: see propose_kernels.hip
     uint8_t chain;           // its tables: GenArgs::tables + chain * table_stride
     uint8_t wait;            // post launch: this tree's tables are being rebuilt by the same launch - wait for GenArgs::table_ready[chain]
-    uint8_t pad_;
+    uint8_t fused;           // post launch: ... and the rebuilding workgroup draws this segment itself, from its LDS (few candidates: no generator workgroups)
 };
 static_assert(sizeof(GenSeg) == 36, "GenSeg layout");
 struct GenArgs
@@ -268,6 +268,12 @@ struct RebuildArgs
     // stores) and table_ready[chain] = ready_seq says when (null: plain stores, the next launch reads them)
     uint32_t *table_ready;
     uint32_t ready_seq;
+    uint64_t wait_mask;      // the chains a generator workgroup of this launch waits for (the others' tables leave as plain stores)
+    // the new tables are made in LDS (in the layout the generator reads) and copied out in one piece; a chain whose next
+    // draw is small is drawn by the rebuilding workgroup itself, straight from there (GenSeg::fused).  0: trees whose
+    // tables do not fit LDS beside the rebuild's own arrays - every entry is stored where it belongs as it is computed
+    uint32_t stage_tables, table_bytes;
+    unsigned long long *prof; // LVBGPU_POST_PROFILE: [8 workgroups][8] clock stamps of the rebuild's phases (else null)
 };
 // what lvbgpu_chains_commit needs on the host of every picked candidate, written straight into pinned memory
 // (gather.hpp) by wave 0 of that pick's workgroup of the post launch, before it rebuilds the chain's tables
@@ -295,6 +301,7 @@ struct PostArgs
     GatherArgs gat;   // k == 0: nothing goes to the host
     uint32_t n_reb;   // rebuild workgroups: reb.n_pick picked candidates, then n_reb - reb.n_pick moves named by the host
     uint32_t n_cblk;  // filled by launch_post
+    unsigned long long *prof; // LVBGPU_POST_PROFILE: [1 + 4 x workgroups] clock stamps of the last launch (else null): count, then {role, start, mid, end}
 };
 static_assert(sizeof(PostArgs) <= 4000, "PostArgs travels as a kernel argument");
 // can the generator ride in a post launch (its tables must fit LDS beside nothing else)?

@@ -891,7 +891,8 @@ __device__ __forceinline__ void store_tab(T *p, T v, bool through)
 }
 
 template <typename IdxT>
-__device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherArgs &ga, const uint32_t j, int32_t *const lds_i32)
+__device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherArgs &ga, const GenArgs &gen, const uint32_t j,
+                                             int32_t *const lds_i32)
 {
     const bool is_ext = j >= g.n_pick;
     const uint32_t x = j - g.n_pick; // (is_ext)
@@ -900,8 +901,8 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
         gather_one_pick(ga, j, threadIdx.x);
     if (!is_ext && !g.rebuild_picks)
         return; // (uniform for the workgroup: no barrier is skipped by some)
-    const bool through = g.table_ready != nullptr;
     const uint32_t chain = is_ext ? (uint32_t)g.ext[x].chain : g.cands[cand].flags >> CAND_CHAIN_SHIFT;
+    const bool through = g.table_ready != nullptr && ((g.wait_mask >> chain) & 1ull) != 0ull;
     IdxT *tab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(g.tables) + (size_t)chain * g.table_stride);
     const int32_t n = g.n, nb = g.nb, K = g.K;
     IdxT *t_parent = tab, *t_left = tab + nb, *t_right = tab + 2 * (size_t)nb, *t_nleaf = tab + 3 * (size_t)nb,
@@ -910,7 +911,20 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
     int32_t *left = lds_i32, *right = left + nb, *parent = right + nb, *nleaf = parent + nb, *shared = nleaf + nb; // shared[0] root
     // one step of a root-ward walk as ONE 8-byte LDS read: {parent, weight}; 8-byte aligned behind the int32 arrays
     uint2 *step = reinterpret_cast<uint2 *>(lds_i32 + ((4 * (size_t)nb + 4 + 1) & ~(size_t)1));
+    // stage_tables: the new tables are made HERE, in LDS behind the arrays above and in the generator's layout, and leave
+    // in one coalesced piece - not as 18 scattered two-byte stores per node - and a chain whose next draw is small is
+    // drawn by this workgroup itself, straight from them
+    const bool stage = g.stage_tables != 0u;
+    IdxT *const ltab = reinterpret_cast<IdxT *>(reinterpret_cast<char *>(step + nb) + ((16u - ((size_t)nb * 8u) % 16u) % 16u));
+    IdxT *l_parent = ltab, *l_left = ltab + nb, *l_right = ltab + 2 * (size_t)nb, *l_nleaf = ltab + 3 * (size_t)nb,
+         *l_depth = ltab + 4 * (size_t)nb, *l_tin = ltab + 5 * (size_t)nb, *l_first = ltab + 6 * (size_t)nb,
+         *l_order = ltab + 7 * (size_t)nb, *l_up = ltab + 7 * (size_t)nb + g.leaf_order_len;
     const int32_t tid = (int32_t)threadIdx.x, nt = (int32_t)blockDim.x;
+    auto phase = [&](uint32_t k) {
+        if (g.prof && tid == 0 && j < 8u)
+            g.prof[j * 8u + k] = wall_clock64();
+    };
+    phase(0);
     for (int32_t v = tid; v < nb; v += nt)
     {
         left[v] = (int32_t)t_left[v];
@@ -918,6 +932,7 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
         parent[v] = (int32_t)t_parent[v];
     }
     __syncthreads();
+    phase(1); // tables loaded
     // the root: given with a re-root, otherwise the one node that is its own parent (device moves never re-root)
     if (is_ext)
     {
@@ -967,6 +982,7 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
     // below is one 8-byte LDS read per level instead of a chain of four dependent ones (parent, right[parent],
     // left[parent], nleaf[that]): the kernel's time was its depth (20-31 us on the start trees of a 500-taxon run,
     // 8 us on the shallow trees at its end) and it sits on the accept path of every annealing step.
+    phase(2); // rewrites applied, parents, leaves below
     for (int32_t v = tid; v < nb; v += nt)
     {
         const int32_t p = parent[v];
@@ -976,6 +992,14 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
     // everything else is a function of the node's own path to the root: its length is the depth, the ancestors met at
     // distances 1, 2, 4, .. are the lifting table's entries (the root beyond), and the preorder number (left subtree
     // first) and the position of the first leaf below are sums along it (weight, and weight / 2: 1 / 2 = 0)
+    if (stage && tid == 0)
+        l_order[g.leaf_order_len - 1u] = (IdxT)0; // (one leaf is the root: the last place of the leaf order is never written)
+    auto put = [&](IdxT *global_at, IdxT *lds_at, size_t at, IdxT value) __attribute__((always_inline)) {
+        if (stage)
+            lds_at[at] = value;
+        else
+            store_tab(global_at + at, value, through);
+    };
     for (int32_t v = tid; v < nb; v += nt)
     {
         uint32_t tv = 0, fv = 0;
@@ -988,19 +1012,65 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
             y = (int32_t)st.x;
             d++;
             if ((d & (d - 1)) == 0 && filled < K)
-                store_tab(&t_up[(size_t)filled++ * nb + v], (IdxT)y, through); // d = 2^filled
+                put(t_up, l_up, (size_t)filled++ * nb + v, (IdxT)y); // d = 2^filled
         }
         for (; filled < K; filled++)
-            store_tab(&t_up[(size_t)filled * nb + v], (IdxT)root, through);
-        store_tab(&t_parent[v], (IdxT)parent[v], through);
-        store_tab(&t_left[v], (IdxT)(has_children(v) ? left[v] : 0), through);
-        store_tab(&t_right[v], (IdxT)(has_children(v) ? right[v] : 0), through);
-        store_tab(&t_nleaf[v], (IdxT)nleaf[v], through);
-        store_tab(&t_depth[v], (IdxT)d, through);
-        store_tab(&t_tin[v], (IdxT)tv, through);
-        store_tab(&t_first[v], (IdxT)fv, through);
+            put(t_up, l_up, (size_t)filled * nb + v, (IdxT)root);
+        put(t_parent, l_parent, (size_t)v, (IdxT)parent[v]);
+        put(t_left, l_left, (size_t)v, (IdxT)(has_children(v) ? left[v] : 0));
+        put(t_right, l_right, (size_t)v, (IdxT)(has_children(v) ? right[v] : 0));
+        put(t_nleaf, l_nleaf, (size_t)v, (IdxT)nleaf[v]);
+        put(t_depth, l_depth, (size_t)v, (IdxT)d);
+        put(t_tin, l_tin, (size_t)v, (IdxT)tv);
+        put(t_first, l_first, (size_t)v, (IdxT)fv);
         if (!has_children(v))
-            store_tab(&t_order[fv], (IdxT)v, through);
+            put(t_order, l_order, (size_t)fv, (IdxT)v);
+    }
+    if (stage)
+    {
+        __syncthreads();
+        phase(3); // root-ward walks done, tables in LDS
+        // this chain's next draw, if it is a small one: drawn here and now, from the tables in LDS - no generator
+        // workgroup has to wait for them to reach memory, fetch them again and start
+        {
+            int32_t fs = -1;
+            for (uint32_t i = 0; i < gen.nseg; i++) // (nseg == 0: no generator in this launch)
+                if (gen.seg[i].fused && gen.seg[i].chain == chain)
+                    fs = (int32_t)i;
+            if (fs >= 0)
+            {
+                const GenSeg &sg = gen.seg[fs];
+                using P = typename TabPtr<IdxT, true>::type;
+                const P lt = (P)ltab;
+                Tab<IdxT, true> t;
+                t.parent = lt;
+                t.left = lt + nb;
+                t.right = lt + 2 * (size_t)nb;
+                t.nleaf = lt + 3 * (size_t)nb;
+                t.depth = lt + 4 * (size_t)nb;
+                t.tin = lt + 5 * (size_t)nb;
+                t.first_leaf = lt + 6 * (size_t)nb;
+                t.leaf_order = lt + 7 * (size_t)nb;
+                t.up = lt + 7 * (size_t)nb + (size_t)g.leaf_order_len;
+                t.n = n;
+                t.nb = nb;
+                t.root = sg.root;
+                t.K = K;
+                const uint32_t lane = threadIdx.x & 63u;
+                const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+                for (uint32_t bl = wave; bl < sg.count; bl += nwaves)
+                    generate_one(t, gen, sg, bl, lane);
+            }
+        }
+        __syncthreads();
+        phase(4); // drawn
+        // the tables leave in one piece (eight bytes per store; written through where a generator of this launch waits)
+        const unsigned long long *src8 = reinterpret_cast<const unsigned long long *>(ltab);
+        unsigned long long *dst8 = reinterpret_cast<unsigned long long *>(tab);
+        const uint32_t n8 = g.table_bytes / 8u;
+        for (uint32_t i = (uint32_t)tid; i < n8; i += (uint32_t)nt)
+            store_tab(dst8 + i, src8[i], through);
+        phase(5); // copied out (issued)
     }
     if (through)
     {
@@ -1040,18 +1110,50 @@ __global__ __launch_bounds__(WAVES * 64u) void post_kernel(const PostArgs p)
     if constexpr (WAVES == 4)
         __builtin_amdgcn_s_setprio(3);
     const uint32_t b = blockIdx.x;
+    // LVBGPU_POST_PROFILE (tools/post_profile.py): when did each workgroup of the launch start and end, and in which role
+    const unsigned long long t_start = p.prof ? wall_clock64() : 0ull;
+    auto stamp = [&](uint32_t role) {
+        if (p.prof && threadIdx.x == 0 && b < 1000u)
+        {
+            p.prof[1u + 4u * b] = role;
+            p.prof[2u + 4u * b] = t_start;
+            p.prof[4u + 4u * b] = wall_clock64();
+            if (b == 0)
+                p.prof[0] = gridDim.x;
+        }
+    };
     if (b < p.n_reb)
     {
-        rebuild_role<IdxT>(p.reb, p.gat, b, reinterpret_cast<int32_t *>(lds_dyn));
+        rebuild_role<IdxT>(p.reb, p.gat, p.gen, b, reinterpret_cast<int32_t *>(lds_dyn));
+        __syncthreads();
+        stamp(1);
         return;
     }
     if (b < p.n_reb + p.n_cblk)
     {
+        // Which item: the commit walk of tile group g runs on the XCD whose L2 holds that tile's column slice - the one
+        // the scoring walks put it on (fitch_walk: XCD x takes the x-th eighth of the tile-major item list, so group g
+        // lies with XCD floor((2 g + 1) 4 / ngroups)).  The accepted candidate's rows were read there a moment ago, and
+        // the sets written here are read there by the next scoring walk; dealt without regard to it, a commit wave's
+        // every load went to memory (one chain: 21 us for 25 tokens) and so did the next walk's reads of the new sets.
+        // The hardware deals consecutive workgroups round-robin over the XCDs; n_cblk is a multiple of 8.
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const uint32_t item = (b - p.n_reb) * WAVES + wave;
-        if (item < p.commit.nitems)
-            walk_item<true, WIDE, 0>(p.commit, lds_dyn, lane, wave, WAVES, item);
+        const uint32_t cb = b - p.n_reb, x = b & 7u;
+        const uint32_t rank = (cb - ((x - (p.n_reb & 7u)) & 7u)) >> 3; // this workgroup's place among the commit role's on XCD x
+        const uint32_t ng = p.commit.ngroups, k = p.commit.B;
+        const uint32_t g_lo = (x * ng + 3u) >> 3, g_hi = x == 7u ? ng : ((x + 1u) * ng + 3u) >> 3;
+        const uint32_t q = rank * WAVES + wave;
+        if (q < (g_hi - g_lo) * k)
+        {
+            const uint32_t g = g_lo + q / k, c = q - (q / k) * k;
+            walk_item<true, WIDE, 0>(p.commit, lds_dyn, lane, wave, WAVES, g * k + c);
+        }
+        if (p.prof)
+        {
+            __syncthreads();
+            stamp(2);
+        }
         return;
     }
     if (p.gen.nseg)
@@ -1061,6 +1163,11 @@ __global__ __launch_bounds__(WAVES * 64u) void post_kernel(const PostArgs p)
             sort_role(p.gen, gb - p.gen.n_gen_blocks, reinterpret_cast<uint32_t *>(lds_dyn));
         else
             gen_role<IdxT, true>(p.gen, gb, p.gen.n_gen_blocks, lds_dyn);
+        if (p.prof)
+        {
+            __syncthreads();
+            stamp(gb >= p.gen.n_gen_blocks ? 4 : 3);
+        }
     }
 }
 
@@ -1113,6 +1220,8 @@ static uint32_t deal_generator_blocks(GenArgs &g, uint32_t per_cu, uint32_t wave
         const uint32_t want = (g.seg[s].count + waves - 1) / waves;
         uint32_t give = want_all <= budget ? want : (uint32_t)((uint64_t)want * budget / want_all);
         give = std::max(1u, std::min(give, std::max(want, 1u)));
+        if (g.seg[s].fused)
+            give = 0; // (drawn by its chain's rebuilding workgroup)
         g.seg[s].blk_start = nblk;
         nblk += give;
     }
@@ -1156,6 +1265,7 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream, uint32_t *tic
     {
         total += g.seg[s].count;
         g.seg[s].wait = 0;
+        g.seg[s].fused = 0;
     }
     if (total == 0)
         return hipSuccess;
@@ -1197,12 +1307,36 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow, ui
         return hipErrorInvalidValue;
     const uint32_t waves = narrow ? 4u : GEN_WAVES;
     size_t lds = 0;
+    p.reb.stage_tables = 0;
     if (p.n_reb)
     {
         lds = rebuild_lds_bytes(p.reb.nb);
         if (lds > MAX_LDS_BYTES || p.reb.n_pick > p.n_reb)
             return hipErrorInvalidValue;
+        // the new tables staged in LDS behind the rebuild's arrays (16-byte aligned), where they fit
+        const uint32_t tb = p.gen.nseg ? p.gen.table_bytes : p.reb.table_bytes;
+        if (tb && lds + 16 + tb <= MAX_LDS_BYTES && (p.reb.rebuild_picks || p.n_reb > p.reb.n_pick))
+        {
+            p.reb.stage_tables = 1;
+            p.reb.table_bytes = tb;
+            lds += 16 + tb;
+        }
     }
+    // a chain that is rebuilt here and draws few candidates next is drawn by its rebuilding workgroup (not with pairing:
+    // the sorting workgroups count generator workgroups' ticks)
+    for (uint32_t s = 0; s < p.gen.nseg; s++)
+    {
+        p.gen.seg[s].fused = 0;
+        if (p.reb.stage_tables && p.gen.seg[s].wait && !p.gen.pairs && !p.gen.prof && p.gen.seg[s].count <= 4u * waves)
+        {
+            p.gen.seg[s].fused = 1;
+            p.gen.seg[s].wait = 0;
+        }
+    }
+    p.reb.wait_mask = 0;
+    for (uint32_t s = 0; s < p.gen.nseg; s++)
+        if (p.gen.seg[s].wait)
+            p.reb.wait_mask |= 1ull << p.gen.seg[s].chain;
     uint32_t gen_total = 0, gen_blocks = 0;
     if (p.gen.nseg)
     {
@@ -1238,7 +1372,17 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow, ui
         p.commit.flip = 0;
         p.commit.watcher = 0;
         lds = std::max(lds, clds);
-        p.n_cblk = (p.commit.nitems + waves - 1) / waves;
+        // (every XCD walks the tile groups whose column slices its L2 holds: as many workgroups per XCD as the fullest needs)
+        {
+            const uint32_t ng = p.commit.ngroups, k = p.commit.B;
+            uint32_t most = 0;
+            for (uint32_t x = 0; x < 8u; x++)
+            {
+                const uint32_t g_lo = (x * ng + 3u) >> 3, g_hi = x == 7u ? ng : ((x + 1u) * ng + 3u) >> 3;
+                most = std::max(most, (g_hi - g_lo) * k);
+            }
+            p.n_cblk = 8u * ((most + waves - 1) / waves);
+        }
     }
     if (p.gen.nseg)
     {
