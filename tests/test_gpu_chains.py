@@ -644,20 +644,25 @@ def test_random_operations_over_chains_against_the_cpu_oracle(mods, monkeypatch,
     ctx.close()
 
 
-def test_commits_reroots_and_the_next_generator_in_one_launch(mods):
+@pytest.mark.parametrize("n,m,sharing", [(48, 4000, False), (48, 4000, True), (1500, 260, False), (1500, 260, True)])
+def test_commits_reroots_and_the_next_generator_in_one_launch(mods, n, m, sharing):
     """What lies between two scoring walks of an annealing step - the commit walk of the chains' accepted candidates (their
     own device-built programs), the re-roots of other chains (host-built programs), the table rebuilds of both and the NEXT
     step's generator, whose segments wait for their chains' rebuilds - goes out as ONE post launch when the steps take
     turns in the two batch slots.  Same lengths, picks, trees, per-node changes and node sets as a context that is made to
     catch up after every single call (its commits, re-roots and generators are launches of their own), and as the CPU
-    oracle's full evaluation of the final trees."""
+    oracle's full evaluation of the final trees.  sharing: the launch in its narrow form (4-wave workgroups: what a context
+    uses beside other contexts' walks, lvbgpu_set_sharing); 1500 taxa: trees whose new tables do not fit LDS beside the
+    rebuild's own arrays (every entry stored where it belongs, no draw by the rebuilding workgroup)."""
     from oracle import binding as ob
     from tests import helpers
     api, host = mods
-    n, m, R = 48, 4000, 6
+    R = 6 if n < 100 else 3
     rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 77))
     enc = ob.encode_rows(rows)
     one, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
+    if sharing:
+        one._chk(one.lib.lvbgpu_set_sharing(one.h, 1))
     cur = []
     for c_ in (one, ref):
         c_.set_chains(R)
@@ -673,10 +678,13 @@ def test_commits_reroots_and_the_next_generator_in_one_launch(mods):
         roots.append(one.topology()[3])
     rng = np.random.default_rng(8)
     both = rerooted = 0
-    for step in range(60):
+    nsteps = 60 if n < 100 else 24
+    for step in range(nsteps):
         slot = step & 1
         active = sorted(rng.choice(R, size=int(rng.integers(2, R + 1)), replace=False).tolist())
-        draws = [(c, int(rng.integers(1, 70)), [1, 2, -1, 0][(step + c) % 4], 9000 * step + c) for c in active]
+        # (now and then a draw too large for the rebuilding workgroup to make itself: its generator workgroups wait)
+        draws = [(c, int(rng.integers(1, 70)) if (step + c) % 5 else int(rng.integers(100, 300)), [1, 2, -1, 0][(step + c) % 4],
+                  9000 * step + c) for c in active]
         rules = [(cur[c], [1e-9, 2e-5, 4e-4, 5e-2][(step + c) % 4], float(min_len), 31 * step + c) for c in active]
         lens, picks = one.chains_step(draws, rules, slot=slot)
         ref.synchronize()
@@ -702,8 +710,8 @@ def test_commits_reroots_and_the_next_generator_in_one_launch(mods):
             ref.synchronize()
     posts, with_generator = one.post_launches()
     rposts, rwith = ref.post_launches()
-    assert with_generator > 30 and rwith == 0, (posts, with_generator, rposts, rwith)
-    assert posts < rposts and rerooted > 10 and both > 0
+    assert with_generator > nsteps // 2 and rwith == 0, (posts, with_generator, rposts, rwith)
+    assert posts < rposts and rerooted > nsteps // 6 and (both > 0 or n > 100)
     for c in range(R):
         for c_ in (one, ref):
             c_.select_chain(c)
