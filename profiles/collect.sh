@@ -10,6 +10,8 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 ARGS="--steps 40 --warmup 5 --headline-only $*"
+# what the counters are measured on: a hash of the scoring walk's sources (bench.py prints `stale` when they have moved)
+( cd "$REPO" && python3 -c "import bench; print(bench.kernel_source_sha())" ) > "$OUT/kernel_sha.txt"
 # pass 1: kernel trace + stats (durations)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"

@@ -88,9 +88,11 @@ def main(tag: str, mixed: bool = False, extra=()) -> None:
         if isinstance(entries, dict):
             entries = [entries]
         key = dict(workload_of(extra), mixed_walk=mixed)
+        sha_file = src / "kernel_sha.txt"   # (profiles/collect.sh: the walk's sources at collection)
+        sha = sha_file.read_text().strip() if sha_file.exists() else None
         entries = [e for e in entries if any(e.get(k, False if k == "mixed_walk" else None) != v for k, v in key.items())]
         entries.append(dict(key, hbm_bytes_per_launch=derived["hbm_read_bytes_per_launch_corrected"] + derived.get(
-            "hbm_write_bytes_per_launch", 0.0), source=f"profiles/{tag}_pmc_summary.json"))
+            "hbm_write_bytes_per_launch", 0.0), source=f"profiles/{tag}_pmc_summary.json", kernel_sha=sha))
         tf.write_text(json.dumps(entries, indent=1) + "\n")
     print(json.dumps(derived, indent=1))
 
