@@ -89,6 +89,7 @@ def parse_args(argv=None):
                          "StartingTemperature.c; DESIGN.md 7c); the default base gives 32 chains without such a straggler, as round "
                          "2's did (tools/anneal_seed_scan.py), so that `scored_per_s` - measured until ALL chains have frozen - says "
                          "something about the scorer.  `scored_per_s_busy` does so for any seed")
+    ap.add_argument("--anneal-second-seed", type=int, default=4, help="a second seed base for the annealing leg (-1: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the B = 256 / 1024 / 16 384 and uniform-alignment legs")
     ap.add_argument("--single-chain-levels", type=int, default=3,
@@ -889,9 +890,9 @@ def rank_main(args) -> None:
         # second half of the metric: best length vs wall clock, whole host loop included (starting temperature,
         # neighbours drawn + scored + committed on the GPU, accept / cool on the host) - not part of `value`.
         # R independent chains are stepped together on this GPU: a device step serves all of them.
-        def params_for(c):
+        def params_for(c, seed_base=None):
             p = host.anneal_defaults()
-            p.seed = args.anneal_seed * 7919 + 1000 * rank + c + 1
+            p.seed = (args.anneal_seed if seed_base is None else seed_base) * 7919 + 1000 * rank + c + 1
             p.algorithm = {"nni": 10, "spr": 11, "tbr": 12}[args.move]
             p.batch = args.anneal_batch
             p.t0 = 0.0   # estimated as StartingTemperature() does (65 % of uphill moves accepted)
@@ -923,9 +924,26 @@ def rank_main(args) -> None:
                 "device_fraction": round(res[0]["seconds_device"] / secs, 3), "batch": args.anneal_batch,
                 "temperatures": [r["temperatures"] for r in res], "frozen": sum(r["frozen"] for r in res),
                 "best_length_vs_wallclock": [[round(t, 3), b] for t, b in keep],
-                "what": f"{R} independent chains (own seeds and start trees) stepped together in one context: one generator "
-                        "launch, one walk and one commit walk per device step for all of them; starting temperatures included",
+                # THE annealing rate: candidates scored per second while at least half the chains were at it (a rate taken
+                # until the last chain has frozen says how long that chain took)
+                "rate": round(res[0]["scored_busy"] / max(res[0]["seconds_busy"], 1e-9)), "rate_unit": "trees/s",
+                "what": f"{R} independent chains (own seeds and start trees) dealt to lanes (contexts of their own, two from 16 "
+                        "chains on) that one host thread serves in turn; a lane's chains are stepped together: one post launch "
+                        "(commit walk, table rebuilds, the next generator) and one scoring walk per step for all of them; "
+                        "starting temperatures included",
             }
+            # ... and on another seed base (the default one was chosen so that no chain is a straggler: bench.py --anneal-seed)
+            if args.anneal_second_seed >= 0:
+                strees = [host.HostTree(args.taxa, seed=ranks.restart_seed(args.anneal_second_seed) * 100 + c) for c in range(R)]
+                res2, log2 = host.anneal_chains(actx, strees, [params_for(c, args.anneal_second_seed) for c in range(R)])
+                secs2 = max(r["seconds"] for r in res2)
+                out["anneal"]["second_seed"] = {
+                    "seed": args.anneal_second_seed, "seconds": round(secs2, 3), "best_length": min(r["best_length"] for r in res2),
+                    "scored_per_s": round(sum(r["scored"] for r in res2) / secs2), "seconds_busy": round(res2[0]["seconds_busy"], 3),
+                    "rate": round(res2[0]["scored_busy"] / max(res2[0]["seconds_busy"], 1e-9)),
+                    "frozen": sum(r["frozen"] for r in res2), "seconds_done_max": round(max(r["seconds_done"] for r in res2), 3)}
+                for t in strees:
+                    t.close()
             # one chain alone, for comparison: the same loop with R = 1
             # (seeded as in rounds 1 and 2 - from --seed, not --anneal-seed; with --single-chain-levels 0 it is the same chain
             # as in their lines, with runs of accepted moves - the default - the hot phase draws by the host's law)
