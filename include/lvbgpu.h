@@ -197,7 +197,11 @@ int lvbgpu_chains_collect(lvbgpu_ctx *ctx, int32_t slot, int64_t *lengths_out);
  * lvbgpu_propose_score* call) for each listed chain, at most one per chain: the candidates' own device-built
  * programs are walked in commit form (one launch for all picks), and the chains' topologies follow (the moves'
  * rewrites are fetched from the device).  Asynchronous like lvbgpu_commit(.., NULL): the lengths are known
- * from scoring.  A pick of a candidate that overflowed (INT64_MAX) is LVBGPU_E_ARG. */
+ * from scoring.  A pick of a candidate that overflowed (INT64_MAX) is LVBGPU_E_ARG.
+ * COLLECTED, not launched: what this call, lvbgpu_chains_reroot and lvbgpu_chains_commit_edits ask for goes to the device
+ * as ONE launch (commit walk + rebuild of the chains' generator tables + the moves' records to the host) with the NEXT
+ * call on the context - with a submit into the OTHER batch slot that batch's generator rides in the same launch (take the
+ * two slots in turn); every other call lets the device catch up first, so no call ever sees a tree half moved. */
 typedef struct
 {
     int32_t chain, b;
@@ -235,12 +239,8 @@ int lvbgpu_chains_picked_edits(lvbgpu_ctx *ctx, int32_t j, lvbgpu_edit *edits, i
  * candidate j of the draw (in order) is taken if its length is <= cur_length, or with probability
  * exp(-deltah / temperature), deltah = min_len_tree / cur_length - min_len_tree / length capped at 1, and never once
  * -deltah < temperature * log(1e-11); its uniform draw is a function of (accept_seed, j).  The chain's pick is the FIRST
- * taken candidate; it is committed at once (lvbgpu_chains_commit's work).  By default the library decides at the collect
- * (lvb_amd/csrc/decide.h); with LVBGPU_DEVICE_DECIDE=1, where the batch allows it, the DEVICE decides - the scoring
- * walk's watcher waves apply the same function the moment a length is complete - and commit walk, table rebuild and the
- * moves' way to the host are enqueued WITH the batch, so that no host round trip lies between a step's scoring and its
- * commit (same picks, same trajectories; on MI355X / ROCm 7.2 the extra launch and event calls cost more than the
- * round trip they save).
+ * taken candidate; the library decides at the collect (lvb_amd/csrc/decide.h: one function for the library and the scorer's
+ * test double) and commits the picks (lvbgpu_chains_commit's work).
  * lvbgpu_chains_step_collect hands over the lengths (as lvbgpu_chains_collect) and picks_out[i] = index of the accepted
  * candidate within draw i, or -1; lvbgpu_chains_step_edits(i) = the accepted move's rewrites (waits for them if they are
  * still on their way).  A slot holds one step at a time; a step and plain batches may not be in flight together. */
