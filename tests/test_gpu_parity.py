@@ -290,3 +290,23 @@ def test_wide_offsets_and_copy_path_steps_match_reference(api):
                         "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+def test_two_candidates_per_wave_match_reference(api):
+    """LVBGPU_PAIR=1 for a whole child process: every scoring batch - host-built, device-built, of several chains - is walked
+    two candidates per wave (fitch_walk_pair; the device-built ones in the order the last workgroups of the generator's own
+    launch make).  The parity cases against the compiled reference, the golden vectors and the device-proposal suite (every
+    drawn move replayed on the host generators, every device-built program scored against the host-built one) run once more
+    that way (the paired walk is optional, so the default runs never exercise it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LVBGPU_PAIR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_device_proposals.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "not wide_offsets and not two_candidates_per_wave", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout, r.stdout[-500:]
+
