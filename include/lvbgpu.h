@@ -103,10 +103,6 @@ int lvbgpu_create_from_text(lvbgpu_ctx **out, int device, long n, long m, const 
 /* a second context on the same alignment and device (the leaf rows are copied on the device; one tree slot, no tree):
  * own stream, own batches - what two groups of chains need whose device work is to overlap (lvbhost_anneal_chains) */
 int lvbgpu_fork(lvbgpu_ctx *src, lvbgpu_ctx **out);
-/* shared != 0: other contexts' kernels run on the device beside this one's (lanes).  The post launch - commit walk,
- * table rebuilds, generator between two scoring walks - then goes out as 4-wave workgroups with little LDS, which find
- * room on CUs that another context's scoring walk keeps full; alone on the device the 16-wave form is the faster one */
-int lvbgpu_set_sharing(lvbgpu_ctx *ctx, int32_t shared);
 void lvbgpu_destroy(lvbgpu_ctx *ctx);
 long lvbgpu_n(const lvbgpu_ctx *ctx);
 long lvbgpu_nwords(const lvbgpu_ctx *ctx);

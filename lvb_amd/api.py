@@ -90,7 +90,6 @@ SIGNATURES = {
     "lvbgpu_chains_step_collect": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i32p]),
     "lvbgpu_chains_ready": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_fork": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
-    "lvbgpu_set_sharing": (C.c_int, [C.c_void_p, C.c_int32]),
     "lvbgpu_chains_step_edits": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_proposal_stats": (C.c_int, [C.c_void_p, C.POINTER(BatchStats)]),
     "lvbgpu_score_full_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_void_p, _i64p]),

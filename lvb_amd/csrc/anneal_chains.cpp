@@ -716,8 +716,6 @@ struct LaneGuard // the forked contexts go with the run, whichever way it ends
         for (Lane &l : lanes)
             if (l.forked && l.ctx)
                 lvbgpu_destroy(l.ctx);
-            else if (l.ctx)
-                (void)lvbgpu_set_sharing(l.ctx, 0);
     }
 };
 
@@ -1007,16 +1005,6 @@ int anneal_chains_run(lvbgpu_ctx *ctx, int32_t R, lvbhost_tree *const *trees, co
             L.picks.resize(L.draws.size());
             auto td = Clock::now();
             L.slot ^= 1;
-            if (nl > 1)
-            {
-                // the post launch goes out narrow when another lane has a big walk on the device: a 16-wave workgroup
-                // finds no room beside it; beside small walks (the hot phase) the 16-wave form is the faster one
-                size_t beside = 0;
-                for (const Lane &o : lanes)
-                    if (&o != &L && o.active)
-                        beside += o.total;
-                (void)lvbgpu_set_sharing(L.ctx, beside >= 2048 ? 1 : 0);
-            }
             r = lvbgpu_chains_step_submit(L.ctx, L.slot, (int32_t)L.draws.size(), L.draws.data(), L.rules.data());
             dev_seconds += since(td);
             t_score += since(td);

@@ -959,14 +959,6 @@ extern "C" int lvbgpu_synchronize(lvbgpu_ctx *ctx)
 
 extern "C" void *lvbgpu_stream(lvbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-extern "C" int lvbgpu_set_sharing(lvbgpu_ctx *ctx, int32_t shared)
-{
-    if (!ctx)
-        return LVBGPU_E_ARG;
-    ctx->sharing = shared != 0;
-    return LVBGPU_OK;
-}
-
 extern "C" int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds)
 {
     if (!ctx || !(seconds > 0.0))

@@ -1000,11 +1000,11 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
         pa.reb.prof = pa.prof + 1 + 4 * 1000;
     }
     ctx->post_launches++;
-    // (beside another context's walk the post launch takes twice as long - 36 -> 81 us at 32 chains in two lanes.  Tried
-    // against that and measured no better or worse: 4-wave workgroups throughout, s_setprio for its waves (both kept for
-    // the case they were made for: a big walk beside it), and a stream of the highest priority for it, ordered against the
-    // main stream by two events: 1.216 -> 1.359 s for the 32-chain run.)
-    HIPCHK(ctx, launch_post(pa, ctx->stream, ctx->sharing, &ctx->gen_ticks_total));
+    // (beside another context's walk - lanes - the post launch takes twice as long: 36 -> 81-86 us at 32 chains in two
+    // lanes.  Tried against that and not kept: 4-wave workgroups that fit wherever a walk workgroup retires, s_setprio for
+    // its waves (together 1.3 % of the 32-chain run), a stream of the highest priority ordered against the main stream by
+    // two events (1.216 -> 1.359 s).  profiles/experiments/r04_post_launch_and_lanes.md)
+    HIPCHK(ctx, launch_post(pa, ctx->stream, &ctx->gen_ticks_total));
     return LVBGPU_OK;
 }
 

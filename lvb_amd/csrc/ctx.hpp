@@ -308,7 +308,6 @@ struct lvbgpu_ctx
         uint64_t chains = 0; // every chain above, as a mask: one move per chain and launch
         bool any() const { return k_pick > 0 || k_ext > 0; }
     } pend;
-    bool sharing = false; // lvbgpu_set_sharing: other contexts' kernels run beside this one's (the post launch goes out narrow)
     DevBuf d_table_ready; // uint32[MAX_CHAINS]: = post_seq once a post launch has rebuilt that chain's tables
     uint32_t post_seq = 0;
     int64_t post_launches = 0, post_launches_with_generator = 0; // (lvbgpu_debug_count)

@@ -306,8 +306,7 @@ struct PostArgs
 static_assert(sizeof(PostArgs) <= 4000, "PostArgs travels as a kernel argument");
 // can the generator ride in a post launch (its tables must fit LDS beside nothing else)?
 bool post_can_generate(const GenArgs &g);
-// narrow: 4-wave workgroups with little LDS, which find room beside another queue's scoring walk (lvbgpu_set_sharing)
-hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow = false, uint32_t *ticks_total = nullptr);
+hipError_t launch_post(const PostArgs &args, hipStream_t stream, uint32_t *ticks_total = nullptr);
 // fills what a walk's launcher owes the kernel (tiles per group, the division constant, and for a commit walk the burst
 // slots that fit `lds_budget` bytes per workgroup of `nwaves` waves beside the operand stacks); *lds_out = dynamic LDS
 hipError_t shape_walk(WalkArgs &a, bool commit, uint32_t nwaves, size_t lds_budget, size_t *lds_out);

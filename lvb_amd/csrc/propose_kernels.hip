@@ -601,7 +601,7 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
     const char *tables = reinterpret_cast<const char *>(g.tables) + (size_t)sg.chain * g.table_stride;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6; // (16 waves; 4 in the narrow post launch)
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;
     using P = typename TabPtr<IdxT, IN_LDS>::type;
     P tab;
     if constexpr (IN_LDS)
@@ -1097,18 +1097,15 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
 // walk, its rebuild, generator): every kernel boundary costs 8-9 us whatever the kernel does, a cross-stream hand-over
 // 2-5 us, and on the accept path the host's launch calls are what the device waits for.
 static_assert(GEN_THREADS == REBUILD_THREADS, "one workgroup size for every role of the post launch");
-// WAVES per workgroup: 16, or 4 - the NARROW form for a context that shares the device (lvbgpu_set_sharing: lanes).  A
-// 1024-thread workgroup with 100+ KB of LDS finds no CU to run on while another queue's scoring walk keeps all of them
-// full of 4-wave workgroups: measured with two lanes, a post launch that started beside the other lane's walk took 86 us
-// instead of 36.  A 4-wave workgroup with 38 KB takes the place of any walk workgroup that retires.
-template <typename IdxT, bool WIDE, uint32_t WAVES>
-__global__ __launch_bounds__(WAVES * 64u) void post_kernel(const PostArgs p)
+// (A NARROW form - 4-wave workgroups with 38 KB of LDS, for a context whose post launch runs beside another context's
+// scoring walk, where a 16-wave workgroup with 100+ KB finds no CU to run on - was built and measured in round 4: a post
+// launch that started beside the other lane's walk took 81 us instead of 86, alone 53 instead of 36; the 32-chain run with
+// it 1.225 s against 1.241 s without, three runs each.  Not kept: profiles/experiments/r04_post_launch_and_lanes.md.)
+template <typename IdxT, bool WIDE>
+__global__ __launch_bounds__(GEN_THREADS) void post_kernel(const PostArgs p)
 {
+    constexpr uint32_t WAVES = GEN_WAVES;
     extern __shared__ uint4 lds_dyn[];
-    // (what this launch does is a chain of latencies that the next scoring walk waits for; beside another context's walk
-    // - eight waves per SIMD that keep the memory path full - its few waves should at least be issued first)
-    if constexpr (WAVES == 4)
-        __builtin_amdgcn_s_setprio(3);
     const uint32_t b = blockIdx.x;
     // LVBGPU_POST_PROFILE (tools/post_profile.py): when did each workgroup of the launch start and end, and in which role
     const unsigned long long t_start = p.prof ? wall_clock64() : 0ull;
@@ -1185,14 +1182,10 @@ static hipError_t raise_generator_lds()
         hipError_t e = hipSuccess;
         for (const void *f : {reinterpret_cast<const void *>(&propose_kernel<uint16_t, true>),
                               reinterpret_cast<const void *>(&propose_kernel<int32_t, true>),
-                              reinterpret_cast<const void *>(&post_kernel<uint16_t, false, 16>),
-                              reinterpret_cast<const void *>(&post_kernel<uint16_t, true, 16>),
-                              reinterpret_cast<const void *>(&post_kernel<int32_t, false, 16>),
-                              reinterpret_cast<const void *>(&post_kernel<int32_t, true, 16>),
-                              reinterpret_cast<const void *>(&post_kernel<uint16_t, false, 4>),
-                              reinterpret_cast<const void *>(&post_kernel<uint16_t, true, 4>),
-                              reinterpret_cast<const void *>(&post_kernel<int32_t, false, 4>),
-                              reinterpret_cast<const void *>(&post_kernel<int32_t, true, 4>)})
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, false>),
+                              reinterpret_cast<const void *>(&post_kernel<uint16_t, true>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, false>),
+                              reinterpret_cast<const void *>(&post_kernel<int32_t, true>)})
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         raised_on[dev] = e;
@@ -1300,12 +1293,12 @@ bool post_can_generate(const GenArgs &g)
     return g.nseg >= 1 && g.nseg <= MAX_GEN_SEGS && g.moves == nullptr && raise_generator_lds() == hipSuccess && g.table_bytes <= MAX_LDS_BYTES;
 }
 
-hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow, uint32_t *ticks_total)
+hipError_t launch_post(const PostArgs &args, hipStream_t stream, uint32_t *ticks_total)
 {
     PostArgs p = args;
     if (raise_generator_lds() != hipSuccess)
         return hipErrorInvalidValue;
-    const uint32_t waves = narrow ? 4u : GEN_WAVES;
+    const uint32_t waves = GEN_WAVES;
     size_t lds = 0;
     p.reb.stage_tables = 0;
     if (p.n_reb)
@@ -1354,18 +1347,15 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow, ui
     }
     // the commit walk's parked sets take what LDS is left - all of it while the generator's workgroups are few (one per
     // CU is plenty then), half of it when they are many (cold chains drawing a thousand candidates each: two generator
-    // workgroups per CU matter more than the commit walk's bursts); the narrow form takes no more than the other roles
-    // need anyway, at least 8 slots' worth: its workgroups are to fit beside another queue's walk
+    // workgroups per CU matter more than the commit walk's bursts)
     p.n_cblk = 0;
     if (p.commit.nitems)
     {
         const bool many = (gen_total + waves - 1) / waves > 256u;
-        size_t budget = many ? MAX_LDS_BYTES / 2 : MAX_LDS_BYTES;
-        if (narrow)
-            budget = std::max(lds, (size_t)waves * (p.commit.stack_depth * 1024u + 8u * 1088u));
+        const size_t budget = many ? MAX_LDS_BYTES / 2 : MAX_LDS_BYTES;
         size_t clds = 0;
         hipError_t e = shape_walk(p.commit, true, waves, budget, &clds);
-        if (e != hipSuccess && (many || narrow))
+        if (e != hipSuccess && many)
             e = shape_walk(p.commit, true, waves, MAX_LDS_BYTES, &clds);
         if (e != hipSuccess)
             return e;
@@ -1386,7 +1376,7 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow, ui
     }
     if (p.gen.nseg)
     {
-        gen_blocks = deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(narrow ? 4 : 2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))), waves);
+        gen_blocks = deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))), waves);
         const size_t slds = shape_sorters(p.gen, gen_blocks, ticks_total);
         if (slds > MAX_LDS_BYTES)
             return hipErrorInvalidValue;
@@ -1401,26 +1391,17 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, bool narrow, ui
     const bool wide = p.commit.nitems != 0 && walk_needs_wide(p.commit);
     const dim3 grid(nblk), block(waves * 64u);
     const bool idx16 = (p.gen.nseg ? p.gen.idx_bytes : p.reb.idx_bytes) != 4;
-#define LVB_POST(I, W)                                                                                                 \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        if (narrow)                                                                                                    \
-            hipLaunchKernelGGL((post_kernel<I, W, 4>), grid, block, lds, stream, p);                                   \
-        else                                                                                                           \
-            hipLaunchKernelGGL((post_kernel<I, W, 16>), grid, block, lds, stream, p);                                  \
-    } while (0)
     if (idx16)
     {
         if (wide)
-            LVB_POST(uint16_t, true);
+            hipLaunchKernelGGL((post_kernel<uint16_t, true>), grid, block, lds, stream, p);
         else
-            LVB_POST(uint16_t, false);
+            hipLaunchKernelGGL((post_kernel<uint16_t, false>), grid, block, lds, stream, p);
     }
     else if (wide)
-        LVB_POST(int32_t, true);
+        hipLaunchKernelGGL((post_kernel<int32_t, true>), grid, block, lds, stream, p);
     else
-        LVB_POST(int32_t, false);
-#undef LVB_POST
+        hipLaunchKernelGGL((post_kernel<int32_t, false>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

@@ -808,7 +808,6 @@ int lvbgpu_fork(lvbgpu_ctx *src, lvbgpu_ctx **out)
 }
 
 void lvbgpu_destroy(lvbgpu_ctx *c) { lvbgpu_double_free(c); }
-int lvbgpu_set_sharing(lvbgpu_ctx *c, int32_t shared) { (void)shared; return c ? LVBGPU_OK : LVBGPU_E_ARG; }
 
 /* everything is computed at the submit: a submitted batch is always ready */
 int lvbgpu_chains_ready(lvbgpu_ctx *c, int32_t s, int32_t *ready)

@@ -644,15 +644,14 @@ def test_random_operations_over_chains_against_the_cpu_oracle(mods, monkeypatch,
     ctx.close()
 
 
-@pytest.mark.parametrize("n,m,sharing", [(48, 4000, False), (48, 4000, True), (1500, 260, False), (1500, 260, True)])
-def test_commits_reroots_and_the_next_generator_in_one_launch(mods, n, m, sharing):
+@pytest.mark.parametrize("n,m", [(48, 4000), (1500, 260)])
+def test_commits_reroots_and_the_next_generator_in_one_launch(mods, n, m):
     """What lies between two scoring walks of an annealing step - the commit walk of the chains' accepted candidates (their
     own device-built programs), the re-roots of other chains (host-built programs), the table rebuilds of both and the NEXT
     step's generator, whose segments wait for their chains' rebuilds - goes out as ONE post launch when the steps take
     turns in the two batch slots.  Same lengths, picks, trees, per-node changes and node sets as a context that is made to
     catch up after every single call (its commits, re-roots and generators are launches of their own), and as the CPU
-    oracle's full evaluation of the final trees.  sharing: the launch in its narrow form (4-wave workgroups: what a context
-    uses beside other contexts' walks, lvbgpu_set_sharing); 1500 taxa: trees whose new tables do not fit LDS beside the
+    oracle's full evaluation of the final trees.  1500 taxa: trees whose new tables do not fit LDS beside the
     rebuild's own arrays (every entry stored where it belongs, no draw by the rebuilding workgroup)."""
     from oracle import binding as ob
     from tests import helpers
@@ -661,8 +660,6 @@ def test_commits_reroots_and_the_next_generator_in_one_launch(mods, n, m, sharin
     rows, min_len = host.prepare_alignment(synth.treelike_rows(n, m, 77))
     enc = ob.encode_rows(rows)
     one, ref = api.FitchContext(text_rows=rows), api.FitchContext(text_rows=rows)
-    if sharing:
-        one._chk(one.lib.lvbgpu_set_sharing(one.h, 1))
     cur = []
     for c_ in (one, ref):
         c_.set_chains(R)
