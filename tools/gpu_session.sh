@@ -37,6 +37,12 @@ for s in "$@"; do
     probe32f8) LVBHOST_SPEC_FACTOR=8 step probe32f8 200 python tools/chains_probe.py 32 --quiet ;;
     probe1f6) LVBHOST_SPEC_FACTOR=6 step probe1f6 200 python tools/chains_probe.py 1 --quiet ;;
     probe1r)  PROBE_RUN_LEVELS=3 step probe1r 200 python tools/chains_probe.py 1 ;;
+    proposals) step proposals 700 python -m pytest tests/test_gpu_device_proposals.py tests/test_gpu_chains.py tests/test_gpu_pairs.py -x -q -m gpu ;;
+    walkab_nl) LVBGPU_LPT=0 step walkab_nl 300 python tools/walk_ab.py ;;
+    walkabm_nl) LVBGPU_LPT=0 step walkabm_nl 300 python tools/walk_ab.py 4096 3075 ;;
+    walkab1k) step walkab1k 300 python tools/walk_ab.py 1024 3075 ;;
+    walkab1k_nl) LVBGPU_LPT=0 step walkab1k_nl 300 python tools/walk_ab.py 1024 3075 ;;
+    probe32q_nl) LVBGPU_LPT=0 step probe32q_nl 200 python tools/chains_probe.py 32 --quiet ;;
     anyorder) step anyorder 60 ./tools/anyorder_probe.bin ;;
     bench)    step bench 600 python bench.py ;;
     benchq)   step benchq 300 python bench.py --no-shapes --no-configs --no-cpu-baseline ;;
