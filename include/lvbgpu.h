@@ -310,6 +310,9 @@ int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms);
  * walk, 3 generator, 4 sort), start, -, end} of each of the first 1000 (100 MHz clock), then 8 x 8 stamps of the first
  * rebuilding workgroups' phases: tools/post_profile.py */
 int lvbgpu_debug_post_stamps(lvbgpu_ctx *ctx, unsigned long long *out4065);
+/* diagnostic: who walked with whom in the last device-built batch of `slot` (LVBGPU_PAIR): out[2 p], out[2 p + 1] = the
+ * candidates of pair p (0xFFFFFFFF: walked alone); *npairs = 0: that batch was walked one candidate per wave */
+int lvbgpu_debug_pairs(lvbgpu_ctx *ctx, int32_t slot, uint32_t *out, int32_t cap_pairs, int32_t *npairs);
 /* test hook: counters of what results cannot show (they are the same either way): scoring walks launched two
  * candidates per wave (LVBGPU_PAIR=n when the context was created; fitch_walk_pair);
  * lvbgpu_chains_commit_edits calls that walked the SCORED programs of the last lvbgpu_chains_score_edits call

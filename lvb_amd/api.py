@@ -105,6 +105,7 @@ SIGNATURES = {
     "lvbgpu_set_wait_limit": (C.c_int, [C.c_void_p, C.c_double]),
     "lvbgpu_debug_stall": (C.c_int, [C.c_void_p, C.c_int32]),
     "lvbgpu_debug_post_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lvbgpu_debug_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lvbgpu_debug_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "lvbgpu_comm_available": (C.c_int, []),
     "lvbgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -250,6 +251,15 @@ class FitchContext:
         """(post launches so far - the chains' commits and re-roots, all pending ones in one launch -, those of them that
         carried the next batch's generator)."""
         return self.debug_count(2), self.debug_count(3)
+
+    def last_pairs(self, slot: int = 0) -> np.ndarray:
+        """who walked with whom in the last device-built batch of `slot`: [npairs, 2] candidate indices (0xFFFFFFFF: alone);
+        empty when that batch was walked one candidate per wave"""
+        cap = 1 << 16
+        out = np.zeros((cap, 2), dtype=np.uint32)
+        n = C.c_int32(0)
+        self._chk(self.lib.lvbgpu_debug_pairs(self.h, int(slot), out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy()
 
     def set_wait_limit(self, seconds: float) -> None:
         self._chk(self.lib.lvbgpu_set_wait_limit(self.h, float(seconds)))

@@ -120,18 +120,8 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
         ctx->direct_steps = ds[0] != '0';
     if (const char *lp = getenv("LVBGPU_LPT"))
         ctx->lpt_order = lp[0] != '0';
-    if (const char *pr = getenv("LVBGPU_PAIR"))
-    {
-        // n: batches of n candidates and more are walked two candidates per wave; auto: big device-built batches whose
-        // programs are long; unset / 0: never (the default: measured, the order costs what the walk gains - DESIGN.md 3)
-        if (pr[0] == 'a')
-            ctx->pair_auto = true;
-        else
-            ctx->pair_min = std::max(0, atoi(pr));
-    }
-    if (const char *pt = getenv("LVBGPU_PAIR_TOKENS"))
-        if (atof(pt) > 0.0)
-            ctx->pair_tokens_min = atof(pt);
+    if (const char *pr = getenv("LVBGPU_PAIR")) // n: batches of n candidates and more are walked two candidates per wave (unset / 0: none)
+        ctx->pair_min = std::max(0, atoi(pr));
     if (const char *pl = getenv("LVBGPU_PIPELINE"))
         ctx->pipeline_steps = pl[0] != '0';
     static_assert(lvbgpu_ctx::STEP_PIPELINE == 4, "lvbgpu_destroy lists the step batches");
@@ -299,7 +289,6 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
     delete ctx->pool;
     ctx->pool = nullptr;
     ctx->d_topo4.release();
-    ctx->d_gen_ticks.release();
     ctx->d_table_ready.release();
     for (lvbgpu_ctx::PropSlot &ps : ctx->pslot)
     {
@@ -309,7 +298,6 @@ extern "C" void lvbgpu_destroy(lvbgpu_ctx *ctx)
             (void)hipEventDestroy(ps.done_ev);
         if (ps.walk_ev)
             (void)hipEventDestroy(ps.walk_ev);
-        ps.d_keys.release();
         ps.h_flag.release();
     }
     ctx->h_pinfo.release();

@@ -370,61 +370,24 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
     ga.cands = (CandDesc *)bt->d_prog.p;
     ga.info = (ProposalInfo *)ps.d_pinfo.p;
     ga.len_out = (unsigned long long *)bt->d_len.p;
-    // two candidates per wave (fitch_walk_pair): big launches only - a small one is a chain of latencies, not of loads -
-    // and only where every segment's keys fit the sorting workgroup's LDS and preorder numbers fit 16 bits
-    // LVBGPU_PAIR=n: every batch of n candidates and more; LVBGPU_PAIR=auto: big launches of long programs - the paired walk
-    // loads the rows two programs share once, which is worth the more the longer the common way to the root is: measured
-    // 500 x 50 000 SPR, B = 4096, walk 88.0 -> 83.4 us on a fresh tree (D = 20), 185.8 -> 175.4 us on one mixed by 3000
-    // moves (D = 52).  The order is made by the last workgroups of the generator's own launch and costs ~9 us whether it is
-    // a kernel of its own (round 3) or not: that is the sort's own chain of passes, not a kernel boundary - so a step gains
-    // nothing at D = 20 (102.1 -> 106.3 us) and 1 us at D = 52 (200.0 -> 199.1): off unless asked for.  The programs'
-    // length is estimated from the trees' mean node depth (D ~ 1.45 x mean depth + 3 for SPR / TBR on these trees),
-    // which the host has without asking the device.
-    bool pair_up = ctx->gen_idx_bytes == 2 && !moves;
-    if (ctx->pair_min > 0)
-        pair_up = pair_up && B >= ctx->pair_min;
-    else if (ctx->pair_auto && B >= 2048)
-    {
-        double est = 0.0;
-        for (int32_t i = 0; i < k; i++)
-        {
-            ChainSlot &cs = ctx->parked[(size_t)draws[i].chain];
-            if (cs.depth_version != cs.topo_version)
-            {
-                cs.mean_depth = cs.topo.mean_depth();
-                cs.depth_version = cs.topo_version;
-            }
-            est += (1.45 * cs.mean_depth + 6.0) * draws[i].count;
-        }
-        pair_up = pair_up && est / B >= ctx->pair_tokens_min;
-    }
-    else
-        pair_up = false;
-    for (int32_t i = 0; i < k && pair_up; i++)
-        pair_up = (uint32_t)draws[i].count <= PAIR_SEG_MAX;
+    // two candidates per wave (fitch_walk_pair, LVBGPU_PAIR=n: every batch of n candidates and more): a wave that walks two
+    // programs loads the rows of their common end once.  Who walks with whom is settled by the generating workgroups among
+    // the sixteen candidates each has just drawn (GenArgs::pairs): nothing waits, nothing is sorted, and the generator's
+    // launch takes 4 us longer (9.9 -> 14.5 us at B = 4096: the workgroup's slowest candidate, then the pairing).  What that
+    // shares depends on the moves and the tree: NNI neighbours 25-33 % of their row reads, SPR / TBR neighbours 10 %.
+    // Measured, 500 x 50 000, B = 4096, step without / with: SPR on a fresh tree (D = 20) 102.0 / 106.8 us; NNI on a fresh
+    // tree (D = 11) 72.2 / 76.0; NNI on a tree mixed by 3000 moves (D = 36) 144.5 / 126.0 (walk 133.6 -> 111.2); the 32-chain
+    // annealing run 1.24-1.27 / 1.20-1.23 s.  Off unless asked for: it pays where paths are long AND run together, which the
+    // library cannot tell from what it is handed.
+    const bool pair_up = ctx->pair_min > 0 && B >= ctx->pair_min;
     bt->npairs = 0;
     if (pair_up)
     {
         uint32_t np = 0;
         for (int32_t i = 0; i < k; i++)
             np += ((uint32_t)draws[i].count + 1u) / 2u;
-        HIPCHK(ctx, ps.d_keys.reserve((size_t)B * 4));
         HIPCHK(ctx, bt->d_pairs.reserve((size_t)np * 8));
-        const size_t old_ticks = ctx->d_gen_ticks.cap;
-        HIPCHK(ctx, ctx->d_gen_ticks.reserve(64));
-        if (ctx->d_gen_ticks.cap != old_ticks) // once per context: the running count starts at zero, with the host's
-        {
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_gen_ticks.p, 0, ctx->d_gen_ticks.cap, ctx->stream));
-            ctx->gen_ticks_total = 0;
-        }
-        ga.keys = (uint32_t *)ps.d_keys.p;
         ga.pairs = (uint32_t *)bt->d_pairs.p;
-        ga.gen_done = (uint32_t *)ctx->d_gen_ticks.p;
-        uint32_t bits = 1;
-        while ((1u << bits) < (uint32_t)ctx->nb + 1u)
-            bits++;
-        ga.major_bits = bits > 12u ? 12u : bits; // buckets by preorder number (coarser for very large trees)
-        ga.major_shift = bits > 12u ? bits - 12u : 0u;
         bt->npairs = np;
     }
     ga.moves = d_moves;
@@ -471,7 +434,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         {
             rc = flush_pending(ctx, nullptr);
             if (rc == LVBGPU_OK)
-                HIPCHK(ctx, launch_propose(ga, ctx->stream, &ctx->gen_ticks_total));
+                HIPCHK(ctx, launch_propose(ga, ctx->stream));
         }
         if (rc != LVBGPU_OK)
         {
@@ -480,7 +443,7 @@ int propose_submit(lvbgpu_ctx *ctx, int32_t slot, int32_t k, const lvbgpu_chain_
         }
     }
     else
-        HIPCHK(ctx, launch_propose(ga, ctx->stream, &ctx->gen_ticks_total));
+        HIPCHK(ctx, launch_propose(ga, ctx->stream));
     bt->len_zeroed = true; // by the generator
     // Only the lengths come back per step (a move's descriptor and edits are fetched when, and only when, the caller
     // wants that candidate - lvbgpu_proposal_edits - or accepts it - lvbgpu_chains_commit).  One batch at a time the
@@ -684,6 +647,24 @@ extern "C" int lvbgpu_debug_post_stamps(lvbgpu_ctx *ctx, unsigned long long *out
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(out4065, ctx->d_post_prof.p, (1 + 4 * 1000 + 64) * 8, hipMemcpyDeviceToHost));
+    return LVBGPU_OK;
+}
+
+// diagnostic: who walked with whom in the last device-built batch of `slot` (two candidates per wave): out[2 p], out[2 p + 1]
+// = the candidates of pair p (0xFFFFFFFF: walked alone); *npairs = 0 when that batch was walked one candidate per wave
+extern "C" int lvbgpu_debug_pairs(lvbgpu_ctx *ctx, int32_t slot, uint32_t *out, int32_t cap_pairs, int32_t *npairs)
+{
+    if (!ctx || slot < 0 || slot >= lvbgpu_ctx::PROP_SLOTS || !out || !npairs || !ctx->pslot[slot].batch)
+        return LVBGPU_E_ARG;
+    const lvbgpu_batch *bt = ctx->pslot[slot].batch;
+    *npairs = (int32_t)bt->npairs;
+    if (bt->npairs == 0)
+        return LVBGPU_OK;
+    if ((uint32_t)cap_pairs < bt->npairs)
+        return LVBGPU_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, bt->d_pairs.p, (size_t)bt->npairs * 8, hipMemcpyDeviceToHost));
     return LVBGPU_OK;
 }
 
@@ -1004,7 +985,7 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
     // lanes.  Tried against that and not kept: 4-wave workgroups that fit wherever a walk workgroup retires, s_setprio for
     // its waves (together 1.3 % of the 32-chain run), a stream of the highest priority ordered against the main stream by
     // two events (1.216 -> 1.359 s).  profiles/experiments/r04_post_launch_and_lanes.md)
-    HIPCHK(ctx, launch_post(pa, ctx->stream, &ctx->gen_ticks_total));
+    HIPCHK(ctx, launch_post(pa, ctx->stream));
     return LVBGPU_OK;
 }
 

@@ -141,8 +141,6 @@ struct ChainSlot
     uint64_t d_topo_version = ~0ull;
     uint32_t gen_table_bytes = 0;
     int32_t gen_K = 1;
-    uint64_t depth_version = ~0ull; // mean_depth belongs to this version of topo
-    double mean_depth = 0.0;        // mean number of edges between a node and the root (how long this tree's programs are)
 };
 
 // Host-side waits for the device are bounded: a spin on a flag, an event or a stream gives up after the context's wait
@@ -216,7 +214,6 @@ struct lvbgpu_ctx
     {
         lvbgpu_batch *batch = nullptr;
         DevBuf d_pedits, d_pinfo;   // the candidates' rewrites and descriptors
-        DevBuf d_keys;              // their sort keys (two candidates per wave: who walks with whom)
         std::vector<PSeg> segs;     // the segments of the batch (lvbgpu_chains_commit picks from them)
         int32_t p_B = 0;            // candidates lvbgpu_proposal_edits may name (single chain, selected; 0: none)
         int32_t B = 0;
@@ -332,10 +329,6 @@ struct lvbgpu_ctx
     int64_t commits_reusing_programs = 0;
     int64_t paired_walks = 0; // scoring walks launched two candidates per wave (lvbgpu_debug_paired_walks)
     int pair_min = 0;         // env LVBGPU_PAIR=n: batches of n candidates and more are walked two candidates per wave
-    bool pair_auto = false;   // LVBGPU_PAIR=auto: device-built batches of 2048 candidates and more whose programs are long
-    double pair_tokens_min = 38.0; // ... "long": estimated tokens per candidate (env LVBGPU_PAIR_TOKENS)
-    DevBuf d_gen_ticks;       // the running count of generator workgroups (the sorting workgroups of a pairing launch wait for it)
-    uint32_t gen_ticks_total = 0;
     DevBuf d_tmp_changes;     // fused commits: per-combine accumulators, zero between launches
     size_t tmp_changes_zeroed_cap = 0; // capacity of d_tmp_changes when it was last cleared (0: never)
     DevBuf d_cin, d_cout; // strict-compat arenas

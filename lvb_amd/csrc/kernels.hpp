@@ -211,15 +211,13 @@ struct GenArgs
     CandDesc *cands;
     ProposalInfo *info;
     unsigned long long *len_out; // [B] length slots of the batch, cleared by the generator
-    uint32_t *keys;              // [B] sort keys for pairing the candidates (sort_role; null: none; needs 16-bit tables)
-    // two candidates per wave: the launch's LAST workgroups (n_sort_blocks of them, dealt behind the generator's) put
-    // every segment's candidates in the order of their keys and hand them out two by two - pairs[2 p], pairs[2 p + 1] -
-    // once all the generator's workgroups have ticked gen_done (a running count: they wait for gen_done_target)
+    // two candidates per wave (fitch_walk_pair): every generating workgroup pairs the sixteen candidates it has just
+    // drawn among themselves - whose programs END alike the longest, found on the programs' last 64 tokens in LDS - and
+    // writes the pairs where the walk looks for them: pairs[2 p], pairs[2 p + 1] (PICK_NONE: walked alone), segment s's
+    // pairs behind those of the segments before it (ceil(count / 2) each).  No pass over the batch, no second kernel, no
+    // workgroup waiting for another.  null: one candidate per wave
     uint32_t *pairs;
-    uint32_t *gen_done;
-    uint32_t gen_done_target, n_sort_blocks, n_gen_blocks;
-    uint32_t major_bits, major_shift; // buckets of the counting sort: (key >> 16) >> major_shift, below 2^major_bits
-    uint32_t sort_cap;                // the longest segment (what a sorting workgroup's LDS arrays hold)
+    uint32_t n_gen_blocks;        // filled by the launcher: generating workgroups of the launch
     const lvbgpu_move_dev *moves; // single segment only: candidate b IS moves[b]
     unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
     const uint32_t *table_ready;  // post launch: [MAX_CHAINS], = ready_seq once that chain's tables have been rebuilt (GenSeg::wait)
@@ -229,13 +227,12 @@ struct GenArgs
     GenSeg seg[MAX_GEN_SEGS];
 };
 static_assert(sizeof(GenArgs) <= 2600, "GenArgs travels as a kernel argument, in the post launch beside three more structs");
-// ticks_total: the caller's running count of generator workgroups (what the sorting workgroups of a pairing launch wait for)
-hipError_t launch_propose(const GenArgs &args, hipStream_t stream, uint32_t *ticks_total = nullptr);
+hipError_t launch_propose(const GenArgs &args, hipStream_t stream);
 
-// who walks with whom (fitch_walk_pair): every segment's candidates ordered by their keys and handed out two by two
-constexpr uint32_t PAIR_SEG_MAX = 4096; // candidates of one segment whose keys and order fit LDS beside the histogram (longer: no pairing)
-// sorting workgroups of a segment of `count` candidates (one per ~512 candidates, at most 8; they never talk to each other)
-__host__ __device__ inline uint32_t sort_blocks_of(uint32_t count) { return count / 512u < 1u ? 1u : (count / 512u > 8u ? 8u : count / 512u); }
+// who walks with whom (GenArgs::pairs): a generating workgroup's LDS beside its tables - the last 64 tokens of its sixteen
+// programs (rows of 65 words: different candidates in different banks), their lengths, the 16 x 16 shared lengths
+constexpr uint32_t PAIR_ROW = 65;
+constexpr uint32_t PAIR_LDS_BYTES = (16 * PAIR_ROW + 16 + 256) * 4;
 
 // rebuild the generator's tables of the picked candidates' chains on the device (one workgroup per pick)
 constexpr uint32_t REBUILD_THREADS = 1024;
@@ -306,7 +303,7 @@ struct PostArgs
 static_assert(sizeof(PostArgs) <= 4000, "PostArgs travels as a kernel argument");
 // can the generator ride in a post launch (its tables must fit LDS beside nothing else)?
 bool post_can_generate(const GenArgs &g);
-hipError_t launch_post(const PostArgs &args, hipStream_t stream, uint32_t *ticks_total = nullptr);
+hipError_t launch_post(const PostArgs &args, hipStream_t stream);
 // fills what a walk's launcher owes the kernel (tiles per group, the division constant, and for a commit walk the burst
 // slots that fit `lds_budget` bytes per workgroup of `nwaves` waves beside the operand stacks); *lds_out = dynamic LDS
 hipError_t shape_walk(WalkArgs &a, bool commit, uint32_t nwaves, size_t lds_budget, size_t *lds_out);

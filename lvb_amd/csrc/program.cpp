@@ -46,27 +46,6 @@ bool Topology::assign(int32_t n_taxa, const int32_t *l, const int32_t *r, int32_
     return validate(why);
 }
 
-double Topology::mean_depth() const
-{
-    if (nb <= 0 || root < 0 || root >= nb)
-        return 0.0;
-    std::vector<int32_t> depth((size_t)nb, 0), stack{root};
-    int64_t sum = 0;
-    while (!stack.empty())
-    {
-        const int32_t v = stack.back();
-        stack.pop_back();
-        sum += depth[(size_t)v];
-        if (left[(size_t)v] >= 0 && right[(size_t)v] >= 0)
-        {
-            depth[(size_t)left[(size_t)v]] = depth[(size_t)right[(size_t)v]] = depth[(size_t)v] + 1;
-            stack.push_back(left[(size_t)v]);
-            stack.push_back(right[(size_t)v]);
-        }
-    }
-    return (double)sum / (double)nb;
-}
-
 bool Topology::validate(std::string *why) const
 {
     auto fail = [&](const std::string &s) {

@@ -53,8 +53,6 @@ struct Topology
     // describe one binary tree over all 2n-3 records rooted at leaf `root`.
     bool assign(int32_t n_taxa, const int32_t *l, const int32_t *r, int32_t root_leaf, std::string *why);
     bool validate(std::string *why) const;
-    // mean number of edges between a node and the root leaf (how long the dirty paths of this tree's neighbours are)
-    double mean_depth() const;
 };
 
 struct Program

@@ -150,12 +150,15 @@ struct Tab
     }
 };
 
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+
 struct GenOut
 {
     uint32_t *toks;
     int32_t *dsts;
     lvbgpu_edit_dev *edits;
     uint32_t ntok, ndst, nedit, nfresh, cap_e;
+    lds_word *ltok; // pairing (GenArgs::pairs): the program's first 64 tokens go to this row of LDS as well (null: not)
 };
 
 template <typename IdxT, bool IN_LDS>
@@ -171,9 +174,15 @@ struct Gen
     {
         if (lane == 0)
         {
-            o.toks[o.ntok] = (uint32_t)row_a | TOK_FRESH | flags_a;
-            o.toks[o.ntok + 1] = (uint32_t)row_b | (merge_after ? 1u << TOK_MERGE_SHIFT : 0u);
+            const uint32_t ta = (uint32_t)row_a | TOK_FRESH | flags_a, tb = (uint32_t)row_b | (merge_after ? 1u << TOK_MERGE_SHIFT : 0u);
+            o.toks[o.ntok] = ta;
+            o.toks[o.ntok + 1] = tb;
             o.dsts[o.ndst] = dst;
+            if (o.ltok && o.ntok + 1u < 64u)
+            {
+                o.ltok[o.ntok] = ta;
+                o.ltok[o.ntok + 1] = tb;
+            }
         }
         o.ntok += 2;
         o.ndst += 1;
@@ -184,8 +193,11 @@ struct Gen
     {
         if (lane == 0)
         {
-            o.toks[o.ntok] = (uint32_t)row | (merge_after ? 1u << TOK_MERGE_SHIFT : 0u);
+            const uint32_t tk = (uint32_t)row | (merge_after ? 1u << TOK_MERGE_SHIFT : 0u);
+            o.toks[o.ntok] = tk;
             o.dsts[o.ndst] = dst;
+            if (o.ltok && o.ntok < 64u)
+                o.ltok[o.ntok] = tk;
         }
         o.ntok += 1;
         o.ndst += 1;
@@ -213,8 +225,11 @@ struct Gen
                 int32_t row = j == 0u ? row0 : t.away(v, y);
                 if (row == fix_from)
                     row = fix_to;
-                o.toks[o.ntok + idx] = (uint32_t)row | ((merge_last && idx == count - 1u) ? 1u << TOK_MERGE_SHIFT : 0u);
+                const uint32_t tk = (uint32_t)row | ((merge_last && idx == count - 1u) ? 1u << TOK_MERGE_SHIFT : 0u);
+                o.toks[o.ntok + idx] = tk;
                 o.dsts[o.ndst + idx] = v;
+                if (o.ltok && o.ntok + idx < 64u)
+                    o.ltok[o.ntok + idx] = tk;
             }
         }
         o.ntok += count;
@@ -241,14 +256,15 @@ struct Gen
 // bl: the candidate's index within its segment (what the draw is a function of, with the segment's seed);
 // b = sg.start + bl: its slot in the batch
 template <typename IdxT, bool IN_LDS>
-__device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const GenSeg &sg, const uint32_t bl, const uint32_t lane)
+__device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const GenSeg &sg, const uint32_t bl, const uint32_t lane,
+                             lds_word *const pair_row = nullptr, lds_word *const pair_ntok = nullptr)
 {
     const int32_t n = t.n, nb = t.nb, root = t.root;
     const uint32_t b = sg.start + bl;
     const uint64_t seed = ((uint64_t)sg.seed_hi << 32) | sg.seed_lo;
     const DevRng rng{seed ^ ((uint64_t)(bl + 1u) * 0xD1B54A32D192ED03ull)};
     Gen<IdxT, IN_LDS> e{t, GenOut{g.toks + (size_t)b * g.stride_t, g.dsts + (size_t)b * g.stride_t, g.edits + (size_t)b * g.stride_e, 0, 0,
-                          0, 0, g.stride_e},
+                          0, 0, g.stride_e, pair_row},
                 lane};
     // LVBGPU_GEN_PROFILE (tools/gen_profile.py): where a candidate's time goes, clock stamps of the first 256 candidates
     auto stamp = [&](uint32_t k) {
@@ -281,8 +297,6 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
     // (the move's description as scalars: as a struct filled field by field it lived in scratch memory)
     int32_t pi_a = -1, pi_b = -1, pi_c = -1, pi_flag = 0;
     bool unusable = false;
-    // where the program's LAST chain starts, and its first (GenArgs::keys): candidates that agree on these end alike
-    int32_t key_major = -1, key_minor = -1;
 
     if (kind == 0)
     {
@@ -293,7 +307,6 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
         const int32_t keep = swap_right ? a : bb, moved = swap_right ? bb : a;
         pi_a = u;
         pi_flag = swap_right ? 1 : 0;
-        key_major = u;
         // edits: v trades c for `moved` (same side), u holds (keep, c)
         {
             const int32_t vl = (int32_t)t.left[v], vr = (int32_t)t.right[v];
@@ -419,6 +432,8 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                             const int32_t dis = i == 1u ? sis_x : t.away(t.toward(node, x), x);
                             e.o.toks[e.o.ntok + q] = (uint32_t)dis;
                             e.o.dsts[e.o.ndst + q] = node;
+                            if (e.o.ltok && e.o.ntok + q < 64u)
+                                e.o.ltok[e.o.ntok + q] = (uint32_t)dis;
                         }
                     }
                     e.o.ntok += k - 1u;
@@ -476,7 +491,6 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                 if (dest != ss && t.inside(dest, ss))
                 {
                     // (1) dest below the sister: one chain sp, dp .. ss, then pp .. (sp's old place is skipped)
-                    key_major = dest;
                     LVB_HEAD_SP();
                     e.run(dp, 0u, (uint32_t)(t.dep(dp) - t.dep(ss)) + 1u, oc_dp, -1, -1, false);
                     if (pp != root)
@@ -490,8 +504,6 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                 else if (pp != root && t.inside(pp, dest))
                 {
                     // (2) dest is pp or above it: one chain from pp through dest, sp (new place), dp ..
-                    key_major = pp;
-                    key_minor = src;
                     const uint32_t up_to_dest = (uint32_t)(t.dep(pp) - t.dep(dest)); // nodes above pp up to dest
                     e.head2(ss, have_acc ? TOK_PUSH : 0u, oc_pp, pp, have_acc && up_to_dest == 0u);
                     e.run(pp, 1u, up_to_dest, -1, -1, -1, have_acc);
@@ -514,7 +526,6 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                     if (pp == root || m == pp)
                     {
                         // pp is the root or lies on the path from dp: one chain; where it passes pp, sp's place holds ss
-                        key_major = dest;
                         LVB_HEAD_SP();
                         if (dp != root)
                         {
@@ -529,8 +540,6 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
                         const uint32_t dm = m == root ? 0u : (uint32_t)t.dep(m);
                         const uint32_t len_a = dp == root ? 0u : (uint32_t)t.dep(dp) - dm; // dp .. below M (0: M is dp)
                         const uint32_t len_b = (uint32_t)t.dep(pp) - dm;                     // pp .. below M (>= 1)
-                        key_major = pp;
-                        key_minor = dest;
                         LVB_HEAD_SP();
                         e.run(dp, 0u, len_a, oc_dp, -1, -1, false);
                         e.head2(ss, TOK_PUSH, oc_pp, pp, len_b == 1u);
@@ -572,12 +581,8 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
         g.cands[b] = cd;
         g.len_out[b] = 0ull; // the walk accumulates into it: cleared here, so a step needs no clearing pass of its own
         g.info[b] = ProposalInfo{kind, pi_a, pi_b, pi_c, pi_flag, (int32_t)e.o.nedit, overflow ? 1 : 0, (int32_t)e.o.ndst};
-        if (g.keys) // preorder numbers of the two chain starts: neighbours in this order end alike (sort_role, in this launch:
-                    // written through, its workgroups sit on other XCDs)
-            __hip_atomic_store(g.keys + b,
-                               (overflow || key_major < 0) ? 0xFFFFFFFFu
-                                                           : ((uint32_t)t.tin[key_major] << 16) | (key_minor >= 0 ? (uint32_t)t.tin[key_minor] & 0xFFFFu : 0u),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pair_ntok) // how much of the program lies in LDS for the workgroup's pairing: all of it, or nothing to share
+            *pair_ntok = (overflow || e.o.ntok > 64u) ? 0u : e.o.ntok;
     }
     stamp(4);
 }
@@ -585,6 +590,97 @@ __device__ void generate_one(const Tab<IdxT, IN_LDS> &t, const GenArgs &g, const
 } // namespace
 
 #undef LVB_HEAD_SP
+// Who walks with whom (fitch_walk_pair; GenArgs::pairs): the sixteen candidates a generating workgroup has just drawn are
+// paired among themselves, by the length of their programs' common END - the number of row loads a wave saves by walking
+// the two together - longest first (greedy; ties: the pair of the later candidates; a function of the draw, nothing of
+// timing).  Every wave left its program's tokens in a row of LDS.  Wave w compares its own, turned round, a token per
+// lane, with those of the eight candidates behind it (cyclically: every pair exactly once, eight rows in flight at a time);
+// then sixteen lanes of one wave - lane w is candidate w - repeat: everybody names the best partner still free, pairs
+// that name each other are made (with a strict order on the pairs that IS the greedy matching, in 3-4 rounds instead of
+// eight searches for a maximum).  Random neighbours of a 500-taxon tree share this way (tools/shared_suffix_estimate.py,
+// tools/pair_quality.py): NNI 0.24-0.35 of their row reads, SPR / TBR 0.11 at D = 20 and 0.20 at D = 52; a sort of the
+// whole batch by one key - rounds 3 and 4, a role of its own at the launch's end that waited for every generating
+// workgroup: 8-9 us - gave SPR 0.13 and 0.17.  first: the batch index of the iteration's first candidate; cnt: how many
+// were drawn (1 .. 16); pair0: their first pair.  Called by all sixteen waves.
+__device__ __forceinline__ void pair_the_drawn(const GenArgs &g, lds_word *const pl, const uint32_t first, const uint32_t cnt, const uint32_t pair0)
+{
+    lds_word *const tok = pl, *const ntok = pl + 16u * PAIR_ROW, *const share = ntok + 16u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __syncthreads(); // the programs are out
+    {
+        const uint32_t nall = lane < 16u ? ntok[lane] : 0u; // (0: too long for one chunk, or not a proposal: shares nothing)
+        const uint32_t nw = (uint32_t)__builtin_amdgcn_readlane((int)nall, (int)wave);
+        const uint32_t mine = lane < nw ? tok[wave * PAIR_ROW + nw - 1u - lane] : 0xFFFFFFFEu;
+        uint32_t other[8];
+#pragma unroll
+        for (uint32_t d = 1; d <= 8u; d++)
+        {
+            const uint32_t j = (wave + d) & 15u;
+            const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)nall, (int)j);
+            other[d - 1u] = lane < nj ? tok[j * PAIR_ROW + nj - 1u - lane] : 0xFFFFFFFDu;
+        }
+#pragma unroll
+        for (uint32_t d = 1; d <= 8u; d++)
+        {
+            const uint32_t j = (wave + d) & 15u;
+            const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)nall, (int)j);
+            const uint64_t differ = ~__builtin_amdgcn_ballot_w64(mine == other[d - 1u]);
+            uint32_t k = differ ? (uint32_t)__builtin_ctzll(differ) : 64u;
+            const uint32_t m = nw < nj ? nw : nj;
+            k = k < m ? k : m;
+            if (lane == 0 && wave < cnt && j < cnt && (d < 8u || wave < 8u))
+            {
+                const uint32_t lo = wave < j ? wave : j, hi = wave < j ? j : wave;
+                const uint32_t v = ((k + 1u) << 8) | (lo << 4) | hi; // (never 0; no two pairs alike)
+                share[wave * 16u + j] = v;
+                share[j * 16u + wave] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0)
+        return; // (the next iteration's rows and lengths are other words than `share`, which all write after the next barrier)
+    uint32_t row[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++)
+        row[j] = (lane < cnt && j < cnt && j != lane) ? share[(lane & 15u) * 16u + j] : 0u;
+    uint32_t used = 0u, out = 0u;
+    for (uint32_t round = 0; round < 8u; round++)
+    {
+        uint32_t best = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; j++)
+            if (!((used >> j) & 1u) && row[j] > best)
+                best = row[j];
+        if (lane >= cnt || ((used >> (lane & 31u)) & 1u))
+            best = 0u;
+        const uint32_t e = best & 255u;
+        const uint32_t partner = (e >> 4) == lane ? (e & 15u) : (e >> 4);
+        const uint32_t theirs = (uint32_t)__shfl((int)best, (int)partner);
+        const bool made = best != 0u && theirs == best; // both named this pair
+        const uint32_t mask = (uint32_t)__builtin_amdgcn_ballot_w64(made);
+        if (!mask)
+            break;
+        const bool writes = made && lane < partner;
+        const uint32_t wm = (uint32_t)__builtin_amdgcn_ballot_w64(writes);
+        if (writes)
+        {
+            const uint32_t slot = pair0 + out + (uint32_t)__builtin_popcount(wm & ((1u << lane) - 1u));
+            g.pairs[2u * slot] = first + lane;
+            g.pairs[2u * slot + 1u] = first + partner;
+        }
+        out += (uint32_t)__builtin_popcount(wm);
+        used |= mask;
+    }
+    const uint32_t rest = ~used & ((1u << cnt) - 1u); // (an odd run's last one)
+    if (rest && lane == 0)
+    {
+        g.pairs[2u * (pair0 + out)] = first + (uint32_t)__builtin_ctz(rest);
+        g.pairs[2u * (pair0 + out) + 1u] = PICK_NONE;
+    }
+}
+
 // The generator's part of a launch: workgroup `blk` of the `nblk` that generate (propose_kernel: the whole grid; the post
 // launch: its last workgroups).  lds_tables: the workgroup's dynamic LDS.
 template <typename IdxT, bool IN_LDS>
@@ -700,173 +796,32 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
         g.prof[(sg.start + blk_local * nwaves + wave) * 8u + 5u] = t_enter;
         g.prof[(sg.start + blk_local * nwaves + wave) * 8u + 6u] = __builtin_readcyclecounter();
     }
-    for (uint32_t bl = blk_local * nwaves + wave; bl < sg.count; bl += seg_blocks * nwaves)
-        generate_one(t, g, sg, bl, lane);
-    if (g.n_sort_blocks)
+    if (!g.pairs)
     {
-        // this workgroup's keys are out (acknowledged: written through): tell the sorting workgroups at the launch's end
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0)
-            atomicAdd(g.gen_done, 1u);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Who walks with whom (fitch_walk_pair): a segment's candidates are put in order of their keys - the preorder number of
-// the node the program's LAST chain starts at, then of the one its first chain starts at: programs that agree on these
-// share their ends - and pair p is whoever stands at places 2p and 2p + 1.  The order is made by the LAST workgroups of
-// the generator's own launch (round 3: a kernel of its own behind it - 8.7 us of a step for what is 3 us of work, more
-// than the paired walk saved at D = 20): they wait until every generating workgroup has ticked, then several workgroups
-// per segment that never talk to each other: workgroup r of a segment's R owns the r-th range of major keys; it reads ALL
-// the segment's keys (a few KB), counts how many fall below its range - that is where its output starts - and sorts the
-// ones inside: counting sort by major key (LDS atomics; the order inside a bucket is whatever the atomics gave), then
-// every candidate finds its own place in its bucket by counting who comes before it in (key, index) order (buckets hold
-// a handful: four candidates per node at B = 4096, n = 500), so the result does not depend on timing.
-__device__ __forceinline__ void sort_role(const GenArgs &g, const uint32_t sblk, uint32_t *const lds_u32)
-{
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    // which segment, which range of it: segment s has sort_blocks_of(count) workgroups, its pairs start at pair_base
-    uint32_t s = 0, first = 0, pair_base = 0;
-    for (; s + 1u < g.nseg && sblk >= first + sort_blocks_of(g.seg[s].count); s++)
-    {
-        first += sort_blocks_of(g.seg[s].count);
-        pair_base += (g.seg[s].count + 1u) / 2u;
-    }
-    const uint32_t r = sblk - first, R = sort_blocks_of(g.seg[s].count);
-    const uint32_t start = g.seg[s].start, count = g.seg[s].count;
-    // every generating workgroup has ticked?  (dealt before this one: resident or done; a word of LDS says what thread 0 saw)
-    volatile uint32_t *const agree = reinterpret_cast<volatile uint32_t *>(lds_u32);
-    if (tid == 0)
-    {
-        uint32_t budget = 1u << 24;
-        while (__hip_atomic_load(g.gen_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.gen_done_target && --budget)
-            __builtin_amdgcn_s_sleep(8);
-        *agree = budget == 0u ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool gave_up = *agree != 0u;
-    __syncthreads();
-    uint32_t *out = g.pairs + 2u * pair_base;
-    if (gave_up)
-    {
-        // never pair by keys that may not be there: everybody walks in the order of the draw (any order is a valid pairing)
-        const uint32_t lo = (uint32_t)((uint64_t)count * r / R), hi = (uint32_t)((uint64_t)count * (r + 1u) / R);
-        for (uint32_t i = lo + tid; i < hi; i += nt)
-            out[i] = start + i;
-        if (r == R - 1u && tid == 0u && (count & 1u))
-            out[count] = PICK_NONE;
+        for (uint32_t bl = blk_local * nwaves + wave; bl < sg.count; bl += seg_blocks * nwaves)
+            generate_one(t, g, sg, bl, lane);
         return;
     }
-    const uint32_t NB = 1u << g.major_bits;
-    auto bucket_of = [&](uint32_t key) { return key == 0xFFFFFFFFu ? NB - 1u : (key >> 16) >> g.major_shift; };
-    const uint32_t b_lo = (uint32_t)((uint64_t)NB * r / R), b_hi = (uint32_t)((uint64_t)NB * (r + 1u) / R); // my buckets
-    const uint32_t nbk = b_hi - b_lo;
-    // LDS: mine[cap] keys | idx[cap] | order[cap] | sorted[cap] | hist[nbk + 1] | scan scratch[64] | counters[2]
-    const uint32_t cap = g.sort_cap;
-    uint32_t *mkey = lds_u32, *midx = mkey + cap, *order = midx + cap, *sorted = order + cap, *hist = sorted + cap,
-             *part = hist + nbk + 1u, *ctr = part + 64u;
-    for (uint32_t b = tid; b <= nbk; b += nt)
-        hist[b] = 0u;
-    if (tid < 2u)
-        ctr[tid] = 0u;
-    __syncthreads();
-    // one pass over all keys: how many lie below my range, and mine into LDS
-    uint32_t below = 0;
-    for (uint32_t i = tid; i < count; i += nt)
+    // two candidates per wave: sixteen candidates at a time, drawn and then paired (the workgroup in step)
+    uint32_t pair_seg = 0; // the segment's first pair: behind those of the segments before it
+    for (uint32_t i = 0; i < s; i++)
+        pair_seg += (g.seg[i].count + 1u) >> 1;
+    lds_word *const pl = (lds_word *)(reinterpret_cast<uint32_t *>(lds_tables) + (IN_LDS ? ((g.table_bytes + 15u) & ~15u) / 4u : 0u));
+    for (uint32_t bl0 = blk_local * nwaves; bl0 < sg.count; bl0 += seg_blocks * nwaves)
     {
-        const uint32_t k = __hip_atomic_load(g.keys + start + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = bucket_of(k);
-        below += b < b_lo ? 1u : 0u;
-        if (b >= b_lo && b < b_hi)
-        {
-            const uint32_t at = atomicAdd(&ctr[1], 1u);
-            if (at < cap)
-            {
-                mkey[at] = k;
-                midx[at] = i;
-                atomicAdd(&hist[b - b_lo + 1u], 1u);
-            }
-        }
+        if (bl0 + wave < sg.count)
+            generate_one(t, g, sg, bl0 + wave, lane, pl + wave * PAIR_ROW, pl + 16u * PAIR_ROW + wave);
+        const uint32_t cnt = sg.count - bl0 < nwaves ? sg.count - bl0 : nwaves;
+        pair_the_drawn(g, pl, sg.start + bl0, cnt, pair_seg + (bl0 >> 1));
+        if (g.prof && lane == 0 && sg.start + bl0 + wave < 256u)
+            g.prof[(sg.start + bl0 + wave) * 8u + 7u] = __builtin_readcyclecounter(); // (paired)
     }
-    for (int off = 32; off > 0; off >>= 1)
-        below += (uint32_t)__shfl_xor((int)below, off);
-    if ((tid & 63u) == 0u)
-        atomicAdd(&ctr[0], below);
-    __syncthreads();
-    const uint32_t base = ctr[0], mine = ctr[1] < cap ? ctr[1] : cap; // (cap = the longest segment: never exceeded)
-    // exclusive scan of my buckets' counts (hist[b + 1] becomes bucket b's start): buckets dealt to the threads, the
-    // threads' sums scanned inside the waves by shuffles and across them through LDS
-    {
-        const uint32_t per = (nbk + nt - 1u) / nt;
-        const uint32_t b0 = tid * per;
-        uint32_t sum = 0;
-        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
-            sum += hist[b + 1u];
-        const uint32_t ln = tid & 63u, wv = tid >> 6, nwv = (nt + 63u) >> 6;
-        uint32_t incl = sum;
-        for (uint32_t d = 1; d < 64u; d <<= 1)
-        {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, (int)d);
-            if (ln >= d)
-                incl += v;
-        }
-        if (ln == 63u)
-            part[wv] = incl;
-        __syncthreads();
-        if (tid < 64u)
-        {
-            const uint32_t w = tid < nwv ? part[tid] : 0u;
-            uint32_t wi = w;
-            for (uint32_t d = 1; d < 64u; d <<= 1)
-            {
-                const uint32_t v = (uint32_t)__shfl_up((int)wi, (int)d);
-                if (tid >= d)
-                    wi += v;
-            }
-            part[tid] = wi - w; // exclusive
-        }
-        __syncthreads();
-        uint32_t run = part[wv] + incl - sum;
-        for (uint32_t b = b0; b < b0 + per && b < nbk; b++)
-        {
-            const uint32_t c = hist[b + 1u];
-            hist[b + 1u] = run;
-            run += c;
-        }
-        __syncthreads();
-    }
-    for (uint32_t i = tid; i < mine; i += nt) // scatter: hist[b + 1] is bucket b's cursor, afterwards its end
-        order[atomicAdd(&hist[bucket_of(mkey[i]) - b_lo + 1u], 1u)] = i;
-    __syncthreads();
-    for (uint32_t pos = tid; pos < mine; pos += nt)
-    {
-        const uint32_t x = order[pos], b = bucket_of(mkey[x]) - b_lo;
-        const uint32_t lo = b ? hist[b] : 0u, hi = hist[b + 1u];
-        const uint64_t kx = ((uint64_t)mkey[x] << 32) | midx[x];
-        uint32_t before = 0;
-        for (uint32_t j = lo; j < hi; j++)
-        {
-            const uint32_t y = order[j];
-            before += ((((uint64_t)mkey[y]) << 32) | midx[y]) < kx ? 1u : 0u;
-        }
-        sorted[lo + before] = start + midx[x];
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < mine; i += nt)
-        out[base + i] = sorted[i];
-    if (r == R - 1u && tid == 0u && (count & 1u))
-        out[count] = PICK_NONE; // an odd segment's last candidate walks alone
 }
 
 template <typename IdxT, bool IN_LDS>
 __global__ __launch_bounds__(GEN_THREADS) void propose_kernel(const GenArgs g)
 {
     extern __shared__ uint4 lds_dyn[];
-    if (blockIdx.x >= g.n_gen_blocks)
-    {
-        sort_role(g, blockIdx.x - g.n_gen_blocks, reinterpret_cast<uint32_t *>(lds_dyn));
-        return;
-    }
     gen_role<IdxT, IN_LDS>(g, blockIdx.x, g.n_gen_blocks, lds_dyn);
 }
 
@@ -1156,14 +1111,11 @@ __global__ __launch_bounds__(GEN_THREADS) void post_kernel(const PostArgs p)
     if (p.gen.nseg)
     {
         const uint32_t gb = b - p.n_reb - p.n_cblk;
-        if (gb >= p.gen.n_gen_blocks)
-            sort_role(p.gen, gb - p.gen.n_gen_blocks, reinterpret_cast<uint32_t *>(lds_dyn));
-        else
-            gen_role<IdxT, true>(p.gen, gb, p.gen.n_gen_blocks, lds_dyn);
+        gen_role<IdxT, true>(p.gen, gb, p.gen.n_gen_blocks, lds_dyn);
         if (p.prof)
         {
             __syncthreads();
-            stamp(gb >= p.gen.n_gen_blocks ? 4 : 3);
+            stamp(3);
         }
     }
 }
@@ -1221,33 +1173,7 @@ static uint32_t deal_generator_blocks(GenArgs &g, uint32_t per_cu, uint32_t wave
     return nblk;
 }
 
-// the sorting workgroups behind the generator's (GenArgs::pairs != null): how many, what LDS they need, and the count of
-// generator ticks they wait for (*ticks_total: the caller's running count of generator workgroups launched so far)
-static size_t shape_sorters(GenArgs &g, uint32_t n_gen_blocks, uint32_t *ticks_total)
-{
-    g.n_gen_blocks = n_gen_blocks;
-    g.n_sort_blocks = 0;
-    if (!g.pairs || !g.keys || !g.gen_done || !ticks_total)
-    {
-        g.pairs = nullptr;
-        return 0;
-    }
-    const uint32_t NB = 1u << g.major_bits;
-    uint32_t longest = 0, most_buckets = 0;
-    for (uint32_t s = 0; s < g.nseg; s++)
-    {
-        const uint32_t R = sort_blocks_of(g.seg[s].count);
-        g.n_sort_blocks += R;
-        longest = std::max(longest, g.seg[s].count);
-        most_buckets = std::max(most_buckets, (NB + R - 1u) / R + 1u);
-    }
-    g.sort_cap = longest;
-    *ticks_total += n_gen_blocks;
-    g.gen_done_target = *ticks_total;
-    return ((size_t)4 * longest + most_buckets + 1 + 64 + 2) * 4;
-}
-
-hipError_t launch_propose(const GenArgs &args, hipStream_t stream, uint32_t *ticks_total)
+hipError_t launch_propose(const GenArgs &args, hipStream_t stream)
 {
     if (args.nseg == 0 || args.nseg > MAX_GEN_SEGS)
         return hipErrorInvalidValue;
@@ -1262,17 +1188,11 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream, uint32_t *tic
     }
     if (total == 0)
         return hipSuccess;
-    g.use_lds = g.table_bytes <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
-    size_t lds = g.use_lds ? g.table_bytes : 0;
+    const size_t pair_lds = g.pairs ? PAIR_LDS_BYTES + 16 : 0; // (behind the tables, 16-byte aligned)
+    g.use_lds = g.table_bytes + pair_lds <= lds_max ? 1 : 0; // else the tables are read where they lie (L2-resident)
+    size_t lds = (g.use_lds ? g.table_bytes : 0) + pair_lds;
     const uint32_t per_cu = g.use_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(2, lds_max / std::max<size_t>(lds, 1))) : 2u;
-    const uint32_t gen_blocks = deal_generator_blocks(g, per_cu);
-    {
-        const size_t slds = shape_sorters(g, gen_blocks, ticks_total);
-        if (slds > lds_max) // (cannot happen below PAIR_SEG_MAX candidates per segment)
-            return hipErrorInvalidValue;
-        lds = std::max(lds, slds);
-    }
-    const uint32_t nblk = gen_blocks + g.n_sort_blocks;
+    const uint32_t nblk = g.n_gen_blocks = deal_generator_blocks(g, per_cu);
     const dim3 grid(nblk), block(GEN_THREADS);
     if (g.idx_bytes == 2)
     {
@@ -1290,10 +1210,11 @@ hipError_t launch_propose(const GenArgs &args, hipStream_t stream, uint32_t *tic
 
 bool post_can_generate(const GenArgs &g)
 {
-    return g.nseg >= 1 && g.nseg <= MAX_GEN_SEGS && g.moves == nullptr && raise_generator_lds() == hipSuccess && g.table_bytes <= MAX_LDS_BYTES;
+    return g.nseg >= 1 && g.nseg <= MAX_GEN_SEGS && g.moves == nullptr && raise_generator_lds() == hipSuccess &&
+           g.table_bytes + (g.pairs ? PAIR_LDS_BYTES + 16 : 0) <= MAX_LDS_BYTES;
 }
 
-hipError_t launch_post(const PostArgs &args, hipStream_t stream, uint32_t *ticks_total)
+hipError_t launch_post(const PostArgs &args, hipStream_t stream)
 {
     PostArgs p = args;
     if (raise_generator_lds() != hipSuccess)
@@ -1316,7 +1237,7 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, uint32_t *ticks
         }
     }
     // a chain that is rebuilt here and draws few candidates next is drawn by its rebuilding workgroup (not with pairing:
-    // the sorting workgroups count generator workgroups' ticks)
+    // pairs are made by generating workgroups)
     for (uint32_t s = 0; s < p.gen.nseg; s++)
     {
         p.gen.seg[s].fused = 0;
@@ -1343,7 +1264,7 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, uint32_t *ticks
     if (p.gen.nseg)
     {
         p.gen.use_lds = 1;
-        lds = std::max(lds, (size_t)p.gen.table_bytes);
+        lds = std::max(lds, (size_t)p.gen.table_bytes + (p.gen.pairs ? PAIR_LDS_BYTES + 16 : 0));
     }
     // the commit walk's parked sets take what LDS is left - all of it while the generator's workgroups are few (one per
     // CU is plenty then), half of it when they are many (cold chains drawing a thousand candidates each: two generator
@@ -1376,15 +1297,11 @@ hipError_t launch_post(const PostArgs &args, hipStream_t stream, uint32_t *ticks
     }
     if (p.gen.nseg)
     {
-        gen_blocks = deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))), waves);
-        const size_t slds = shape_sorters(p.gen, gen_blocks, ticks_total);
-        if (slds > MAX_LDS_BYTES)
-            return hipErrorInvalidValue;
-        lds = std::max(lds, slds);
-        gen_blocks += p.gen.n_sort_blocks;
+        gen_blocks = p.gen.n_gen_blocks =
+            deal_generator_blocks(p.gen, (uint32_t)std::max<size_t>(1, std::min<size_t>(2, MAX_LDS_BYTES / std::max<size_t>(lds, 1))), waves);
     }
     else
-        p.gen.n_gen_blocks = p.gen.n_sort_blocks = 0;
+        p.gen.n_gen_blocks = 0;
     const uint32_t nblk = p.n_reb + p.n_cblk + gen_blocks;
     if (nblk == 0)
         return hipSuccess;

@@ -1,8 +1,8 @@
-"""Two candidates per wave (fitch_walk_pair, `LVBGPU_PAIR=n`): the same lengths as one candidate per wave, whoever is
-paired with whom - host-built batches (pairs from the full order of the programs read backwards), device-built ones
-(pairs from the generator's keys, sorted by pair_kernel), several chains in one launch (pairs never cross a segment),
-odd counts (the last candidate walks alone), programs longer than one 64-token chunk (walked alone), and batches below
-the threshold (not paired at all).  A context reads the switch when it is created."""
+"""Two candidates per wave (fitch_walk_pair): the same lengths as one candidate per wave, whoever is paired with whom -
+host-built batches (`LVBGPU_PAIR=n`: pairs from the full order of the programs read backwards), device-built ones (pairs
+made by every generating workgroup among the sixteen candidates it has drawn), several chains in one launch (pairs never
+cross a segment), odd counts (the last candidate walks alone), programs longer than one 64-token chunk (no sharing), and
+batches below the threshold (not paired at all).  A context reads the switch when it is created."""
 import os
 
 import numpy as np
@@ -21,11 +21,13 @@ def mods():
 
 
 def _contexts(api, rows, pair_min):
-    plain = api.FitchContext(text_rows=rows)
+    """-> (a context that never pairs, one that pairs every batch of pair_min candidates and more)"""
     old = os.environ.get("LVBGPU_PAIR"), os.environ.get("LVBGPU_DIRECT_STEPS")
-    os.environ["LVBGPU_PAIR"] = str(pair_min)
-    os.environ["LVBGPU_DIRECT_STEPS"] = "0"       # (direct steps - tiny batches straight to the host - are never paired)
     try:
+        os.environ["LVBGPU_PAIR"] = "0"
+        plain = api.FitchContext(text_rows=rows)
+        os.environ["LVBGPU_PAIR"] = str(pair_min)
+        os.environ["LVBGPU_DIRECT_STEPS"] = "0"       # (direct steps - tiny batches straight to the host - are never paired)
         paired = api.FitchContext(text_rows=rows)
     finally:
         for key, val in zip(("LVBGPU_PAIR", "LVBGPU_DIRECT_STEPS"), old):
@@ -122,44 +124,96 @@ def test_long_programs_walk_alone_and_small_batches_are_left_alone(mods):
     thresh.close()
 
 
-def test_long_programs_are_paired_when_the_library_is_left_to_choose(mods):
-    """LVBGPU_PAIR=auto: the library walks two candidates per wave where the loads saved are many - device-built batches of
-    2048 candidates and more whose programs are long (estimated from the tree's mean node depth) - and nowhere else; the
-    order is made by the last workgroups of the generator's own launch.  Same lengths as the plain walk either way."""
+def test_every_kind_of_draw_pairs_and_scores_the_same(mods):
+    """NNI, SPR, TBR, mixed by position and alternating (the annealing schedule's) draws, one chain or several in a batch,
+    one batch or two in flight: the paired walk's lengths are the plain walk's."""
     api, host = mods
     n, m = 200, 6000
     rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 41))
-    other, never = _contexts(api, rows, 0)            # LVBGPU_PAIR=0 ...
-    other.close()
-    old = os.environ.get("LVBGPU_PAIR")
-    os.environ["LVBGPU_PAIR"] = "auto"
-    try:
-        auto = api.FitchContext(text_rows=rows)       # ... and left to the library
-    finally:
-        if old is None:
-            os.environ.pop("LVBGPU_PAIR", None)
-        else:
-            os.environ["LVBGPU_PAIR"] = old
+    never, paired = _contexts(api, rows, 1000)
     tree = host.HostTree(n, seed=7)
-    assert tree.upload(never) == tree.upload(auto)
-    # a fresh random tree is shallow: short programs, nothing is paired
-    assert np.array_equal(auto.propose_score(2500, 1, 11), never.propose_score(2500, 1, 11))
-    assert auto.paired_walks() == 0
-    # mixed by accepted moves its paths get long: big batches are paired, small ones never
-    for _ in range(600):
+    assert tree.upload(never) == tree.upload(paired)
+    walks = 0
+    # kinds: 0 NNI, 1 SPR, 2 TBR, -1 by b % 3, -2 NNI / SPR alternating
+    for B, kind in ((2500, 1), (4096, 2), (3000, -1), (1024, 0), (999, 0), (2048, -2)):
+        draws = [(0, B, kind, 13 + B, B & 1, 0)]
+        assert np.array_equal(paired.chains_propose_score(draws)[0], never.chains_propose_score(draws)[0]), (B, kind)
+        walks += 1 if B >= 1000 else 0
+        assert paired.paired_walks() == walks, (B, kind)
+    for _ in range(100):
         e = tree.propose(1)
         never.commit(e)
-        auto.commit(e)
+        paired.commit(e)
         tree.apply(e)
-    for B, kind in ((2048, 1), (4096, 2), (3000, -1)):
-        assert np.array_equal(auto.propose_score(B, kind, 13 + B), never.propose_score(B, kind, 13 + B)), B
-    assert auto.paired_walks() == 3 and never.paired_walks() == 0
-    assert np.array_equal(auto.propose_score(2047, 1, 5), never.propose_score(2047, 1, 5)) and auto.paired_walks() == 3
-    # two batches in flight, both paired
-    counts = auto.chains_submit(0, [(0, 2100, 1, 21)])
-    auto.chains_submit(1, [(0, 2100, 1, 22)])
-    a0, a1 = auto.chains_collect(0, counts)[0], auto.chains_collect(1, counts)[0]
-    assert np.array_equal(a0, never.propose_score(2100, 1, 21)) and np.array_equal(a1, never.propose_score(2100, 1, 22))
-    assert auto.paired_walks() == 5
+    for c_ in (never, paired):
+        c_.set_chains(2)
+        for c in range(2):
+            c_.select_chain(c)
+            tree.upload(c_)
+    for draws in ([(0, 900, 0, 5), (1, 601, 1, 6)], [(0, 17, 0, 7), (1, 1483, 2, 8)], [(0, 700, -2, 9, 1, 0), (1, 700, 0, 10)]):
+        for g, w in zip(paired.chains_propose_score(draws), never.chains_propose_score(draws)):
+            assert np.array_equal(g, w)
+        walks += 1
+        assert paired.paired_walks() == walks
+    counts = paired.chains_submit(0, [(0, 2100, 0, 21)])
+    paired.chains_submit(1, [(1, 2100, -2, 22)])
+    a0, a1 = paired.chains_collect(0, counts)[0], paired.chains_collect(1, counts)[0]
+    assert np.array_equal(a0, never.chains_propose_score([(0, 2100, 0, 21)])[0])
+    assert np.array_equal(a1, never.chains_propose_score([(1, 2100, -2, 22)])[0])
+    assert paired.paired_walks() == walks + 2 and never.paired_walks() == 0
     never.close()
-    auto.close()
+    paired.close()
+
+
+def test_a_workgroup_pairs_its_sixteen_by_their_longest_common_ends(mods):
+    """Who walks with whom in a device-built batch: every candidate exactly once, partners from the same sixteen (and so
+    from the same chain), odd runs end with a lone candidate - and for NNI neighbours, whose programs the host builder
+    emits token for token as the device does, the pairs share exactly as many tokens as a greedy matching of each sixteen
+    by the length of the programs' common end (longest first) does, more than half of what pairing the whole batch in
+    the full order of the programs read backwards would share."""
+    api, host = mods
+    n, m = 120, 3000
+    rows, _ = host.prepare_alignment(synth.treelike_rows(n, m, 43))
+    never, paired = _contexts(api, rows, 1)
+    never.close()
+    tree = host.HostTree(n, seed=11)
+    tree.upload(paired)
+    for _ in range(40):
+        e = tree.propose(1)
+        paired.commit(e)
+        tree.apply(e)
+
+    def suffix(a, b):
+        k = 0
+        while k < len(a) and k < len(b) and a[len(a) - 1 - k] == b[len(b) - 1 - k]:
+            k += 1
+        return k
+
+    for B, kind in ((1000, 0), (1000, 1), (333, 2), (47, -1)):
+        paired.propose_score(B, kind, 3 * B + kind)
+        pairs = paired.last_pairs(0)
+        assert len(pairs) == (B + 1) // 2
+        seen = np.zeros(B, int)
+        for a, b in pairs:
+            seen[a] += 1
+            if b != 0xFFFFFFFF:
+                seen[b] += 1
+                assert a // 16 == b // 16
+        assert (seen == 1).all() and int((pairs[:, 1] == 0xFFFFFFFF).sum()) == B % 2
+        if kind != 0:
+            continue
+        progs = [tree.program(mode=0, edits=paired.proposal_edits(b)[0])["toks"] for b in range(B)]
+        got = sum(suffix(progs[a], progs[b]) for a, b in pairs if b != 0xFFFFFFFF)
+        want = 0
+        for w0 in range(0, B, 16):
+            idx = list(range(w0, min(B, w0 + 16)))
+            sh = {(i, j): suffix(progs[i], progs[j]) for i in idx for j in idx if j > i}
+            used = set()
+            for (i, j), v in sorted(sh.items(), key=lambda kv: (-kv[1], -(16 * (kv[0][0] - w0) + kv[0][1] - w0))):   # (ties: the later pair, as the device)
+                if i not in used and j not in used:
+                    used |= {i, j}
+                    want += v
+        full = sorted(range(B), key=lambda i: tuple(progs[i][::-1].tolist()))
+        best = sum(suffix(progs[full[i]], progs[full[i + 1]]) for i in range(0, B - 1, 2))
+        assert got == want and 2 * got > best, (got, want, best)
+    paired.close()

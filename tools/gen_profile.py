@@ -29,4 +29,8 @@ print(f"B={B} kind={kind}: clock ticks (s_memtime, 100 MHz = 10 ns each) per pha
 for nme, c in zip(names, cols):
     print(f"  {nme:24s} {c.mean():8.1f} {c.max():8d}")
 print(f"  {'total':24s} {(s[:, 4] - s[:, 5]).mean():8.1f} {(s[:, 4] - s[:, 5]).max():8d}")
+if (s[:, 7] > 0).any():
+    c = (s[:, 7] - s[:, 4])[s[:, 7] > 0]
+    print(f"  {'descriptors->paired':24s} {c.mean():8.1f} {c.max():8d}   (waits for the workgroup's slowest candidate, then the pairing)")
+    print(f"  {'enter->paired':24s} {(s[:, 7] - s[:, 5])[s[:, 7] > 0].mean():8.1f} {(s[:, 7] - s[:, 5])[s[:, 7] > 0].max():8d}")
 print("  first candidate enters at", int(s[:, 5].min() - s[:, 5].min()), "last of the 256 ends at", int(s[:, 4].max() - s[:, 5].min()))

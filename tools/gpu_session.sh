@@ -43,6 +43,14 @@ for s in "$@"; do
     walkab1k) step walkab1k 300 python tools/walk_ab.py 1024 3075 ;;
     walkab1k_nl) LVBGPU_LPT=0 step walkab1k_nl 300 python tools/walk_ab.py 1024 3075 ;;
     probe32q_nl) LVBGPU_LPT=0 step probe32q_nl 200 python tools/chains_probe.py 32 --quiet ;;
+    probe32q_p) LVBGPU_PAIR=1024 step probe32q_p 200 python tools/chains_probe.py 32 --quiet ;;
+    probe1q_p) LVBGPU_PAIR=64 step probe1q_p 200 python tools/chains_probe.py 1 --quiet ;;
+    probe32q_np) LVBGPU_PAIR=0 step probe32q_np 200 python tools/chains_probe.py 32 --quiet ;;
+    probe1q)  step probe1q 200 python tools/chains_probe.py 1 --quiet ;;
+    probe1q_np) LVBGPU_PAIR=0 step probe1q_np 200 python tools/chains_probe.py 1 --quiet ;;
+    parity)   step parity 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu ;;
+    pairq)    step pairq 400 python tools/pair_quality.py ;;
+    pairqm)   step pairqm 400 python tools/pair_quality.py 4096 3075 ;;
     anyorder) step anyorder 60 ./tools/anyorder_probe.bin ;;
     bench)    step bench 600 python bench.py ;;
     benchq)   step benchq 300 python bench.py --no-shapes --no-configs --no-cpu-baseline ;;

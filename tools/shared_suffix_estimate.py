@@ -12,6 +12,9 @@ paired:
   key       sorted by ONE small key a device could produce in a single counting-sort pass: the preorder number of the
             bottom node of the program's last chain
   plain     full order, but only suffixes without a chain start or merge inside (what a simple paired loop could take)
+  window W  the candidates in the order of the DRAW, cut into runs of W (what one generator workgroup holds: W = 16; with
+            several candidates per wave 32 or 64), each run sorted by the full order among its own and paired greedily:
+            the pairing a workgroup could do by itself, without a pass over the whole batch
 
   python tools/shared_suffix_estimate.py [B] [moves]
 """
@@ -85,7 +88,19 @@ def estimate(tree, kind, B):
     by_key = sorted(range(B), key=lambda i: keys[i])
     consecutive = lambda order, only_plain=False: sum(common_suffix(progs[order[i]], progs[order[i + 1]], only_plain)
                                                       for i in range(0, B - 1, 2))
-    return (total / B, pairs / total, groups4 / total, consecutive(by_key) / total, consecutive(full, True) / total)
+    windows = {}
+    for W in (16, 32, 64, 256):
+        got = 0
+        for w0 in range(0, B, W):
+            run = sorted(range(w0, min(B, w0 + W)), key=lambda i: tuple(progs[i][::-1].tolist()))
+            nbw = [common_suffix(progs[run[i]], progs[run[i + 1]]) for i in range(len(run) - 1)]
+            usedw = np.zeros(len(run), bool)
+            for i in sorted(range(len(run) - 1), key=lambda i: -nbw[i]):
+                if not usedw[i] and not usedw[i + 1] and nbw[i] > 0:
+                    usedw[i] = usedw[i + 1] = True
+                    got += nbw[i]
+        windows[W] = got / total
+    return (total / B, pairs / total, groups4 / total, consecutive(by_key) / total, consecutive(full, True) / total, windows)
 
 
 for walk in ([int(sys.argv[2])] if len(sys.argv) > 2 else [75, 3075]):
@@ -93,7 +108,8 @@ for walk in ([int(sys.argv[2])] if len(sys.argv) > 2 else [75, 3075]):
     for _ in range(walk):
         tree.apply(tree.propose(1))
     for name, kind in kinds.items():
-        mean_tok, pairs, groups4, key, pl = estimate(tree, kind, B)
+        mean_tok, pairs, groups4, key, pl, windows = estimate(tree, kind, B)
         print(f"walk {walk:5d} {name}: B={B} mean tokens {mean_tok:.1f} (D = {mean_tok - 3:.1f}); row reads shared: full order, pairs "
-              f"{pairs:.3f}, groups of 4 {groups4:.3f}; one-pass key {key:.3f}; plain suffixes only {pl:.3f}", flush=True)
+              f"{pairs:.3f}, groups of 4 {groups4:.3f}; one-pass key {key:.3f}; plain suffixes only {pl:.3f}; paired within runs of the draw: "
+              + ", ".join(f"{W}: {v:.3f}" for W, v in windows.items()), flush=True)
     tree.close()

@@ -8,6 +8,7 @@ from tests.synth import treelike_rows
 
 n, m, B = 500, 50000, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 walk = int(sys.argv[2]) if len(sys.argv) > 2 else 75
+kind = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # 0 NNI, 1 SPR, 2 TBR
 rows, _ = host.prepare_alignment(treelike_rows(n, m, 3))
 ctx = api.FitchContext(text_rows=rows)
 tree = host.HostTree(n, seed=3001)
@@ -16,7 +17,7 @@ for _ in range(walk):
     e = tree.propose(1); ctx.commit(e); tree.apply(e)
 batches = []
 for _ in range(4):
-    offs, edits = tree.propose_batch(1, B)
+    offs, edits = tree.propose_batch(kind, B)
     bh = api.C.c_void_p()
     ctx._chk(ctx.lib.lvbgpu_batch_build(ctx.h, B, offs, edits.ctypes.data, None, api.C.byref(bh)))
     batches.append(api.Batch(ctx, bh, B))
@@ -40,14 +41,14 @@ print(f"host-built LPT  B={B} D={st['dirty_nodes']/B:.1f}: {1e3*ms/K:.1f} us per
 # device-built (unsorted)
 ctx.walk_timing(1)
 for i in range(100):
-    ctx.propose_score(B, 1, 77 + i)
+    ctx.propose_score(B, kind, 77 + i)
 wms, k = ctx.walk_timing_read()
 ctx.walk_timing(0)
 print(f"device-built    B={B}: {1e3*wms/k:.1f} us per walk")
 # ... and the whole pipelined step (generator [+ pair sort] + walk, two in flight), as bench.py's headline measures it
 import time
 draw = np.zeros(1, dtype=api.DRAW_DTYPE)
-draw[0]["chain"], draw[0]["count"], draw[0]["kind"] = 0, B, 1
+draw[0]["chain"], draw[0]["count"], draw[0]["kind"] = 0, B, kind
 outs = [np.zeros(B, dtype=np.int64), np.zeros(B, dtype=np.int64)]
 def submit(slot, seed):
     draw[0]["seed"] = seed
@@ -67,5 +68,5 @@ dt = time.perf_counter() - t0
 wms, k = ctx.walk_timing_read()
 ctx.walk_timing(0)
 print(f"pipelined step  B={B}: {1e6 * dt / 200:.1f} us per step = {B * 200 / dt / 1e6:.1f} M candidates/s, walk {1e3 * wms / k:.1f} us")
-chk = ctx.propose_score(B, 1, 4242)
+chk = ctx.propose_score(B, kind, 4242)
 print("checksum", int(chk.sum()), int(chk.min()))
