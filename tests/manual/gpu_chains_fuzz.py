@@ -2,7 +2,7 @@
 """Randomised run of the multi-chain step on the GPU box: many small shapes (every taxon count from 5 to 140; site counts
 around the word, tile and multi-tile boundaries), 1-5 chains, whole annealing steps (lvbgpu_chains_step_*: the library
 decides and commits) in the two batch slots in turn, re-roots in between - so that commit walk, table rebuilds, re-roots
-and the next generator go out as ONE post launch, in its 16-wave and in its 4-wave form - and after every few steps each
+and the next generator go out as ONE post launch - and after every few steps each
 chain against the C ORACLE: full evaluation of the topology the library reports == the resident length, per-node changes
 and node sets; and the next device-drawn neighbourhood replayed on the host generators scores what the oracle scores.
 Prints one line per shape only on failure, and a summary.
