@@ -307,7 +307,7 @@ int lvbgpu_set_wait_limit(lvbgpu_ctx *ctx, double seconds);
  * the clock, so that what is enqueued behind it cannot complete before then */
 int lvbgpu_debug_stall(lvbgpu_ctx *ctx, int32_t ms);
 /* diagnostic (LVBGPU_POST_PROFILE set): out[0] = workgroups of the last post launch, then {role (1 table rebuild, 2 commit
- * walk, 3 generator, 4 sort), start, -, end} of each of the first 1000 (100 MHz clock), then 8 x 8 stamps of the first
+ * walk, 3 generator), start, -, end} of each of the first 1000 (100 MHz clock), then 8 x 8 stamps of the first
  * rebuilding workgroups' phases: tools/post_profile.py */
 int lvbgpu_debug_post_stamps(lvbgpu_ctx *ctx, unsigned long long *out4065);
 /* diagnostic: who walked with whom in the last device-built batch of `slot` (LVBGPU_PAIR): out[2 p], out[2 p + 1] = the

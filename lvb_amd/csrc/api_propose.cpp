@@ -639,7 +639,7 @@ extern "C" int lvbgpu_chains_propose_score(lvbgpu_ctx *ctx, int32_t k, const lvb
 }
 
 // diagnostic (LVBGPU_POST_PROFILE set): the clock stamps of the last post launch's workgroups: out[0] = their number, then
-// {role (1 rebuild, 2 commit walk, 3 generator, 4 sort), start, -, end} per workgroup (100 MHz clock), the first 1000
+// {role (1 rebuild, 2 commit walk, 3 generator), start, -, end} per workgroup (100 MHz clock), the first 1000
 extern "C" int lvbgpu_debug_post_stamps(lvbgpu_ctx *ctx, unsigned long long *out4065)
 {
     if (!ctx || !out4065 || !ctx->d_post_prof.p)

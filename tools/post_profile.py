@@ -23,7 +23,7 @@ for c in range(R):
     host.HostTree(n, seed=100 + c).upload(ctx)
 buf = np.zeros(4065, dtype=np.uint64)
 phases = []
-names = {1: "rebuild", 2: "commit", 3: "generator", 4: "sort"}
+names = {1: "rebuild", 2: "commit", 3: "generator"}
 acc = {}
 slot = 0
 draws = [(c, B, 1, 1000 + c) for c in range(R)]
