@@ -2,7 +2,8 @@
 One chain (or R) at 500 x 50k: steps of a few candidates with one accepted each time, the post launch of every step
 inspected: per role - table rebuild, commit walk, generator - when its workgroups started and ended relative to the launch's
 first stamp.
-  gpurun -- python tools/post_profile.py [R] [B]
+  gpurun -- python tools/post_profile.py [R] [B] [beside]
+beside > 0: another context (a lane) has a scoring walk of that many candidates on the device while each post launch runs.
 """
 import os, sys
 from pathlib import Path
@@ -14,6 +15,7 @@ from tests.synth import treelike_rows
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+BESIDE = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 n, m = 500, 50000
 rows, min_len = host.prepare_alignment(treelike_rows(n, m, 3))
 ctx = api.FitchContext(text_rows=rows)
@@ -21,6 +23,10 @@ ctx.set_chains(R)
 for c in range(R):
     ctx.select_chain(c)
     host.HostTree(n, seed=100 + c).upload(ctx)
+other = None
+if BESIDE:
+    other = ctx.fork()
+    host.HostTree(n, seed=999).upload(other)
 buf = np.zeros(4065, dtype=np.uint64)
 phases = []
 names = {1: "rebuild", 2: "commit", 3: "generator"}
@@ -32,7 +38,12 @@ for step in range(60):
     lens = ctx.chains_collect(slot, [B] * R)
     ctx.chains_commit([(c, int(np.argmin(lens[c]))) for c in range(R)])
     slot ^= 1
+    if other is not None:
+        cnt = other.chains_submit(0, [(0, BESIDE, 1, 77 + step)])      # the other lane's walk: on the device when the post launch arrives
     ctx.chains_submit(slot, [(c, B, 1, 5000 + 10 * step + c) for c in range(R)])      # post launch: commits + rebuilds + this generator
+    if other is not None:
+        ctx.synchronize()
+        other.chains_collect(0, cnt)
     if step >= 20:
         ctx._chk(ctx.lib.lvbgpu_debug_post_stamps(ctx.h, buf.ctypes.data))
         nb = int(buf[0])
@@ -46,7 +57,7 @@ for step in range(60):
             r = rec[rec[:, 0] == role]
             acc.setdefault(int(role), []).append((len(r), (r[:, 1].min() - t0) / 100.0, (r[:, 3].max() - t0) / 100.0,
                                                   float(np.mean(r[:, 3] - r[:, 1])) / 100.0))
-print(f"R={R} B={B}: post launches inspected: {len(next(iter(acc.values())))}")
+print(f"R={R} B={B} beside a walk of {BESIDE}: post launches inspected: {len(next(iter(acc.values())))}")
 for role, v in sorted(acc.items()):
     a = np.array(v)
     print(f"  {names.get(role, role):10s} workgroups {a[:,0].mean():6.1f}  first start {a[:,1].mean():6.2f} us  last end {a[:,2].mean():6.2f} us  "
