@@ -737,6 +737,14 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
                         g.cands[sg.start + bl] = cd;
                         g.len_out[sg.start + bl] = 0ull;
                         g.info[sg.start + bl] = ProposalInfo{0, -1, -1, -1, 0, 0, 1, 0};
+                        if (g.pairs && !(bl & 1u)) // (the paired walk still finds every candidate once: neighbours, as they come)
+                        {
+                            uint32_t pair_seg = 0;
+                            for (uint32_t i = 0; i < s; i++)
+                                pair_seg += (g.seg[i].count + 1u) >> 1;
+                            g.pairs[2u * (pair_seg + (bl >> 1))] = sg.start + bl;
+                            g.pairs[2u * (pair_seg + (bl >> 1)) + 1u] = bl + 1u < sg.count ? sg.start + bl + 1u : PICK_NONE;
+                        }
                     }
                 return;
             }
