@@ -18,9 +18,7 @@ for s in "$@"; do
     newtests) step newtests 600 python -m pytest tests/test_gpu_chains.py -x -q -m gpu -k "one_launch or oracle or decides or trajectory or runs_of or lanes" ;;
     pairs)    step pairs 500 python -m pytest tests/test_gpu_pairs.py tests/test_gpu_device_proposals.py -x -q -m gpu ;;
     walkab)   step walkab 300 python tools/walk_ab.py ;;
-    walkab_np) LVBGPU_PAIR=0 step walkab_np 300 python tools/walk_ab.py ;;
     walkabm)  step walkabm 300 python tools/walk_ab.py 4096 3075 ;;
-    walkabm_np) LVBGPU_PAIR=0 step walkabm_np 300 python tools/walk_ab.py 4096 3075 ;;
     walkabm_p) LVBGPU_PAIR=2048 step walkabm_p 300 python tools/walk_ab.py 4096 3075 ;;
     walkab_p) LVBGPU_PAIR=2048 step walkab_p 300 python tools/walk_ab.py ;;
     chains)   step chains 400 python -m pytest tests/test_gpu_chains.py -x -q -m gpu ;;
@@ -28,21 +26,12 @@ for s in "$@"; do
     probe1)   step probe1 200 python tools/chains_probe.py 1 ;;
     probe32)  step probe32 200 python tools/chains_probe.py 32 ;;
     probe32q) step probe32q 200 python tools/chains_probe.py 32 --quiet ;;
-    probe32l3q) PROBE_LANES=3 step probe32l3q 200 python tools/chains_probe.py 32 --quiet ;;
     probe32l1) PROBE_LANES=1 step probe32l1 200 python tools/chains_probe.py 32 ;;
     probe32l3) PROBE_LANES=3 step probe32l3 200 python tools/chains_probe.py 32 ;;
     probe32l4) PROBE_LANES=4 step probe32l4 200 python tools/chains_probe.py 32 ;;
-    probe32f4) LVBHOST_SPEC_FACTOR=4 step probe32f4 200 python tools/chains_probe.py 32 --quiet ;;
-    probe32f6) LVBHOST_SPEC_FACTOR=6 step probe32f6 200 python tools/chains_probe.py 32 --quiet ;;
-    probe32f8) LVBHOST_SPEC_FACTOR=8 step probe32f8 200 python tools/chains_probe.py 32 --quiet ;;
-    probe1f6) LVBHOST_SPEC_FACTOR=6 step probe1f6 200 python tools/chains_probe.py 1 --quiet ;;
     probe1r)  PROBE_RUN_LEVELS=3 step probe1r 200 python tools/chains_probe.py 1 ;;
     proposals) step proposals 700 python -m pytest tests/test_gpu_device_proposals.py tests/test_gpu_chains.py tests/test_gpu_pairs.py -x -q -m gpu ;;
-    walkab_nl) LVBGPU_LPT=0 step walkab_nl 300 python tools/walk_ab.py ;;
-    walkabm_nl) LVBGPU_LPT=0 step walkabm_nl 300 python tools/walk_ab.py 4096 3075 ;;
     walkab1k) step walkab1k 300 python tools/walk_ab.py 1024 3075 ;;
-    walkab1k_nl) LVBGPU_LPT=0 step walkab1k_nl 300 python tools/walk_ab.py 1024 3075 ;;
-    probe32q_nl) LVBGPU_LPT=0 step probe32q_nl 200 python tools/chains_probe.py 32 --quiet ;;
     probe32q_p) LVBGPU_PAIR=1024 step probe32q_p 200 python tools/chains_probe.py 32 --quiet ;;
     probe1q_p) LVBGPU_PAIR=64 step probe1q_p 200 python tools/chains_probe.py 1 --quiet ;;
     probe32q_np) LVBGPU_PAIR=0 step probe32q_np 200 python tools/chains_probe.py 32 --quiet ;;
@@ -51,7 +40,6 @@ for s in "$@"; do
     parity)   step parity 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu ;;
     pairq)    step pairq 400 python tools/pair_quality.py ;;
     pairqm)   step pairqm 400 python tools/pair_quality.py 4096 3075 ;;
-    anyorder) step anyorder 60 ./tools/anyorder_probe.bin ;;
     bench)    step bench 600 python bench.py ;;
     benchq)   step benchq 300 python bench.py --no-shapes --no-configs --no-cpu-baseline ;;
     *) echo "unknown step $s"; exit 2 ;;
