@@ -609,7 +609,7 @@ __device__ __forceinline__ void pair_the_drawn(const GenArgs &g, lds_word *const
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __syncthreads(); // the programs are out
     {
-        const uint32_t nall = lane < 16u ? ntok[lane] : 0u; // (0: too long for one chunk, or not a proposal: shares nothing)
+        const uint32_t nall = lane < cnt ? ntok[lane] : 0u; // (0: too long for one chunk, not a proposal, or not drawn: shares nothing)
         const uint32_t nw = (uint32_t)__builtin_amdgcn_readlane((int)nall, (int)wave);
         const uint32_t mine = lane < nw ? tok[wave * PAIR_ROW + nw - 1u - lane] : 0xFFFFFFFEu;
         uint32_t other[8];
