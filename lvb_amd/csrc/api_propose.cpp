@@ -969,6 +969,15 @@ int flush_pending(lvbgpu_ctx *ctx, const GenArgs *gen)
             pa.gen.ready_seq = ctx->post_seq;
             pa.reb.table_ready = (uint32_t *)ctx->d_table_ready.p;
             pa.reb.ready_seq = ctx->post_seq;
+            // test hook: the rebuilding workgroups keep their words to themselves and the waiting ones look only a few
+            // thousand times - what a generating workgroup does when its wait runs out (its candidates become "not
+            // proposals", nothing hangs) is otherwise never seen
+            static const bool withhold = getenv("LVBGPU_DEBUG_WITHHOLD_READY") != nullptr;
+            if (withhold)
+            {
+                pa.reb.withhold_ready = 1u;
+                pa.gen.wait_spins = 4096u;
+            }
         }
         ctx->post_launches_with_generator++;
     }

@@ -222,6 +222,7 @@ struct GenArgs
     unsigned long long *prof;     // LVBGPU_GEN_PROFILE: [256][8] clock stamps of the first candidates (else null)
     const uint32_t *table_ready;  // post launch: [MAX_CHAINS], = ready_seq once that chain's tables have been rebuilt (GenSeg::wait)
     uint32_t ready_seq;
+    uint32_t wait_spins;          // how often a waiting workgroup looks at that word before it gives up (0: 2^24, ~seconds; tests: few)
     int32_t use_lds;              // filled by the launcher
     uint32_t nseg;
     GenSeg seg[MAX_GEN_SEGS];
@@ -265,6 +266,7 @@ struct RebuildArgs
     // stores) and table_ready[chain] = ready_seq says when (null: plain stores, the next launch reads them)
     uint32_t *table_ready;
     uint32_t ready_seq;
+    uint32_t withhold_ready;  // test hook (LVBGPU_DEBUG_WITHHOLD_READY): the words are never set - whoever waits must give up
     uint64_t wait_mask;      // the chains a generator workgroup of this launch waits for (the others' tables leave as plain stores)
     // the new tables are made in LDS (in the layout the generator reads) and copied out in one piece; a chain whose next
     // draw is small is drawn by the rebuilding workgroup itself, straight from there (GenSeg::fused).  0: trees whose

@@ -714,7 +714,7 @@ __device__ __forceinline__ void gen_role(const GenArgs &g, const uint32_t blk, c
             if (threadIdx.x == 0)
                 *agree = 0u;
             __syncthreads();
-            uint32_t budget = 1u << 24; // ~ seconds: a backstop, the rebuild finishes on its own
+            uint32_t budget = g.wait_spins ? g.wait_spins : 1u << 24; // ~ seconds: a backstop, the rebuild finishes on its own
             if (lane == 0)
             {
                 while (__hip_atomic_load(g.table_ready + sg.chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.ready_seq && --budget)
@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void rebuild_role(const RebuildArgs &g, const GatherA
         // every wave's stores acknowledged (written through: in no cache of this chip), then the chain's word
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0)
+        if (tid == 0 && !g.withhold_ready)
             __hip_atomic_store(g.table_ready + chain, g.ready_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -974,3 +974,21 @@ def test_a_step_decides_and_commits_like_the_host_would(mods):
     ctx.chains_collect(0, [8])
     ctx.close()
     ref.close()
+
+
+@pytest.mark.parametrize("pair", ["0", "4"])
+def test_a_generator_that_waits_in_vain_gives_up_and_nothing_hangs(mods, pair):
+    """The post launch's generating workgroups wait for a word of an earlier workgroup of the same launch (their chain's
+    tables are out).  Every wait in a kernel is bounded; what happens when this one runs out is otherwise never seen:
+    LVBGPU_DEBUG_WITHHOLD_READY (a child process - tests/children/withheld_tables.py) keeps the words back.  The candidates
+    of the chains concerned come back as "not proposals", the other chains of the launch are served, nothing hangs, the
+    resident trees stay what the oracle says - with one and (pair = 4) with two candidates per wave, where the workgroup
+    that gives up still has to say who walks with whom."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LVBGPU_DEBUG_WITHHOLD_READY="1", LVBGPU_PAIR=pair)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "children", "withheld_tables.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "withheld ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
