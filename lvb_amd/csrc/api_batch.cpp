@@ -450,6 +450,7 @@ extern "C" int lvbgpu_batch_launch(lvbgpu_ctx *ctx, lvbgpu_batch *b)
             b->own_watch = true;
         }
     }
+    a.watch_starve = ctx->starve_watcher ? 1u : 0u;
     if (b->npairs && !b->direct)
     {
         a.pairs = (const uint32_t *)b->d_pairs.p;

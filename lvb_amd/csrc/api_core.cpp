@@ -118,6 +118,7 @@ int context_common_init(lvbgpu_ctx *ctx, int device, long n, long nwords)
     memset(ctx->h_step.p, 0, 64);
     if (const char *ds = getenv("LVBGPU_DIRECT_STEPS"))
         ctx->direct_steps = ds[0] != '0';
+    ctx->starve_watcher = getenv("LVBGPU_DEBUG_STARVE_WATCHER") != nullptr;
     if (const char *lp = getenv("LVBGPU_LPT"))
         ctx->lpt_order = lp[0] != '0';
     if (const char *pr = getenv("LVBGPU_PAIR")) // n: batches of n candidates and more are walked two candidates per wave (unset / 0: none)

@@ -314,6 +314,7 @@ struct lvbgpu_ctx
     PinBuf h_step;
     uint32_t step_seq = 0;
     bool direct_steps = true; // env LVBGPU_DIRECT_STEPS=0 turns them off (A/B measurements)
+    bool starve_watcher = false; // env LVBGPU_DEBUG_STARVE_WATCHER (test hook, kernels.hpp WalkArgs::watch_starve)
     bool lpt_order = true;    // env LVBGPU_LPT=0: keep big batches in the caller's order on the device
     // the candidates of the last lvbgpu_chains_score_edits call: lvbgpu_chains_commit_edits walks an accepted one's SCORED
     // program (it lies in the batch) instead of building it again

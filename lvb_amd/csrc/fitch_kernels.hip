@@ -89,7 +89,7 @@ __device__ __forceinline__ void watcher_block(const WalkArgs &a, const uint32_t 
     // all 32 waves of the eight extra blocks watch: wave w takes the 64-candidate chunks w, w + 32, ... (one
     // wave alone would take B / 64 dependent round trips AFTER the last walking wave: 35 us at B = 4096)
     constexpr uint32_t WATCHERS = WATCH_WAVES;
-    const unsigned long long want = (unsigned long long)a.ngroups;
+    const unsigned long long want = (unsigned long long)a.ngroups + (a.watch_starve ? 1u : 0u);
     const unsigned long long count_mask = 0xFFFull << WATCH_COUNT_SHIFT;
     bool gave_up = false;
     for (uint32_t base = wid * 64u; base < a.B; base += WATCHERS * 64u)
@@ -98,7 +98,7 @@ __device__ __forceinline__ void watcher_block(const WalkArgs &a, const uint32_t 
         if (i < a.B)
         {
             unsigned long long v;
-            uint32_t budget = 1u << 24; // ~ seconds: every walking wave finishes on its own, this is a backstop
+            uint32_t budget = a.watch_starve ? 4096u : 1u << 24; // ~ seconds: every walking wave finishes on its own, this is a backstop
             while ((((v = __hip_atomic_load(a.len_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & count_mask) >>
                     WATCH_COUNT_SHIFT) != want &&
                    --budget)
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(CO
 // feeds a wave, and a pure-load probe with this shape - half the waves, as many loads fewer as
 // the pairs share - takes proportionally less time (tools/pair_probe.py: 4096 x 28 loads 90.9 us, 2048 x 40 loads
 // 64.7 us).  Who is paired with whom is the producer's business (host: sorted by the program read backwards; device:
-// sorted by a key of the paths' preorder numbers); the wave finds the suffix itself by comparing the two token vectors
-// from the end.  Programs longer than one 64-token chunk are walked alone (b = NONE, or no sharing).
+// every generating workgroup among the sixteen candidates it has drawn); the wave finds the suffix itself by comparing the
+// two token vectors from the end.  Programs longer than one 64-token chunk are walked alone (b = NONE, or no sharing).
 struct WalkState
 {
     uint4 acc;

@@ -106,6 +106,8 @@ struct WalkArgs
     // walking waves pay nothing for it (no returning atomic, no fence, no counter of their own), and a step needs no
     // read-back copy behind the walk.
     uint32_t watcher;
+    uint32_t watch_starve; // test hook (LVBGPU_DEBUG_STARVE_WATCHER): the watchers wait for one wave more than there are and look only
+                           // a few thousand times - they must give up (flag 0xFFFFFFFF) and the host must say so
     // fused commits (COMMIT, tmp_changes != null): the waves accumulate combine k's changes in tmp_changes[k]
     // (zero between launches); the last wave to finish moves them into changes_out[], keeps *s_all_out current
     // with the difference to what those nodes held before, and clears tmp_changes and done_count again - no

@@ -113,3 +113,35 @@ def test_a_wait_gives_up_at_the_contexts_limit(mods):
     with pytest.raises(api.LvbGpuError):
         ctx.set_wait_limit(0.0)
     ctx.close()
+
+
+def test_watcher_waves_that_wait_in_vain_give_up_and_the_host_says_so(mods, monkeypatch):
+    """The walk's lengths reach the host through watcher waves at the end of its grid, which wait for every candidate's
+    waves to have counted themselves in.  That wait is bounded like every other; what happens when it runs out is otherwise
+    never seen: LVBGPU_DEBUG_STARVE_WATCHER (read when a context is created) makes the watchers wait for one wave more than
+    there are and look only a few thousand times.  They give up, the host gets LVBGPU_E_STATE naming the watcher within
+    milliseconds - nothing hangs, the resident tree is untouched - and a context created without the switch is served."""
+    import time
+    api, host = mods
+    rows, _ = host.prepare_alignment(synth.treelike_rows(30, 900, 5))
+    monkeypatch.setenv("LVBGPU_DEBUG_STARVE_WATCHER", "1")
+    starved = api.FitchContext(text_rows=rows)
+    monkeypatch.delenv("LVBGPU_DEBUG_STARVE_WATCHER")
+    plain = api.FitchContext(text_rows=rows)
+    tree = host.HostTree(30, seed=6)
+    length = tree.upload(plain)
+    assert tree.upload(starved) == length
+    want = plain.propose_score(300, -1, 11)
+    for B in (300, 64, 2000):
+        t0 = time.perf_counter()
+        with pytest.raises(api.LvbGpuError) as ei:
+            starved.propose_score(B, -1, 11)
+        assert ei.value.status == -5 and "watcher" in str(ei.value), str(ei.value)
+        assert time.perf_counter() - t0 < 2.0
+    # what does not go through the watchers still works on that context, and its tree is what it was
+    assert starved.current_length() == length
+    cands = [tree.propose(1) for _ in range(9)]
+    assert np.array_equal(starved.score_batch(cands), plain.score_batch(cands))
+    assert np.array_equal(plain.propose_score(300, -1, 11), want)
+    starved.close()
+    plain.close()
